@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference at /root/reference is imported read-only (sys.dont_write_bytecode
+is forced; cv2/imageio, which the hot path never touches, are registered as
+empty modules exactly as SURVEY.md section 8c records).  Weights, rays and random
+draws come from the build-owned generator lush_nerf_amd/synth.py; the reference's
+torch.rand / torch.randn_like calls are served from those draws in call order
+(shape-checked), so fixtures are independent of torch's RNG streams.
+
+Only DATA is written: inputs are regenerated from (seed, shape) recorded in the
+fixture; outputs are the reference's tensors.  Gradients of tensors > 4096
+elements are stored as 8 fixed projections + the L2 norm.
+"""
+import os
+import sys
+import types
+import argparse
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import numpy as np
+import torch
+
+from lush_nerf_amd import synth
+
+for _m in ("cv2", "imageio"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.path.insert(0, REF)
+import models.lushnerf as ref_model          # noqa: E402
+import utils.run_lushnerf_helpers as ref_helpers  # noqa: E402
+
+H, W, FOCAL = synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF
+K = [[FOCAL, 0, W / 2], [0, FOCAL, H / 2], [0, 0, 1]]
+NUM_IMG = 30
+
+
+def build_ref(N_importance, weights, rmnear=80):
+    args = argparse.Namespace(
+        blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+        N_importance=N_importance, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+        rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
+        render_rmnearplane=rmnear)
+    rbk = ref_model.RBK(num_img=NUM_IMG, view_embed_ch=64, D_rbk=4, W_rbk=64, skips_rbk=[4],
+                        num_motion_rbk=4, D_rbk_r=1, W_rbk_r=32, output_ch_rbk_r=3,
+                        D_rbk_v=1, W_rbk_v=32, output_ch_rbk_v=3, D_rbk_w=1, W_rbk_w=32,
+                        rbk_se_rv_window=0.1, use_dpnerf=True, rbk_use_origin=True)
+    net = ref_model.NeRFAll(args, rbk)
+    sd = net.state_dict()
+    new = {}
+    for k in sd:
+        canon = k
+        if k.startswith("blur_kernel_net.RBK."):
+            canon = "mlp_rbk." + k[len("blur_kernel_net.RBK."):]
+        elif k.startswith("blur_kernel_net.view_embed_layer.") or k.startswith("dbk_view_embedding."):
+            canon = "mlp_rbk.view_embedding_layer.view_embed_layer.weight"
+        if canon in weights:
+            new[k] = torch.from_numpy(weights[canon].copy())
+        elif N_importance == 0 and canon.startswith("mlp_fine."):
+            continue
+        else:
+            raise KeyError(k)
+    net.load_state_dict(new, strict=True)
+    return net
+
+
+class ServeDraws:
+    """Serve torch.rand / torch.randn_like from a list of numpy arrays."""
+
+    def __init__(self, seq):
+        self.seq = [torch.from_numpy(np.ascontiguousarray(a)) for a in seq]
+        self.i = 0
+
+    def _next(self, shape):
+        t = self.seq[self.i]
+        assert tuple(t.shape) == tuple(shape), (self.i, t.shape, shape)
+        self.i += 1
+        return t.clone()
+
+    def __enter__(self):
+        self._rand, self._randn_like = torch.rand, torch.randn_like
+        torch.rand = lambda *s, **k: self._next(s[0] if len(s) == 1 and not isinstance(s[0], int) else s)
+        torch.randn_like = lambda x, **k: self._next(x.shape)
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn_like = self._rand, self._randn_like
+        assert self.i == len(self.seq), (self.i, len(self.seq))
+
+
+def proj_vecs(name, numel):
+    return synth.normal((8, numel), 1234, synth._stream("proj." + name)).astype(np.float64)
+
+
+def pack_grads(named_grads):
+    out = {}
+    for k, g in named_grads.items():
+        g = g.detach().numpy()
+        if g.size <= 4096:
+            out["grad." + k] = g
+        else:
+            out["gradproj." + k] = (proj_vecs(k, g.size) @ g.reshape(-1).astype(np.float64))
+            out["gradnorm." + k] = np.array(np.linalg.norm(g.astype(np.float64)))
+    return out
+
+
+def canon_name(k):
+    if k.startswith("blur_kernel_net.RBK."):
+        return "mlp_rbk." + k[len("blur_kernel_net.RBK."):]
+    if k.startswith("blur_kernel_net.view_embed_layer."):
+        return "mlp_rbk.view_embedding_layer.view_embed_layer.weight"
+    return k
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def case_train(name, n_rand, Ns, Ni, force_naive, sharp, seed, allkernel=True):
+    wts = synth.all_weights(NUM_IMG, seed, sharp=sharp, rbk_scale=2.0e4 if not force_naive else 1.0)
+    net = build_ref(Ni, wts)
+    net.train()
+    b = synth.ray_batch(n_rand, seed, NUM_IMG)
+    M = 1 if force_naive else 5
+    d = synth.draws(n_rand * M, Ns, Ni, seed)
+    seq = [d["t_rand"], d["noise_c"]] + ([d["u"], d["noise_f"]] if Ni > 0 else [])
+    rays = torch.from_numpy(b["rays"]).requires_grad_(True)
+    info = {"images_idx": torch.from_numpy(b["images_idx"])}
+    kw = dict(perturb=1., N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False,
+              raw_noise_std=1., inference=False, near=0., far=1.)
+    with ServeDraws(seq):
+        out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info=info, retraw=True,
+                  force_naive=force_naive, allkernel=allkernel,
+                  kernel_pixel=torch.from_numpy(b["fq_mask"]).bool(), **kw)
+    rgb_blur, rgb0_blur, _, noise, _, rgb, rgb0 = out
+    target = torch.from_numpy(b["target"])
+    loss = ref_helpers.img2mse(rgb_blur, target) * 0.5 + ref_helpers.img2l1(rgb_blur, target) * 0.5 \
+        + ref_helpers.img2mse(rgb0_blur, target) * 0.5 + ref_helpers.img2l1(rgb0_blur, target) * 0.5
+    loss.backward()
+    grads = {}
+    seen = set()
+    for k, p in net.named_parameters():
+        ck = canon_name(k)
+        if ck in seen:
+            continue
+        seen.add(ck)
+        if p.grad is not None:
+            grads[ck] = p.grad
+    arrs = dict(meta=np.array([n_rand, Ns, Ni, int(force_naive), int(sharp), seed, int(allkernel)]),
+                rgb_blur=rgb_blur.detach().numpy(), rgb0_blur=rgb0_blur.detach().numpy(),
+                noise=noise.detach().numpy(), loss=np.array(loss.item()),
+                grad_rays=rays.grad.numpy() if rays.grad is not None else np.zeros(0))
+    if not force_naive:
+        arrs.update(rgb=rgb.detach().numpy(), rgb0=rgb0.detach().numpy())
+    arrs.update(pack_grads(grads))
+    arrs["grad_none"] = np.array(sorted(set(canon_name(k) for k, p in net.named_parameters()
+                                            if p.grad is None)))
+    save(name, **arrs)
+
+
+def case_render_rays(name, n_rays, Ns, Ni, train, sharp, seed):
+    """render_infer -> render_rays: the per-ray dict (rgb_map, depth, acc, density, raw, ...)."""
+    wts = synth.all_weights(NUM_IMG, seed, sharp=sharp)
+    net = build_ref(Ni, wts)
+    net.train(train)
+    b = synth.ray_batch(n_rays, seed, NUM_IMG)
+    d = synth.draws(n_rays, Ns, Ni, seed)
+    seq = ([d["t_rand"], d["noise_c"]] + ([d["u"], d["noise_f"]] if Ni > 0 else [])) if train else []
+    kw = dict(perturb=1. if train else 0., N_importance=Ni, N_samples=Ns, use_viewdirs=True,
+              white_bkgd=False, raw_noise_std=1. if train else 0., inference=not train,
+              near=0., far=1., retraw=True)
+    with torch.no_grad(), ServeDraws(seq):
+        (rgb, depth, acc, extras), noise = net.render_infer(
+            H, W, K, 1 << 20, rays=torch.from_numpy(b["rays"]), **kw)
+    arrs = dict(meta=np.array([n_rays, Ns, Ni, int(train), int(sharp), seed]),
+                rgb_map=rgb.numpy(), depth_map=depth.numpy(), acc_map=acc.numpy(),
+                noise_rgb=noise.numpy())
+    for k, v in extras.items():
+        arrs[k] = v.numpy()
+    save(name, **arrs)
+
+
+def case_sample_pdf(seed=5):
+    R, S, Ni = 48, 64, 64
+    bins = np.sort(synth.uniform((R, S - 1), 0, 1, seed, 1), -1)
+    w = synth.uniform((R, S - 2), 0, 1, seed, 2) ** 8        # spiky
+    w[:4] = 0.0                                              # all-zero weights rows
+    w[4:8, 10:] = 0.0
+    u = np.minimum(synth.uniform((R, Ni), 0, 1, seed, 3), np.float32(1 - 2 ** -24))
+    with ServeDraws([u]):
+        s_rand = ref_helpers.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), Ni, det=False)
+    s_det = ref_helpers.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), Ni, det=True)
+    save("sample_pdf", bins=bins, weights=w, u=u, s_rand=s_rand.numpy(), s_det=s_det.numpy())
+
+
+def case_rbk(seed=6):
+    n = 40
+    wts = synth.all_weights(NUM_IMG, seed, rbk_scale=3.0e5)   # rotations up to ~0.5 rad
+    net = build_ref(64, wts)
+    b = synth.ray_batch(n, seed, NUM_IMG)
+    with torch.no_grad():
+        new_rays, ccw = net.mlp_rbk(torch.from_numpy(b["rays"]),
+                                    {"images_idx": torch.from_numpy(b["images_idx"])})
+        o, d = ref_helpers.ndc_rays(H, W, FOCAL, 1., new_rays[..., 0], new_rays[..., 1])
+    save("rbk", meta=np.array([n, seed]), new_rays=new_rays.numpy(), ccw=ccw.numpy(),
+         ndc_o=o.numpy(), ndc_d=d.numpy())
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    case_sample_pdf()
+    case_rbk()
+    case_render_rays("rays_c1_train", 64, 32, 0, True, False, 11)
+    case_render_rays("rays_6464_train_sharp", 48, 64, 64, True, True, 12)
+    case_render_rays("rays_6464_eval_sharp", 48, 64, 64, False, True, 13)
+    case_train("train_naive_sharp", 32, 64, 64, True, True, 21)
+    case_train("train_kernel_sharp", 12, 64, 64, False, True, 22)
+    case_train("train_kernel_default", 12, 64, 64, False, False, 23, allkernel=False)
+    # the imported reference packages must be left untouched (gim/ ships its own
+    # upstream __pycache__ dirs; we never import it)
+    for sub in ("", "models", "utils"):
+        assert not os.path.isdir(os.path.join(REF, sub, "__pycache__")), sub

@@ -1,0 +1,59 @@
+"""Shared helpers for the tests (inputs are regenerated from seeds, never stored)."""
+import os
+
+import numpy as np
+import torch
+
+from lush_nerf_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+H, W, FOCAL, NUM_IMG = synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 30
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def params(seed, sharp=False, rbk_scale=1.0, requires_grad=False, device="cpu"):
+    w = synth.all_weights(NUM_IMG, seed, sharp=sharp, rbk_scale=rbk_scale)
+    return {k: torch.from_numpy(v.copy()).to(device).requires_grad_(requires_grad) for k, v in w.items()}
+
+
+def tdraws(R, Ns, Ni, seed, device="cpu"):
+    return {k: torch.from_numpy(v).to(device) for k, v in synth.draws(R, Ns, Ni, seed).items()}
+
+
+def proj_vecs(name, numel):
+    return synth.normal((8, numel), 1234, synth._stream("proj." + name)).astype(np.float64)
+
+
+def relerr(a, b):
+    """max|a-b| / max(|b|, tiny): the normalised max error used for parity gates."""
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    if isinstance(b, torch.Tensor):
+        b = b.detach().cpu().numpy()
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def check_grads(named_grads, fixture, tol, skip_missing=False):
+    """Compare a {canonical name -> grad tensor/None} dict with a train_* fixture."""
+    worst = {}
+    for key in fixture:
+        if key.startswith("grad.") and not key.startswith("grad_"):
+            k = key[5:]
+            g = named_grads[k].detach().cpu().numpy()
+            worst[k] = relerr(g, fixture[key])
+        elif key.startswith("gradproj."):
+            k = key[9:]
+            g = named_grads[k].detach().cpu().numpy().reshape(-1).astype(np.float64)
+            pr = proj_vecs(k, g.size) @ g
+            nrm = float(fixture["gradnorm." + k])
+            # projections of a vector of norm nrm onto N(0,1) vectors have scale nrm
+            worst[k] = float(np.max(np.abs(pr - fixture[key])) / max(nrm, 1e-30))
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, f"gradient mismatch (normalised max err > {tol}): {bad}"
+    return worst
