@@ -1,0 +1,193 @@
+/* lush_march.h -- C ABI of liblush_march.so: the MI355X (gfx950) ray-march hot
+ * path of LuSh-NeRF.
+ *
+ * The reference has no FFI; its boundary for this path is a set of Python
+ * methods on an nn.Module.  Each entry point below names
+ * the reference code it replaces (file:line into the LuSh-NeRF tree).  The
+ * Python mirror in lush_nerf_amd/ binds these with ctypes and wraps them in
+ * torch.autograd.Function objects that keep the reference signatures.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless marked host;
+ *  - all work is enqueued on `stream` (a hipStream_t); no call synchronises,
+ *    allocates device memory, or keeps state between calls;
+ *  - return value 0 = ok, negative = error; lush_last_error() gives a
+ *    thread-local message;
+ *  - tensors are fp32, row-major, contiguous, with the shapes shown;
+ *  - "accumulate" outputs are added to, everything else is overwritten.
+ */
+#ifndef LUSH_MARCH_H
+#define LUSH_MARCH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lush_stream_t;
+
+const char* lush_last_error(void);
+int lush_abi_version(void);
+
+/* ------------------------------------------------------------------ sampling
+ * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
+ * rays [R][11] = [o(3) d(3) near far viewdir(3)]; t_rand [R][S] or NULL
+ * (perturb == 0); z [R][S]. */
+int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z,
+               lush_stream_t stream);
+/* z of sample `index` of the un-jittered grid (the noise MLP's point,
+ * models/lushnerf.py:271, 396, 612): z [R]. */
+int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* z, lush_stream_t stream);
+
+/* ---------------------------------------------------------------- compositing
+ * NeRFAll.raw2outputs, models/lushnerf.py:296-352.  raw [R][S][4]; noise [R][S-1]
+ * N(0,1) draws or NULL; near_mask < 0 disables the eval-only near-plane mask
+ * (:331-335), otherwise density is zeroed where z[j+1] <= near_mask.
+ * Outputs rgb [R][3], depth [R], acc [R], weights [R][S], density [R][S-1]. */
+int lush_composite_fwd(const float* raw, const float* z, const float* rays, int R, int S,
+                       const float* noise, float noise_std, float near_mask, int white_bkgd,
+                       float* rgb, float* depth, float* acc, float* weights, float* density,
+                       lush_stream_t stream);
+/* Backward of the above w.r.t. raw and rays_d.  g_* may be NULL (= 0).
+ * draw [R][S][4] overwritten; drays [R][11] accumulate (columns 3..5). */
+int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S,
+                       const float* noise, float noise_std, float near_mask, int white_bkgd,
+                       const float* g_rgb, const float* g_depth, const float* g_acc,
+                       float* draw, float* drays, lush_stream_t stream);
+
+/* ------------------------------------------------------ hierarchical sampling
+ * sample_pdf (utils/run_lushnerf_helpers.py:566-609) on bins = mid-points and
+ * weights[1:-1], followed by sort(cat(z, z_samples)) (models/lushnerf.py:435-440,
+ * 544-549).  u [R][Ni] U[0,1) draws, or NULL for the deterministic linspace.
+ * z_out [R][S+Ni] sorted; z_samples [R][Ni] (may be NULL); z_std [R] =
+ * std(z_samples, unbiased=False) (:465). */
+int lush_sample_merge(const float* z, const float* weights, int R, int S, int Ni, const float* u,
+                      float* z_out, float* z_samples, float* z_std, lush_stream_t stream);
+
+/* ------------------------------------------------------------- ray prologue
+ * The shared head of render_infer / render_train_scene / render_train_noise
+ * (models/lushnerf.py:706-729, 772-795, 827-850) with ndc_rays
+ * (utils/run_lushnerf_helpers.py:542-562): rays [N][3][2] -> batch [N][11].
+ * cx = -1/(W/(2 focal)), cy = -1/(H/(2 focal)) rounded to fp32 by the caller. */
+int lush_pack_rays_fwd(const float* rays, int N, int ndc, float cx, float cy, float near, float far,
+                       float* batch, lush_stream_t stream);
+/* dbatch [N][11] -> drays [N][3][2] (overwritten). */
+int lush_pack_rays_bwd(const float* rays, int N, int ndc, float cx, float cy, const float* dbatch,
+                       float* drays, lush_stream_t stream);
+
+/* ----------------------------------------------------------- blur kernel (RBK)
+ * View_Embedding + Rigid_Blurring_Kernel.forward trunk/heads,
+ * models/lushnerf.py:27-35, 118-148.  The MLP input is the image embedding only,
+ * so it is evaluated once per IMAGE (num_img rows), not once per ray. */
+typedef struct {
+    const float* embed;              /* [num_img][64] */
+    const float* w_trunk[4];         /* [64][64] */
+    const float* b_trunk[4];
+    const float *w_rb, *b_rb, *w_vb, *b_vb, *w_wb, *b_wb;   /* branches [32][64] */
+    const float *w_r, *b_r, *w_v, *b_v;                     /* heads [3M][32] */
+    const float *w_w, *b_w;                                 /* [M+1][32] */
+} lush_rbk_params;
+typedef struct {
+    float* embed;
+    float* w_trunk[4];
+    float* b_trunk[4];
+    float *w_rb, *b_rb, *w_vb, *b_vb, *w_wb, *b_wb;
+    float *w_r, *b_r, *w_v, *b_v;
+    float *w_w, *b_w;
+} lush_rbk_grads;
+#define LUSH_RBK_ACT_STRIDE 512      /* floats per image in `acts` */
+#define LUSH_RBK_RVW_STRIDE 32       /* r(12) v(12) w(5) pad(3) */
+/* acts [num_img][512] (hidden activations + r, v, w). */
+int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts,
+                     lush_stream_t stream);
+/* d_rvw [num_img][32] = gradients w.r.t. r(12), v(12), normalised w(5).
+ * All of `g` is overwritten; scratch >= num_img*512 floats. */
+int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
+                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, lush_stream_t stream);
+/* rbk_warp (models/lushnerf.py:75-98) + SE3Field.warp (utils/rigid_warping.py:20-140):
+ * rays [N][3][2], idx [N] int64 -> new_rays [N*(M+1)][3][2] (slot 0 = input ray),
+ * ccw [N][M+1]. */
+int lush_rbk_warp_fwd(const float* rays, const int64_t* idx, int N, int M, const float* acts,
+                      float* new_rays, float* ccw, lush_stream_t stream);
+/* mask [N] (uint8) or NULL: rays whose mask is 0 pass no gradient through
+ * new_rays (the allkernel torch.where(..., x, x.detach()), models/lushnerf.py:641-643).
+ * d_rvw [num_img][32] accumulate (must be zeroed by the caller); drays [N][3][2]
+ * overwritten, may be NULL. */
+int lush_rbk_warp_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts,
+                      const float* dnew_rays, const float* dccw, const uint8_t* mask,
+                      float* d_rvw, float* drays, lush_stream_t stream);
+
+/* ------------------------------------------------------- blur mix and tone map
+ * rbk_weighted_sum (models/lushnerf.py:100-116): x [N*M][C], ccw [N][M] -> y [N][C]. */
+int lush_wsum_fwd(const float* x, const float* ccw, int N, int M, int C, float* y, lush_stream_t stream);
+int lush_wsum_bwd(const float* x, const float* ccw, int N, int M, int C, const float* dy,
+                  float* dx, float* dccw, lush_stream_t stream);          /* dccw accumulate */
+/* y = (add ? x + 0.1*sigmoid(nraw) : x) ** (1/2.2) when gamma, else without the
+ * power (ToneMapping 'gamma'/'none', utils/run_lushnerf_helpers.py:164-174, and
+ * models/lushnerf.py:649, 654).  x [n][3]; nraw [n][3] or NULL. */
+int lush_tonemap_fwd(const float* x, const float* nraw, int n, int gamma, float* y, lush_stream_t stream);
+int lush_tonemap_bwd(const float* x, const float* nraw, int n, int gamma, const float* dy,
+                     float* dx, float* dnraw, lush_stream_t stream);      /* dx, dnraw accumulate */
+/* y = 0.1*sigmoid(x), models/lushnerf.py:649, 660. */
+int lush_noise_act_fwd(const float* x, int n, float* y, lush_stream_t stream);
+int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_stream_t stream); /* accumulate */
+/* Training loss of run_lushnerf.py:652-661: sum over the two colours of
+ * 0.5*MSE + 0.5*L1 against target [n][3].  loss[0] accumulate (zero it first);
+ * ga / gb = d loss / d a, d loss / d b (overwritten). */
+int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float* loss,
+                      float* ga, float* gb, lush_stream_t stream);
+
+/* ------------------------------------------------------------------- the MLPs
+ * Embedder + NeRF.forward / NeRF_Noise.forward behind NeRFAll.mlpforward /
+ * mlpforward_noise (utils/run_lushnerf_helpers.py:334-344, 394-423, 483-512;
+ * models/lushnerf.py:234-293).
+ * net 0 = NeRF (D=8, W=256, skip after layer 4), net 1 = NeRF_Noise (D=4, W=128).
+ * planes = bf16 planes per operand: 1 plain bf16, 2 parity mode (~2^-17), 3 ~fp32. */
+typedef struct {
+    const float* w[8];
+    const float* b[8];
+    const float *w_feat, *b_feat, *w_alpha, *b_alpha, *w_views, *b_views, *w_rgb, *b_rgb;
+} lush_mlp_params;
+typedef struct {
+    float* w[8];
+    float* b[8];
+    float *w_feat, *b_feat, *w_alpha, *b_alpha, *w_views, *b_views, *w_rgb, *b_rgb;
+} lush_mlp_grads;
+
+size_t lush_mlp_packed_bytes(int net, int planes);
+/* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */
+int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream);
+/* Bytes of the activation stash for P points (forward -> backward) and of the
+ * dZ workspace used inside lush_mlp_bwd. */
+size_t lush_mlp_stash_bytes(int net, int planes, long long P);
+size_t lush_mlp_dstash_bytes(int net, int planes, long long P);
+/* rays [R][11], z [R][S] -> raw [R*S][4] (rgb raw x3, sigma raw; sigma = 0 for
+ * net 1).  stash may be NULL (inference: nothing saved). */
+int lush_mlp_fwd(int net, int planes, const float* rays, const float* z, int R, int S,
+                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash,
+                 lush_stream_t stream);
+/* Backward: draw [R*S][4] -> parameter gradients (accumulate, fp32 atomics) and
+ * dpts [R*S][8] = d/dpoint (3), 0, d/dviewdir (3), 0 (overwritten).
+ * planes_b <= planes_f; packed_b holds planes_b planes. */
+int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                 const void* packed_b, const lush_mlp_params* prm, const float* draw,
+                 const void* stash, void* dstash, const lush_mlp_grads* grads, float* dpts,
+                 lush_stream_t stream);
+/* d rays from d points: pts = o + d*z (models/lushnerf.py:414, 525).  dpts [R*S][8]
+ * -> drays [R][11] accumulate (o: 0..2, d: 3..5, viewdir: 8..10). */
+int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays,
+                         lush_stream_t stream);
+
+/* ---------------------------------------------------------------------- Adam
+ * torch.optim.Adam step on a flat segment (run_lushnerf.py:368-371, 675-685). */
+int lush_adam(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1,
+              float beta2, float eps, int step, float grad_scale, lush_stream_t stream);
+
+/* Test hooks (tests/ only): raw access to a stash array for layer-wise parity. */
+int lush_debug_stash_layout(int net, int planes, long long P, long long* offsets /* host, 16 entries */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

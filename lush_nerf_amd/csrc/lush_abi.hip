@@ -1,0 +1,250 @@
+// lush-march: C ABI of the fused MLP path (pack plan, stash layout, launch order).
+#include "lush_common.h"
+#include "lush_host.h"
+#include "../../include/lush_march.h"
+
+using namespace lush;
+
+namespace {
+
+struct NetInfo { int HW, NL, SKIP, HV, NRB, total_entries; };
+template <class N> NetInfo info_of() { return {N::HW, N::NL, N::SKIP, N::HV, N::NRB, N::total_entries}; }
+bool net_info(int net, NetInfo& o) {
+    if (net == 0) { o = info_of<NetNerf>(); return true; }
+    if (net == 1) { o = info_of<NetNoise>(); return true; }
+    return false;
+}
+
+constexpr int MT = 64;
+inline long long pad_pts(long long P) { return (P + MT - 1) / MT * MT; }
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Byte offsets inside the forward stash.
+struct StashLayout {
+    size_t mask, pe, h[NET_MAX_LAYERS], feat, hv, total;
+    long long Ppad, n_tiles;
+};
+StashLayout stash_layout(const NetInfo& n, int ns, long long P) {
+    StashLayout L{};
+    L.Ppad = pad_pts(P);
+    L.n_tiles = L.Ppad / MT;
+    size_t off = 0;
+    L.mask = off; off += al256((size_t)L.n_tiles * (n.NL + 1) * n.NRB * (MT / 32) * 16 * 8);
+    L.pe = off;   off += al256((size_t)ns * L.Ppad * PE_ROW * 2);
+    for (int l = 0; l < n.NL; ++l) { L.h[l] = off; off += al256((size_t)ns * L.Ppad * n.HW * 2); }
+    L.feat = off; off += al256((size_t)ns * L.Ppad * n.HW * 2);
+    L.hv = off;   off += al256((size_t)ns * L.Ppad * n.HV * 2);
+    L.total = off;
+    return L;
+}
+struct DStashLayout { size_t dz[NET_MAX_LAYERS], dfeat, dzv, total; };
+DStashLayout dstash_layout(const NetInfo& n, int ns, long long P) {
+    DStashLayout L{};
+    const long long Ppad = pad_pts(P);
+    size_t off = 0;
+    for (int l = 0; l < n.NL; ++l) { L.dz[l] = off; off += al256((size_t)ns * Ppad * n.HW * 2); }
+    L.dfeat = off; off += al256((size_t)ns * Ppad * n.HW * 2);
+    L.dzv = off;   off += al256((size_t)ns * Ppad * n.HV * 2);
+    L.total = off;
+    return L;
+}
+
+MlpParams to_params(const lush_mlp_params* p) {
+    MlpParams q;
+    for (int i = 0; i < NET_MAX_LAYERS; ++i) { q.w[i] = p->w[i]; q.b[i] = p->b[i]; }
+    q.w_feat = p->w_feat; q.b_feat = p->b_feat; q.w_alpha = p->w_alpha; q.b_alpha = p->b_alpha;
+    q.w_views = p->w_views; q.b_views = p->b_views; q.w_rgb = p->w_rgb; q.b_rgb = p->b_rgb;
+    return q;
+}
+
+template <class N>
+void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP;
+    T.n = 0;
+    blocks = 0;
+    auto add = [&](const float* src, int sr, int sk, int rows, int cols, int nrb, int kk, int dst) {
+        PackJob& j = T.j[T.n++];
+        j.src = src; j.sr = sr; j.sk = sk; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk;
+        j.dst_entry = dst; j.first_block = blocks;
+        blocks += nrb * kk;
+    };
+    const int XV = PE_X_VALID, DV = PE_D_VALID;
+    // forward
+    add(p->w[0], XV, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(0, false));
+    for (int l = 1; l < NL; ++l) {
+        if (l == SK) {
+            add(p->w[l], XV + HW, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(l, false));
+            add(p->w[l] + XV, XV + HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_L(l, true));
+        } else {
+            add(p->w[l], HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_L(l, true));
+        }
+    }
+    add(p->w_feat, HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_FEAT);
+    add(p->w_alpha, HW, 1, 1, HW, 1, N::KKH, N::fwd_ALPHA);
+    add(p->w_views, HW + DV, 1, HV, HW, N::NRBV, N::KKH, N::fwd_VA);
+    add(p->w_views + HW, HW + DV, 1, HV, DV, N::NRBV, N::KKD, N::fwd_VB);
+    add(p->w_rgb, HV, 1, 3, HV, 1, N::KKV, N::fwd_RGB);
+    // transposed: element (row, k) = W[k][c0 + row]
+    add(p->w_views, 1, HW + DV, HW, HV, N::NRB, N::KKV, N::bwd_VAT);
+    add(p->w_views + HW, 1, HW + DV, DV, HV, 1, N::KKV, N::bwd_VBT);
+    add(p->w_feat, 1, HW, HW, HW, N::NRB, N::KKH, N::bwd_FEATT);
+    for (int l = NL - 1; l >= 1; --l) {
+        if (l == SK) {
+            add(p->w[l], 1, XV + HW, XV, HW, 2, N::KKH, N::bwd_LT(l, false));
+            add(p->w[l] + XV, 1, XV + HW, HW, HW, N::NRB, N::KKH, N::bwd_LT(l, true));
+        } else {
+            add(p->w[l], 1, HW, HW, HW, N::NRB, N::KKH, N::bwd_LT(l, true));
+        }
+    }
+    add(p->w[0], 1, XV, XV, HW, 2, N::KKH, N::bwd_LT(0, false));
+}
+
+int dw_splits(long long Ppad, int tiles) {
+    int s = 1024 / tiles;
+    const long long max_s = Ppad / 32;
+    if (s > max_s) s = (int)max_s;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t lush_mlp_packed_bytes(int net, int planes) {
+    NetInfo n;
+    if (!net_info(net, n) || planes < 1 || planes > 3) return 0;
+    return (size_t)n.total_entries * planes * 1024;
+}
+
+int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream) {
+    PackTable T;
+    int blocks = 0;
+    if (net == 0) build_pack_table<NetNerf>(prm, T, blocks);
+    else if (net == 1) build_pack_table<NetNoise>(prm, T, blocks);
+    else return set_error("lush_mlp_pack: bad net");
+    return launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+}
+
+size_t lush_mlp_stash_bytes(int net, int planes, long long P) {
+    NetInfo n;
+    if (!net_info(net, n)) return 0;
+    return stash_layout(n, planes, P).total;
+}
+size_t lush_mlp_dstash_bytes(int net, int planes, long long P) {
+    NetInfo n;
+    if (!net_info(net, n)) return 0;
+    return dstash_layout(n, planes, P).total;
+}
+
+int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
+    NetInfo n;
+    if (!net_info(net, n)) return set_error("bad net");
+    const StashLayout L = stash_layout(n, planes, P);
+    o[0] = (long long)L.mask; o[1] = (long long)L.pe;
+    for (int l = 0; l < NET_MAX_LAYERS; ++l) o[2 + l] = l < n.NL ? (long long)L.h[l] : -1;
+    o[10] = (long long)L.feat; o[11] = (long long)L.hv; o[12] = L.Ppad; o[13] = (long long)L.total;
+    o[14] = n.HW; o[15] = n.NL;
+    return 0;
+}
+
+int lush_mlp_fwd(int net, int planes, const float* rays, const float* z, int R, int S, const void* packed,
+                 const lush_mlp_params* prm, float* raw, void* stash, lush_stream_t stream) {
+    NetInfo n;
+    if (!net_info(net, n)) return set_error("lush_mlp_fwd: bad net");
+    if (planes < 1 || planes > 3) return set_error("lush_mlp_fwd: planes must be 1..3");
+    if (R <= 0 || S <= 0) return set_error("lush_mlp_fwd: empty batch");
+    const long long P = (long long)R * S;
+    const StashLayout L = stash_layout(n, planes, P);
+    MlpFwdArgs a{};
+    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)L.n_tiles;
+    if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
+    a.wpk = (const uint4*)packed;
+    a.prm = to_params(prm);
+    a.raw = raw;
+    a.write_stash = stash != nullptr;
+    if (stash) {
+        char* b = (char*)stash;
+        a.st.mask = (unsigned long long*)(b + L.mask);
+        a.st.pe = (__bf16*)(b + L.pe);
+        for (int l = 0; l < n.NL; ++l) a.st.h[l] = (__bf16*)(b + L.h[l]);
+        a.st.feat = (__bf16*)(b + L.feat);
+        a.st.hv = (__bf16*)(b + L.hv);
+        a.st.plane_pe = L.Ppad * PE_ROW; a.st.plane_h = L.Ppad * n.HW; a.st.plane_hv = L.Ppad * n.HV;
+    }
+    const int grid = (int)(L.n_tiles < 1024 ? L.n_tiles : 1024);
+    return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
+}
+
+int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                 const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
+                 void* dstash, const lush_mlp_grads* g, float* dpts, lush_stream_t stream) {
+    NetInfo n;
+    if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
+    if (planes_b < 1 || planes_b > planes_f || planes_f > 3) return set_error("lush_mlp_bwd: need 1 <= planes_b <= planes_f <= 3");
+    if (!stash || !dstash) return set_error("lush_mlp_bwd: stash and dstash are required");
+    const long long P = (long long)R * S;
+    const StashLayout L = stash_layout(n, planes_f, P);
+    const DStashLayout D = dstash_layout(n, planes_b, P);
+    hipStream_t st = (hipStream_t)stream;
+    const char* sb = (const char*)stash;
+    char* db = (char*)dstash;
+    const long long plane_h = L.Ppad * n.HW, plane_hv = L.Ppad * n.HV, plane_pe = L.Ppad * PE_ROW;
+
+    MlpBwdArgs a{};
+    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)L.n_tiles;
+    a.wpk = (const uint4*)packed_b;
+    a.prm = to_params(prm);
+    a.draw = draw;
+    a.mask = (const unsigned long long*)(sb + L.mask);
+    for (int l = 0; l < n.NL; ++l) a.dz[l] = (__bf16*)(db + D.dz[l]);
+    a.dfeat = (__bf16*)(db + D.dfeat);
+    a.dzv = (__bf16*)(db + D.dzv);
+    a.plane_h = plane_h; a.plane_hv = plane_hv;
+    a.dpts = dpts;
+    const int grid = (int)(L.n_tiles < 1024 ? L.n_tiles : 1024);
+    int rc = launch_mlp_bwd(net, planes_b, a, grid, st);
+    if (rc) return rc;
+
+    const __bf16* pe = (const __bf16*)(sb + L.pe);
+    auto H = [&](int l) { return (const __bf16*)(sb + L.h[l]); };
+    const int XV = PE_X_VALID, DV = PE_D_VALID;
+    auto dw = [&](const __bf16* Z, long long zplane, int ldz, int n_out, const __bf16* X, long long xplane, int ldx,
+                  int xcol0, int k_in, float* dW, int ldw, int wcol0, float* dbias) {
+        DwArgs d{};
+        d.Z = Z; d.z_plane = zplane; d.ldz = ldz; d.n_out = n_out;
+        d.X = X; d.x_plane = xplane; d.ldx = ldx; d.xcol0 = xcol0; d.k_in = k_in;
+        d.dW = dW; d.ldw = ldw; d.wcol0 = wcol0; d.db = dbias;
+        d.Ppad = (int)L.Ppad;
+        const int tiles = ((n_out + 127) / 128) * ((k_in + 127) / 128);
+        const int splits = dw_splits(L.Ppad, tiles);
+        long long pps = (L.Ppad + splits - 1) / splits;
+        pps = (pps + 31) / 32 * 32;
+        d.pts_per_split = (int)pps;
+        const int real_splits = (int)((L.Ppad + pps - 1) / pps);
+        return launch_dw(planes_b, d, real_splits, st);
+    };
+    for (int l = 0; l < n.NL && !rc; ++l) {
+        const __bf16* Z = a.dz[l];
+        if (l == 0) {
+            rc = dw(Z, plane_h, n.HW, n.HW, pe, plane_pe, PE_ROW, 0, XV, g->w[0], XV, 0, g->b[0]);
+        } else if (l == n.SKIP) {
+            rc = dw(Z, plane_h, n.HW, n.HW, pe, plane_pe, PE_ROW, 0, XV, g->w[l], XV + n.HW, 0, g->b[l]);
+            if (!rc) rc = dw(Z, plane_h, n.HW, n.HW, H(l - 1), plane_h, n.HW, 0, n.HW, g->w[l], XV + n.HW, XV, nullptr);
+        } else {
+            rc = dw(Z, plane_h, n.HW, n.HW, H(l - 1), plane_h, n.HW, 0, n.HW, g->w[l], n.HW, 0, g->b[l]);
+        }
+    }
+    if (rc) return rc;
+    rc = dw(a.dfeat, plane_h, n.HW, n.HW, H(n.NL - 1), plane_h, n.HW, 0, n.HW, g->w_feat, n.HW, 0, g->b_feat);
+    if (rc) return rc;
+    const __bf16* feat = (const __bf16*)(sb + L.feat);
+    rc = dw(a.dzv, plane_hv, n.HV, n.HV, feat, plane_h, n.HW, 0, n.HW, g->w_views, n.HW + DV, 0, g->b_views);
+    if (rc) return rc;
+    rc = dw(a.dzv, plane_hv, n.HV, n.HV, pe, plane_pe, PE_ROW, PE_X, DV, g->w_views, n.HW + DV, n.HW, nullptr);
+    if (rc) return rc;
+    const __bf16* hv = (const __bf16*)(sb + L.hv);
+    return launch_head_dw(planes_b, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
+                          net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// lush-march: shared device helpers (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lush {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;   // 8 bytes
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator block
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int WAVE = 64;
+constexpr int MAX_PLANES = 3;
+
+// Positional-encoding image: one 256-byte row (128 bf16) per point and plane.
+//   cols 0..62   gamma(x)  (x, then per frequency sin xyz, cos xyz), col 63 = 0
+//   cols 64..90  gamma(d)  (same order, 4 frequencies),             cols 91..95 = 0
+//   cols 96..127 never read (keeps the XOR swizzle inside one 256-B row)
+constexpr int PE_X = 64;
+constexpr int PE_D = 32;
+constexpr int PE_ROW = 128;
+constexpr int PE_X_VALID = 63;
+constexpr int PE_D_VALID = 27;
+constexpr int L_X = 10;   // multires        (utils/run_lushnerf_helpers.py:347-361)
+constexpr int L_D = 4;    // multires_views
+
+// Row of a 32x32 MFMA accumulator held in register q of a lane in half h
+// (cdna_hip_programming.md section 3: row=(reg&3)+8*(reg>>2)+4*(lane>>5)).
+__device__ __forceinline__ constexpr int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// Byte offset of 16-byte chunk `chunk` of row `row` in an XOR-swizzled LDS image
+// whose rows are a multiple of 256 bytes (T2 swizzle: conflict-free ds_read_b128
+// when the 32 lanes of a half-wave read 32 different rows at the same chunk).
+__device__ __forceinline__ int swz(int row, int chunk, int row_bytes) {
+    return row * row_bytes + ((chunk ^ (row & 15)) << 4);
+}
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
+
+// Split x into NS bf16 planes: x ~= p0 + p1 (+ p2), each the round-to-nearest
+// bf16 of the running remainder.  Two planes carry 16 mantissa bits, three 24.
+template <int NS>
+__device__ __forceinline__ void split_planes(float x, __bf16 (&p)[NS]) {
+    float r = x;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        p[i] = (__bf16)r;
+        if (i + 1 < NS) r = r - (float)p[i];
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// acc += sum over plane pairs of A_i * B_j keeping every product of order
+// <= 2^-8(NS-1): NS=1 -> 1 MFMA, NS=2 -> 3, NS=3 -> 6.  Small terms first.
+template <int NS>
+__device__ __forceinline__ f32x16 mfma_planes(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x16 c) {
+    if constexpr (NS == 3) {
+        c = mfma_bf16(a[1], b[1], c);
+        c = mfma_bf16(a[2], b[0], c);
+        c = mfma_bf16(a[0], b[2], c);
+    }
+    if constexpr (NS >= 2) {
+        c = mfma_bf16(a[1], b[0], c);
+        c = mfma_bf16(a[0], b[1], c);
+    }
+    c = mfma_bf16(a[0], b[0], c);
+    return c;
+}
+
+__host__ __device__ constexpr int mfma_per_product(int ns) { return ns == 1 ? 1 : (ns == 2 ? 3 : 6); }
+
+// wave64 reductions / scans -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+
+}  // namespace lush

@@ -1,0 +1,28 @@
+// lush-march: host-side helpers shared by the launch translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lush_mlp.h"
+
+namespace lush {
+
+int set_error(const char* msg);                 // stores a thread-local message, returns -1
+int set_hip_error(hipError_t e, const char* what, const char* file, int line);
+
+#define LUSH_HIP(expr)                                                              \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) return ::lush::set_hip_error(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+// lush_mlp.hip
+size_t mlp_fwd_lds_bytes(int hw, int ns, int mt);
+size_t mlp_bwd_lds_bytes(int hw, int ns, int mt);
+int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s);
+int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s);
+int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
+int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);
+int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
+                   const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
+                   float* db_alpha, hipStream_t s);
+
+}  // namespace lush

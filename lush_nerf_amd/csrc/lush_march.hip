@@ -1,0 +1,876 @@
+// lush-march: ray-level kernels (everything around the MLPs) + their C ABI.
+// One wavefront (64 lanes) owns one ray: 64 coarse samples map 1:1 onto lanes and
+// scans/reductions along the ray are wave-level shuffles.
+#include "lush_common.h"
+#include "lush_host.h"
+#include "../../include/lush_march.h"
+
+#include <cmath>
+#include <string>
+
+namespace lush {
+
+static thread_local std::string g_err;
+int set_error(const char* msg) { g_err = msg; return -1; }
+int set_hip_error(hipError_t e, const char* what, const char* file, int line) {
+    g_err = std::string(hipGetErrorString(e)) + " in " + what + " at " + file + ":" + std::to_string(line);
+    return -2;
+}
+
+constexpr int RAYS_PER_BLOCK = 4;   // 4 waves per workgroup, one ray each
+
+// torch.linspace(0, 1, n)[i] as ATen computes it in fp32
+// (aten/src/ATen/native/RangeFactories: step=(end-start)/(n-1); first half counts
+// up from start, second half counts down from end).
+__device__ __forceinline__ float linspace01(int i, int n) {
+    if (n == 1) return 0.f;
+    const float step = 1.0f / (float)(n - 1);
+    // the count-down half is one fused multiply-add in ATen's vectorised kernel (verified bit-exact
+    // against torch.linspace for n = 2..256)
+    return i < n / 2 ? __fmul_rn(step, (float)i) : __fmaf_rn(-step, (float)(n - 1 - i), 1.0f);
+}
+
+__device__ __forceinline__ float zgrid_at(float near, float far, int i, int S, int lindisp) {
+    const float t = linspace01(i, S);
+    if (!lindisp) return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+    return 1.f / __fadd_rn(__fmul_rn(1.f / near, __fsub_rn(1.f, t)), __fmul_rn(1.f / far, t));
+}
+
+// --------------------------------------------------------------------- z grid
+__global__ void zgrid_kernel(const float* __restrict__ rays, int R, int S, int lindisp,
+                             const float* __restrict__ t_rand, float* __restrict__ z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)R * S) return;
+    const int ray = (int)(i / S), s = (int)(i % S);
+    const float near = rays[ray * 11 + 6], far = rays[ray * 11 + 7];
+    const float zc = zgrid_at(near, far, s, S, lindisp);
+    if (t_rand == nullptr) { z[i] = zc; return; }
+    const float zl = s > 0 ? zgrid_at(near, far, s - 1, S, lindisp) : zc;
+    const float zr = s < S - 1 ? zgrid_at(near, far, s + 1, S, lindisp) : zc;
+    const float lower = s > 0 ? __fmul_rn(.5f, __fadd_rn(zc, zl)) : zc;
+    const float upper = s < S - 1 ? __fmul_rn(.5f, __fadd_rn(zr, zc)) : zc;
+    z[i] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[i]));
+}
+
+__global__ void zfixed_kernel(const float* __restrict__ rays, int R, int S, int index, int lindisp,
+                              float* __restrict__ z) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray < R) z[ray] = zgrid_at(rays[ray * 11 + 6], rays[ray * 11 + 7], index, S, lindisp);
+}
+
+// ---------------------------------------------------------------- compositing
+// Lane l owns samples l*SPL .. l*SPL+SPL-1.
+struct CompIn {
+    const float *raw, *z, *rays, *noise;
+    int R, S;
+    float noise_std, near_mask;
+    int white_bkgd;
+};
+
+template <int SPL>
+__device__ __forceinline__ void comp_load(const CompIn& c, int ray, int lane, float (&alpha)[SPL], float (&dist)[SPL],
+                                          float (&dens)[SPL], float (&gate)[SPL], float (&zz)[SPL],
+                                          float (&rgbv)[SPL][3], float& norm) {
+    const float* rr = c.rays + (long long)ray * 11;
+    norm = sqrtf(rr[3] * rr[3] + rr[4] * rr[4] + rr[5] * rr[5]);
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        const int j = lane * SPL + e;
+        alpha[e] = 0.f; dist[e] = 0.f; dens[e] = 0.f; gate[e] = 0.f; zz[e] = 0.f;
+        rgbv[e][0] = rgbv[e][1] = rgbv[e][2] = 0.f;
+        if (j < c.S) {
+            const long long p = (long long)ray * c.S + j;
+            const float4 rw = *reinterpret_cast<const float4*>(c.raw + p * 4);
+            zz[e] = c.z[p];
+            rgbv[e][0] = 1.f / (1.f + expf(-rw.x));
+            rgbv[e][1] = 1.f / (1.f + expf(-rw.y));
+            rgbv[e][2] = 1.f / (1.f + expf(-rw.z));
+            if (j < c.S - 1) {
+                const float znext = c.z[p + 1];
+                dist[e] = (znext - zz[e]) * norm;
+                float pre = rw.w;
+                if (c.noise != nullptr && c.noise_std > 0.f)
+                    pre += c.noise[(long long)ray * (c.S - 1) + j] * c.noise_std;
+                float g = pre > 0.f ? 1.f : 0.f;
+                float d = fmaxf(pre, 0.f);
+                if (c.near_mask >= 0.f && !(znext > c.near_mask)) { d = 0.f; g = 0.f; }
+                dens[e] = d; gate[e] = g;
+                alpha[e] = 1.f - expf(-d * dist[e]);
+            } else {
+                alpha[e] = 1.f;   // last sample: models/lushnerf.py:338
+            }
+        }
+    }
+}
+
+// transmittance T_j = prod_{k<j} (1 - alpha_k)
+template <int SPL>
+__device__ __forceinline__ void comp_trans(const float (&alpha)[SPL], int lane, float (&T)[SPL]) {
+    float loc = 1.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) { T[e] = loc; loc *= (1.f - alpha[e]); }
+    float incl = wave_incl_prod(loc, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) T[e] *= excl;
+}
+
+template <int SPL>
+__global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_fwd_kernel(CompIn c, float* __restrict__ rgb,
+        float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ density) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= c.R) return;
+    float alpha[SPL], dist[SPL], dens[SPL], gate[SPL], zz[SPL], col[SPL][3], T[SPL], norm;
+    comp_load<SPL>(c, ray, lane, alpha, dist, dens, gate, zz, col, norm);
+    comp_trans<SPL>(alpha, lane, T);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+        const int j = lane * SPL + e;
+        const float wgt = alpha[e] * T[e];
+        if (j < c.S) {
+            if (weights) weights[(long long)ray * c.S + j] = wgt;
+            if (density && j < c.S - 1) density[(long long)ray * (c.S - 1) + j] = dens[e];
+        }
+        s0 += wgt * col[e][0]; s1 += wgt * col[e][1]; s2 += wgt * col[e][2];
+        sd += wgt * zz[e]; sa += wgt;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); sd = wave_sum(sd); sa = wave_sum(sa);
+    if (lane == 0) {
+        if (c.white_bkgd) { s0 += 1.f - sa; s1 += 1.f - sa; s2 += 1.f - sa; }
+        rgb[ray * 3 + 0] = s0; rgb[ray * 3 + 1] = s1; rgb[ray * 3 + 2] = s2;
+        depth[ray] = sd; acc[ray] = sa;
+    }
+}
+
+template <int SPL>
+__global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(CompIn c, const float* __restrict__ g_rgb,
+        const float* __restrict__ g_depth, const float* __restrict__ g_acc, float* __restrict__ draw,
+        float* __restrict__ drays) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= c.R) return;
+    float alpha[SPL], dist[SPL], dens[SPL], gate[SPL], zz[SPL], col[SPL][3], T[SPL], norm;
+    comp_load<SPL>(c, ray, lane, alpha, dist, dens, gate, zz, col, norm);
+    comp_trans<SPL>(alpha, lane, T);
+    float gr[3] = {0.f, 0.f, 0.f};
+    if (g_rgb) { gr[0] = g_rgb[ray * 3]; gr[1] = g_rgb[ray * 3 + 1]; gr[2] = g_rgb[ray * 3 + 2]; }
+    const float gd = g_depth ? g_depth[ray] : 0.f;
+    float ga = g_acc ? g_acc[ray] : 0.f;
+    if (c.white_bkgd) ga -= gr[0] + gr[1] + gr[2];
+    // G_j = dL/dw_j ; S_j = sum_{k>j} G_k alpha_k prod_{j<m<k}(1-alpha_m): reverse scan of the
+    // affine maps f_k(s) = G_k alpha_k + (1-alpha_k) s, composed (a1,b1)o(a2,b2) = (a1 a2, a1 b2 + b1).
+    float G[SPL];
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) G[e] = gr[0] * col[e][0] + gr[1] * col[e][1] + gr[2] * col[e][2] + gd * zz[e] + ga;
+    // lane aggregate F = f_{first} o ... o f_{last} of this lane's samples
+    float Fa = 1.f, Fb = 0.f;
+#pragma unroll
+    for (int e = SPL - 1; e >= 0; --e) {   // F <- f_e o F
+        Fb = G[e] * alpha[e] + (1.f - alpha[e]) * Fb;
+        Fa = (1.f - alpha[e]) * Fa;
+    }
+    // suffix composition over lanes: Suf_l = F_l o F_{l+1} o ... o F_63
+    float Sa = Fa, Sb = Fb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float ta = __shfl_down(Sa, o, 64), tb = __shfl_down(Sb, o, 64);
+        if (lane + o < 64) { Sb = Sa * tb + Sb; Sa = Sa * ta; }
+    }
+    float tail = __shfl_down(Sb, 1, 64);   // value of everything after this lane, applied to 0
+    if (lane == 63) tail = 0.f;
+    float dnorm = 0.f;
+    float sfx = tail;                        // S_j for the lane's last sample
+#pragma unroll
+    for (int e = SPL - 1; e >= 0; --e) {
+        const int j = lane * SPL + e;
+        const float wgt = alpha[e] * T[e];
+        float4 o = {0.f, 0.f, 0.f, 0.f};
+        if (j < c.S) {
+            o.x = wgt * gr[0] * col[e][0] * (1.f - col[e][0]);
+            o.y = wgt * gr[1] * col[e][1] * (1.f - col[e][1]);
+            o.z = wgt * gr[2] * col[e][2] * (1.f - col[e][2]);
+            if (j < c.S - 1) {
+                const float dalpha = T[e] * (G[e] - sfx);
+                const float om = 1.f - alpha[e];            // = exp(-dens*dist)
+                o.w = dalpha * dist[e] * om * gate[e];
+                const float ddist = dalpha * dens[e] * om;
+                dnorm += ddist * (dist[e] / (norm > 0.f ? norm : 1.f));
+            }
+            *reinterpret_cast<float4*>(draw + ((long long)ray * c.S + j) * 4) = o;
+        }
+        sfx = G[e] * alpha[e] + (1.f - alpha[e]) * sfx;     // becomes S_{j-1}
+    }
+    dnorm = wave_sum(dnorm);
+    if (lane < 3 && drays != nullptr && norm > 0.f)
+        drays[(long long)ray * 11 + 3 + lane] += dnorm * c.rays[(long long)ray * 11 + 3 + lane] / norm;
+}
+
+// ------------------------------------------------------ hierarchical sampling
+constexpr int SM_MAXN = 512;   // S + Ni rounded up to a power of two
+__global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const float* __restrict__ z,
+        const float* __restrict__ weights, int R, int S, int Ni, const float* __restrict__ u,
+        float* __restrict__ z_out, float* __restrict__ z_samples, float* __restrict__ z_std) {
+    __shared__ float s_cdf[RAYS_PER_BLOCK][256];
+    __shared__ float s_bins[RAYS_PER_BLOCK][256];
+    __shared__ float s_sort[RAYS_PER_BLOCK][SM_MAXN];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= R) return;                   // whole wave exits together
+    float* cdf = s_cdf[wv];
+    float* bins = s_bins[wv];
+    float* srt = s_sort[wv];
+    const float* zr = z + (long long)ray * S;
+    const float* wr = weights + (long long)ray * S;
+    const int nb = S - 1;                   // knots in cdf and entries in bins
+    // pdf over weights[1..S-2] + 1e-5, inclusive scan in chunks of 64
+    float tot = 0.f;
+    for (int k = lane; k < S - 2; k += 64) tot += wr[k + 1] + 1e-5f;
+    tot = wave_sum(tot);
+    float carry = 0.f;
+    if (lane == 0) cdf[0] = 0.f;
+    for (int k0 = 0; k0 < S - 2; k0 += 64) {
+        const int k = k0 + lane;
+        const float pdf = k < S - 2 ? (wr[k + 1] + 1e-5f) / tot : 0.f;
+        const float inc = wave_incl_sum(pdf, lane) + carry;
+        if (k < S - 2) cdf[k + 1] = inc;
+        carry = __shfl(inc, 63, 64);
+    }
+    for (int k = lane; k < nb; k += 64) bins[k] = .5f * (zr[k + 1] + zr[k]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): LDS writes visible to the wave
+    // inverse CDF
+    float sum = 0.f;
+    const int N = S + Ni;
+    for (int i = lane; i < Ni; i += 64) {
+        const float uu = u ? u[(long long)ray * Ni + i] : linspace01(i, Ni);
+        int lo = 0, hi = nb;                // first index with cdf > uu  (searchsorted right=True)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < nb - 1 ? lo : nb - 1;
+        const float cb = cdf[below], ca = cdf[above];
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (uu - cb) / denom;
+        const float bb = bins[below];
+        const float smp = bb + t * (bins[above] - bb);
+        if (z_samples) z_samples[(long long)ray * Ni + i] = smp;
+        srt[S + i] = smp;
+        sum += smp;
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / (float)Ni;
+    float var = 0.f;
+    for (int i = lane; i < Ni; i += 64) { const float d = srt[S + i] - mean; var += d * d; }
+    var = wave_sum(var);
+    if (lane == 0 && z_std) z_std[ray] = sqrtf(var / (float)Ni);
+    // sort(cat(z, samples)): bitonic network over N2 >= N values padded with +inf
+    int N2 = 64;
+    while (N2 < N) N2 <<= 1;
+    for (int i = lane; i < S; i += 64) srt[i] = zr[i];
+    for (int i = N + lane; i < N2; i += 64) srt[i] = __builtin_inff();
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= N2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < N2; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float a = srt[i], b = srt[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { srt[i] = b; srt[p] = a; }
+                }
+            }
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < N; i += 64) z_out[(long long)ray * N + i] = srt[i];
+}
+
+// -------------------------------------------------------------- ray prologue
+__global__ void pack_rays_fwd_kernel(const float* __restrict__ rays, int N, int ndc, float cx, float cy, float near,
+                                     float far, float* __restrict__ batch) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = rays + (long long)n * 6;          // [3][2]: r[2*i] = o_i, r[2*i+1] = d_i
+    float o[3] = {r[0], r[2], r[4]}, d[3] = {r[1], r[3], r[5]};
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float* b = batch + (long long)n * 11;
+    b[8] = d[0] / nrm; b[9] = d[1] / nrm; b[10] = d[2] / nrm;
+    if (ndc) {   // utils/run_lushnerf_helpers.py:542-562 with near = 1
+        const float t = -(1.f + o[2]) / d[2];
+        const float px = __fadd_rn(o[0], __fmul_rn(t, d[0])), py = __fadd_rn(o[1], __fmul_rn(t, d[1])),
+                    pz = __fadd_rn(o[2], __fmul_rn(t, d[2]));
+        b[0] = __fmul_rn(cx, px) / pz;
+        b[1] = __fmul_rn(cy, py) / pz;
+        b[2] = 1.f + 2.f / pz;
+        b[3] = __fmul_rn(cx, __fsub_rn(d[0] / d[2], px / pz));
+        b[4] = __fmul_rn(cy, __fsub_rn(d[1] / d[2], py / pz));
+        b[5] = -2.f / pz;
+    } else {
+        b[0] = o[0]; b[1] = o[1]; b[2] = o[2]; b[3] = d[0]; b[4] = d[1]; b[5] = d[2];
+    }
+    b[6] = near; b[7] = far;
+}
+
+__global__ void pack_rays_bwd_kernel(const float* __restrict__ rays, int N, int ndc, float cx, float cy,
+                                     const float* __restrict__ dbatch, float* __restrict__ drays) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = rays + (long long)n * 6;
+    const float o[3] = {r[0], r[2], r[4]}, d[3] = {r[1], r[3], r[5]};
+    const float* g = dbatch + (long long)n * 11;
+    float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+    // viewdir = d/|d|
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float v[3] = {d[0] / nrm, d[1] / nrm, d[2] / nrm};
+    const float vg = v[0] * g[8] + v[1] * g[9] + v[2] * g[10];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gd[i] += (g[8 + i] - v[i] * vg) / nrm;
+    if (ndc) {
+        const float t = -(1.f + o[2]) / d[2];
+        const float px = o[0] + t * d[0], py = o[1] + t * d[1], pz = o[2] + t * d[2];
+        const float ipz = 1.f / pz, ipz2 = ipz * ipz, idz = 1.f / d[2];
+        const float gpx = cx * ipz * (g[0] - g[3]);
+        const float gpy = cy * ipz * (g[1] - g[4]);
+        const float gpz = ipz2 * (-cx * px * (g[0] - g[3]) - cy * py * (g[1] - g[4]) - 2.f * g[2] + 2.f * g[5]);
+        gd[0] += cx * g[3] * idz;
+        gd[1] += cy * g[4] * idz;
+        gd[2] += -(cx * d[0] * g[3] + cy * d[1] * g[4]) * idz * idz;
+        const float gp[3] = {gpx, gpy, gpz};
+        float gt = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { go[i] += gp[i]; gd[i] += t * gp[i]; gt += gp[i] * d[i]; }
+        go[2] += -gt * idz;
+        gd[2] += -gt * t * idz;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { go[i] += g[i]; gd[i] += g[3 + i]; }
+    }
+    float* out = drays + (long long)n * 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { out[2 * i] = go[i]; out[2 * i + 1] = gd[i]; }
+}
+
+// ---------------------------------------------------------------- SE(3) warp
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct Se3 { V3 w, nu; float theta, s, c, rn; };   // rn = |r|
+__device__ __forceinline__ Se3 se3_setup(V3 r, V3 v) {
+    Se3 q;
+    q.rn = sqrtf(dot(r, r));
+    q.theta = q.rn + 1.0e-10f;
+    q.w = (1.f / q.theta) * r;
+    q.nu = (1.f / q.theta) * v;
+    sincosf(q.theta, &q.s, &q.c);
+    return q;
+}
+// utils/rigid_warping.py:20-45 in closed form: y = R p + t
+__device__ __forceinline__ V3 se3_apply(const Se3& q, V3 p) {
+    const V3 a = cross(q.w, p), b = cross(q.w, a);
+    const V3 e = cross(q.w, q.nu), f = cross(q.w, e);
+    return p + q.s * a + (1.f - q.c) * b + q.theta * q.nu + (1.f - q.c) * e + (q.theta - q.s) * f;
+}
+// reverse mode of se3_apply for one point: adds into gp, and into (gw, gnu, gth, gs, gc)
+__device__ __forceinline__ void se3_apply_bwd(const Se3& q, V3 p, V3 gy, V3& gp, V3& gw, V3& gnu, float& gth,
+                                              float& gs, float& gc) {
+    const V3 a = cross(q.w, p), b = cross(q.w, a);
+    const V3 e = cross(q.w, q.nu), f = cross(q.w, e);
+    gp = gp + gy;
+    gs += dot(gy, a) - dot(gy, f);
+    gc += -dot(gy, b) - dot(gy, e);
+    gth += dot(gy, q.nu) + dot(gy, f);
+    V3 ga = q.s * gy, gb = (1.f - q.c) * gy;
+    V3 ge = (1.f - q.c) * gy, gf = (q.theta - q.s) * gy;
+    gnu = gnu + q.theta * gy;
+    // b = w x a
+    gw = gw + cross(a, gb); ga = ga + cross(gb, q.w);
+    // a = w x p
+    gw = gw + cross(p, ga); gp = gp + cross(ga, q.w);
+    // f = w x e
+    gw = gw + cross(e, gf); ge = ge + cross(gf, q.w);
+    // e = w x nu
+    gw = gw + cross(q.nu, ge); gnu = gnu + cross(ge, q.w);
+}
+// finish: adjoints of (w, nu, theta, s, c) -> (r, v)
+__device__ __forceinline__ void se3_finish_bwd(const Se3& q, V3 r, V3 gw, V3 gnu, float gth, float gs, float gc,
+                                               V3& gr, V3& gv) {
+    gth += gs * q.c - gc * q.s;
+    const float it = 1.f / q.theta;
+    gth -= it * (dot(gw, q.w) + dot(gnu, q.nu));
+    gr = it * gw;
+    gv = it * gnu;
+    if (q.rn > 0.f) gr = gr + (gth / q.rn) * r;
+}
+
+// acts layout per image (LUSH_RBK_ACT_STRIDE floats)
+constexpr int RA_E = 0, RA_H0 = 64, RA_HR = 320, RA_HV = 352, RA_HW = 384, RA_WS = 416, RA_R = 424, RA_V = 440,
+              RA_WN = 456;
+
+__global__ void rbk_warp_fwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
+                                    const float* __restrict__ acts, float* __restrict__ new_rays,
+                                    float* __restrict__ ccw) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r6 = rays + (long long)n * 6;
+    const V3 o = {r6[0], r6[2], r6[4]}, d = {r6[1], r6[3], r6[5]};
+    const V3 end = o + d;
+    const float* A = acts + idx[n] * LUSH_RBK_ACT_STRIDE;
+    float* out = new_rays + (long long)n * (M + 1) * 6;
+    out[0] = o.x; out[1] = d.x; out[2] = o.y; out[3] = d.y; out[4] = o.z; out[5] = d.z;
+    for (int m = 0; m < M; ++m) {   // r.reshape(N,3,M): component c of motion m is column c*M+m (models/lushnerf.py:76)
+        const V3 r = {A[RA_R + m], A[RA_R + M + m], A[RA_R + 2 * M + m]};
+        const V3 v = {A[RA_V + m], A[RA_V + M + m], A[RA_V + 2 * M + m]};
+        const Se3 q = se3_setup(r, v);
+        const V3 wo = se3_apply(q, o), we = se3_apply(q, end);
+        const V3 wd = we - wo;
+        float* w6 = out + (m + 1) * 6;
+        w6[0] = wo.x; w6[1] = wd.x; w6[2] = wo.y; w6[3] = wd.y; w6[4] = wo.z; w6[5] = wd.z;
+    }
+    for (int m = 0; m <= M; ++m) ccw[(long long)n * (M + 1) + m] = A[RA_WN + m];
+}
+
+__global__ void rbk_warp_bwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
+                                    const float* __restrict__ acts, const float* __restrict__ dnew,
+                                    const float* __restrict__ dccw, const uint8_t* __restrict__ mask,
+                                    float* __restrict__ d_rvw, float* __restrict__ drays) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const long long img = idx[n];
+    float* G = d_rvw + img * LUSH_RBK_RVW_STRIDE;
+    if (dccw)
+        for (int m = 0; m <= M; ++m) atomicAdd(G + 24 + m, dccw[(long long)n * (M + 1) + m]);
+    const bool live = dnew != nullptr && (mask == nullptr || mask[n] != 0);
+    V3 go = {0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f};
+    if (live) {
+        const float* r6 = rays + (long long)n * 6;
+        const V3 o = {r6[0], r6[2], r6[4]}, d = {r6[1], r6[3], r6[5]};
+        const V3 end = o + d;
+        const float* A = acts + img * LUSH_RBK_ACT_STRIDE;
+        const float* g6 = dnew + (long long)n * (M + 1) * 6;
+        go = {g6[0], g6[2], g6[4]};
+        gd = {g6[1], g6[3], g6[5]};
+        for (int m = 0; m < M; ++m) {
+            const V3 r = {A[RA_R + m], A[RA_R + M + m], A[RA_R + 2 * M + m]};
+            const V3 v = {A[RA_V + m], A[RA_V + M + m], A[RA_V + 2 * M + m]};
+            const Se3 q = se3_setup(r, v);
+            const float* w6 = g6 + (m + 1) * 6;
+            const V3 gwo = {w6[0], w6[2], w6[4]}, gwd = {w6[1], w6[3], w6[5]};
+            // wd = we - wo
+            const V3 gye = gwd, gyo = gwo - gwd;
+            V3 gp_o = {0, 0, 0}, gp_e = {0, 0, 0}, gw = {0, 0, 0}, gnu = {0, 0, 0};
+            float gth = 0.f, gs = 0.f, gc = 0.f;
+            se3_apply_bwd(q, o, gyo, gp_o, gw, gnu, gth, gs, gc);
+            se3_apply_bwd(q, end, gye, gp_e, gw, gnu, gth, gs, gc);
+            V3 gr, gv;
+            se3_finish_bwd(q, r, gw, gnu, gth, gs, gc, gr, gv);
+            go = go + gp_o + gp_e;
+            gd = gd + gp_e;
+            atomicAdd(G + m, gr.x); atomicAdd(G + M + m, gr.y); atomicAdd(G + 2 * M + m, gr.z);
+            atomicAdd(G + 12 + m, gv.x); atomicAdd(G + 12 + M + m, gv.y); atomicAdd(G + 12 + 2 * M + m, gv.z);
+        }
+    }
+    if (drays) {
+        float* out = drays + (long long)n * 6;
+        out[0] = go.x; out[1] = gd.x; out[2] = go.y; out[3] = gd.y; out[4] = go.z; out[5] = gd.z;
+    }
+}
+
+// ------------------------------------------------------------------- RBK MLP
+// One workgroup; num_img rows.  y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]).
+__device__ void rbk_dense(const float* W, const float* b, const float* x, int xs, float* y, int ys, int n, int IN,
+                          int OUT, int relu) {
+    for (int t = threadIdx.x; t < n * OUT; t += blockDim.x) {
+        const int i = t / OUT, o = t % OUT;
+        float s = b[o];
+        for (int k = 0; k < IN; ++k) s += W[o * IN + k] * x[i * xs + k];
+        y[i * ys + o] = relu ? fmaxf(s, 0.f) : s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
+                                                          float* __restrict__ acts) {
+    const int ST = LUSH_RBK_ACT_STRIDE;
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) acts[(t / 64) * ST + RA_E + (t % 64)] = p.embed[t];
+    __syncthreads();
+    for (int l = 0; l < 4; ++l)
+        rbk_dense(p.w_trunk[l], p.b_trunk[l], acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1)), ST,
+                  acts + RA_H0 + 64 * l, ST, n, 64, 64, 1);
+    const float* h3 = acts + RA_H0 + 192;
+    rbk_dense(p.w_rb, p.b_rb, h3, ST, acts + RA_HR, ST, n, 64, 32, 1);
+    rbk_dense(p.w_vb, p.b_vb, h3, ST, acts + RA_HV, ST, n, 64, 32, 1);
+    rbk_dense(p.w_wb, p.b_wb, h3, ST, acts + RA_HW, ST, n, 64, 32, 1);
+    rbk_dense(p.w_r, p.b_r, acts + RA_HR, ST, acts + RA_R, ST, n, 32, 3 * M, 0);
+    rbk_dense(p.w_v, p.b_v, acts + RA_HV, ST, acts + RA_V, ST, n, 32, 3 * M, 0);
+    rbk_dense(p.w_w, p.b_w, acts + RA_HW, ST, acts + RA_WS, ST, n, 32, M + 1, 0);
+    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
+        const int i = t / (3 * M), o = t % (3 * M);
+        acts[i * ST + RA_R + o] *= window;
+        acts[i * ST + RA_V + o] *= window;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float sum = 0.f;
+        for (int m = 0; m <= M; ++m) {
+            const float s = 1.f / (1.f + expf(-acts[i * ST + RA_WS + m]));
+            acts[i * ST + RA_WS + m] = s;
+            sum += s;
+        }
+        for (int m = 0; m <= M; ++m) acts[i * ST + RA_WN + m] = acts[i * ST + RA_WS + m] / (sum + 1e-10f);
+    }
+}
+
+// dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
+__device__ void rbk_dense_bwd_x(const float* W, const float* dz, int zs, float* dx, int xs, const float* gate,
+                                int gs, int n, int IN, int OUT, int accumulate) {
+    for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
+        const int i = t / IN, k = t % IN;
+        float s = 0.f;
+        for (int o = 0; o < OUT; ++o) s += W[o * IN + k] * dz[i * zs + o];
+        if (accumulate) s += dx[i * xs + k];
+        dx[i * xs + k] = s;
+    }
+    __syncthreads();
+    if (gate) {
+        for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
+            const int i = t / IN, k = t % IN;
+            if (!(gate[i * gs + k] > 0.f)) dx[i * xs + k] = 0.f;
+        }
+        __syncthreads();
+    }
+}
+__device__ void rbk_dense_bwd_w(const float* dz, int zs, const float* x, int xs, float* dW, float* db, int n, int IN,
+                                int OUT) {
+    for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
+        const int o = t / IN, k = t % IN;
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += dz[i * zs + o] * x[i * xs + k];
+        dW[t] = s;
+    }
+    for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += dz[i * zs + o];
+        db[o] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
+                                                          const float* __restrict__ acts,
+                                                          const float* __restrict__ d_rvw, lush_rbk_grads g,
+                                                          float* __restrict__ sc) {
+    // scratch uses the same per-image layout as acts, holding adjoints of the pre-activations
+    const int ST = LUSH_RBK_ACT_STRIDE, RS = LUSH_RBK_RVW_STRIDE;
+    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
+        const int i = t / (3 * M), o = t % (3 * M);
+        sc[i * ST + RA_R + o] = d_rvw[i * RS + o] * window;
+        sc[i * ST + RA_V + o] = d_rvw[i * RS + 12 + o] * window;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float sum = 1e-10f, dotp = 0.f;
+        for (int m = 0; m <= M; ++m) { sum += acts[i * ST + RA_WS + m]; dotp += d_rvw[i * RS + 24 + m] * acts[i * ST + RA_WS + m]; }
+        for (int m = 0; m <= M; ++m) {
+            const float ws = acts[i * ST + RA_WS + m];
+            const float dws = d_rvw[i * RS + 24 + m] / sum - dotp / (sum * sum);
+            sc[i * ST + RA_WS + m] = dws * ws * (1.f - ws);
+        }
+    }
+    __syncthreads();
+    rbk_dense_bwd_w(sc + RA_R, ST, acts + RA_HR, ST, g.w_r, g.b_r, n, 32, 3 * M);
+    rbk_dense_bwd_w(sc + RA_V, ST, acts + RA_HV, ST, g.w_v, g.b_v, n, 32, 3 * M);
+    rbk_dense_bwd_w(sc + RA_WS, ST, acts + RA_HW, ST, g.w_w, g.b_w, n, 32, M + 1);
+    rbk_dense_bwd_x(p.w_r, sc + RA_R, ST, sc + RA_HR, ST, acts + RA_HR, ST, n, 32, 3 * M, 0);
+    rbk_dense_bwd_x(p.w_v, sc + RA_V, ST, sc + RA_HV, ST, acts + RA_HV, ST, n, 32, 3 * M, 0);
+    rbk_dense_bwd_x(p.w_w, sc + RA_WS, ST, sc + RA_HW, ST, acts + RA_HW, ST, n, 32, M + 1, 0);
+    const float* h3 = acts + RA_H0 + 192;
+    rbk_dense_bwd_w(sc + RA_HR, ST, h3, ST, g.w_rb, g.b_rb, n, 64, 32);
+    rbk_dense_bwd_w(sc + RA_HV, ST, h3, ST, g.w_vb, g.b_vb, n, 64, 32);
+    rbk_dense_bwd_w(sc + RA_HW, ST, h3, ST, g.w_wb, g.b_wb, n, 64, 32);
+    float* dh3 = sc + RA_H0 + 192;
+    rbk_dense_bwd_x(p.w_rb, sc + RA_HR, ST, dh3, ST, nullptr, 0, n, 64, 32, 0);
+    rbk_dense_bwd_x(p.w_vb, sc + RA_HV, ST, dh3, ST, nullptr, 0, n, 64, 32, 1);
+    rbk_dense_bwd_x(p.w_wb, sc + RA_HW, ST, dh3, ST, h3, ST, n, 64, 32, 1);
+    for (int l = 3; l >= 0; --l) {
+        const float* x = acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
+        rbk_dense_bwd_w(sc + RA_H0 + 64 * l, ST, x, ST, g.w_trunk[l], g.b_trunk[l], n, 64, 64);
+        float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
+        rbk_dense_bwd_x(p.w_trunk[l], sc + RA_H0 + 64 * l, ST, dx, ST, l == 0 ? nullptr : x, ST, n, 64, 64, 0);
+    }
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) g.embed[t] = sc[(t / 64) * ST + RA_E + (t % 64)];
+}
+
+// ------------------------------------------------------- blur mix / tone map
+__global__ void wsum_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ccw, int N, int M, int C,
+                                float* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * C) return;
+    const long long n = t / C; const int c = (int)(t % C);
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += x[(n * M + m) * C + c] * ccw[n * M + m];
+    y[t] = s;
+}
+__global__ void wsum_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ccw, int N, int M, int C,
+                                const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dccw) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (n, m)
+    if (t >= (long long)N * M) return;
+    const long long n = t / M;
+    float s = 0.f;
+    const float w = ccw[t];
+    for (int c = 0; c < C; ++c) {
+        const float g = dy[n * C + c];
+        s += g * x[t * C + c];
+        if (dx) dx[t * C + c] = g * w;
+    }
+    if (dccw) dccw[t] += s;
+}
+
+constexpr float INV_GAMMA = (float)(1.0 / 2.2);
+__global__ void tonemap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nraw, int n3, int gamma,
+                                   float* __restrict__ y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    float v = x[t];
+    if (nraw) v += 0.1f * (1.f / (1.f + expf(-nraw[t])));
+    y[t] = gamma ? powf(v, INV_GAMMA) : v;
+}
+__global__ void tonemap_bwd_kernel(const float* __restrict__ x, const float* __restrict__ nraw, int n3, int gamma,
+                                   const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dnraw) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    float v = x[t], sg = 0.f;
+    if (nraw) { sg = 1.f / (1.f + expf(-nraw[t])); v += 0.1f * sg; }
+    const float gv = gamma ? dy[t] * INV_GAMMA * powf(v, INV_GAMMA - 1.f) : dy[t];
+    if (dx) dx[t] += gv;
+    if (nraw && dnraw) dnraw[t] += gv * 0.1f * sg * (1.f - sg);
+}
+__global__ void noise_act_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) y[t] = 0.1f * (1.f / (1.f + expf(-x[t])));
+}
+__global__ void noise_act_bwd_kernel(const float* __restrict__ x, int n, const float* __restrict__ dy,
+                                     float* __restrict__ dx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { const float s = 1.f / (1.f + expf(-x[t])); dx[t] += dy[t] * 0.1f * s * (1.f - s); }
+}
+__global__ void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ tg,
+                            int n3, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    if (t < n3) {
+        const float inv = 1.f / (float)n3;
+        const float da = a[t] - tg[t], db = b[t] - tg[t];
+        l = 0.5f * (da * da + fabsf(da) + db * db + fabsf(db)) * inv;
+        ga[t] = (da + 0.5f * (da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f))) * inv;
+        gb[t] = (db + 0.5f * (db > 0.f ? 1.f : (db < 0.f ? -1.f : 0.f))) * inv;
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+}
+
+// ------------------------------------------------------- d rays from d points
+__global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void ray_grad_reduce_kernel(const float* __restrict__ dpts,
+        const float* __restrict__ z, int R, int S, float* __restrict__ drays) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = lane; s < S; s += 64) {
+        const long long p = (long long)ray * S + s;
+        const float4 gx = *reinterpret_cast<const float4*>(dpts + p * 8);
+        const float4 gv = *reinterpret_cast<const float4*>(dpts + p * 8 + 4);
+        const float zz = z[p];
+        a[0] += gx.x; a[1] += gx.y; a[2] += gx.z;
+        a[3] += gx.x * zz; a[4] += gx.y * zz; a[5] += gx.z * zz;
+        a[6] += gv.x; a[7] += gv.y; a[8] += gv.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = wave_sum(a[i]);
+    if (lane == 0) {
+        float* o = drays + (long long)ray * 11;
+        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3]; o[4] += a[4]; o[5] += a[5];
+        o[8] += a[6]; o[9] += a[7]; o[10] += a[8];
+    }
+}
+
+// ------------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace lush
+
+// =============================================================================
+// C ABI
+// =============================================================================
+using namespace lush;
+#define S_(s) ((hipStream_t)(s))
+#define CHECK_LAUNCH() LUSH_HIP(hipGetLastError())
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+extern "C" {
+
+const char* lush_last_error(void) { return g_err.c_str(); }
+int lush_abi_version(void) { return 1; }
+
+int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
+    if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
+    hipLaunchKernelGGL(zgrid_kernel, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, S_(st), rays, R, S, lindisp, t_rand, z);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* z, lush_stream_t st) {
+    if (index < 0 || index >= S) return set_error("lush_zfixed: index out of range");
+    hipLaunchKernelGGL(zfixed_kernel, dim3(cdiv(R, 256)), dim3(256), 0, S_(st), rays, R, S, index, lindisp, z);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_composite_fwd(const float* raw, const float* z, const float* rays, int R, int S, const float* noise,
+                       float noise_std, float near_mask, int white_bkgd, float* rgb, float* depth, float* acc,
+                       float* weights, float* density, lush_stream_t st) {
+    if (S < 2 || S > 256) return set_error("lush_composite_fwd: S must be in [2,256]");
+    CompIn c{raw, z, rays, noise, R, S, noise_std, near_mask, white_bkgd};
+    dim3 g(cdiv(R, RAYS_PER_BLOCK)), b(RAYS_PER_BLOCK * 64);
+    if (S <= 64) hipLaunchKernelGGL(composite_fwd_kernel<1>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density);
+    else if (S <= 128) hipLaunchKernelGGL(composite_fwd_kernel<2>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density);
+    else hipLaunchKernelGGL(composite_fwd_kernel<4>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S, const float* noise,
+                       float noise_std, float near_mask, int white_bkgd, const float* g_rgb, const float* g_depth,
+                       const float* g_acc, float* draw, float* drays, lush_stream_t st) {
+    if (S < 2 || S > 256) return set_error("lush_composite_bwd: S must be in [2,256]");
+    CompIn c{raw, z, rays, noise, R, S, noise_std, near_mask, white_bkgd};
+    dim3 g(cdiv(R, RAYS_PER_BLOCK)), b(RAYS_PER_BLOCK * 64);
+    if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays);
+    else if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays);
+    else hipLaunchKernelGGL(composite_bwd_kernel<4>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_sample_merge(const float* z, const float* weights, int R, int S, int Ni, const float* u, float* z_out,
+                      float* z_samples, float* z_std, lush_stream_t st) {
+    if (S < 3 || S > 256 || Ni < 1 || S + Ni > SM_MAXN) return set_error("lush_sample_merge: need 3<=S<=256, S+Ni<=512");
+    hipLaunchKernelGGL(sample_merge_kernel, dim3(cdiv(R, RAYS_PER_BLOCK)), dim3(RAYS_PER_BLOCK * 64), 0, S_(st), z,
+                       weights, R, S, Ni, u, z_out, z_samples, z_std);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_pack_rays_fwd(const float* rays, int N, int ndc, float cx, float cy, float near, float far, float* batch,
+                       lush_stream_t st) {
+    hipLaunchKernelGGL(pack_rays_fwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, S_(st), rays, N, ndc, cx, cy, near, far, batch);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_pack_rays_bwd(const float* rays, int N, int ndc, float cx, float cy, const float* dbatch, float* drays,
+                       lush_stream_t st) {
+    hipLaunchKernelGGL(pack_rays_bwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, S_(st), rays, N, ndc, cx, cy, dbatch, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts, lush_stream_t st) {
+    if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
+    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(1), dim3(256), 0, S_(st), *p, num_img, M, window, acts);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
+                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, lush_stream_t st) {
+    if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
+    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(256), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_rbk_warp_fwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, float* new_rays,
+                      float* ccw, lush_stream_t st) {
+    hipLaunchKernelGGL(rbk_warp_fwd_kernel, dim3(cdiv(N, 128)), dim3(128), 0, S_(st), rays, idx, N, M, acts, new_rays, ccw);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_rbk_warp_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, const float* dnew_rays,
+                      const float* dccw, const uint8_t* mask, float* d_rvw, float* drays, lush_stream_t st) {
+    hipLaunchKernelGGL(rbk_warp_bwd_kernel, dim3(cdiv(N, 128)), dim3(128), 0, S_(st), rays, idx, N, M, acts, dnew_rays, dccw, mask, d_rvw, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_wsum_fwd(const float* x, const float* ccw, int N, int M, int C, float* y, lush_stream_t st) {
+    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(cdiv((long long)N * C, 256)), dim3(256), 0, S_(st), x, ccw, N, M, C, y);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_wsum_bwd(const float* x, const float* ccw, int N, int M, int C, const float* dy, float* dx, float* dccw,
+                  lush_stream_t st) {
+    hipLaunchKernelGGL(wsum_bwd_kernel, dim3(cdiv((long long)N * M, 256)), dim3(256), 0, S_(st), x, ccw, N, M, C, dy, dx, dccw);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_tonemap_fwd(const float* x, const float* nraw, int n, int gamma, float* y, lush_stream_t st) {
+    hipLaunchKernelGGL(tonemap_fwd_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), x, nraw, 3 * n, gamma, y);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_tonemap_bwd(const float* x, const float* nraw, int n, int gamma, const float* dy, float* dx, float* dnraw,
+                     lush_stream_t st) {
+    hipLaunchKernelGGL(tonemap_bwd_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), x, nraw, 3 * n, gamma, dy, dx, dnraw);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_noise_act_fwd(const float* x, int n, float* y, lush_stream_t st) {
+    hipLaunchKernelGGL(noise_act_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), x, n, y);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_stream_t st) {
+    hipLaunchKernelGGL(noise_act_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), x, n, dy, dx);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float* loss, float* ga, float* gb,
+                      lush_stream_t st) {
+    hipLaunchKernelGGL(loss_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), a, b, target, 3 * n, loss, ga, gb);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays, lush_stream_t st) {
+    hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3(cdiv(R, RAYS_PER_BLOCK)), dim3(RAYS_PER_BLOCK * 64), 0, S_(st), dpts, z, R, S, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_adam(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1, float beta2,
+              float eps, int step, float grad_scale, lush_stream_t st) {
+    if (n <= 0) return 0;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), param, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

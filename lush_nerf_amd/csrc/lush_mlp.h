@@ -1,0 +1,140 @@
+// lush-march: layout of the packed MLP weights and the argument blocks of the
+// fused MLP kernels.  Shared by host launchers and device code.
+//
+// One MLP (NeRF: HW=256, NL=8, SKIP=5; NeRF_Noise: HW=128, NL=4, SKIP=-1;
+// utils/run_lushnerf_helpers.py:365-423, 456-512) is a list of GEMM *segments*
+//     out[rows][pts] += Wseg[rows][K] * img[K][pts]
+// Each segment is stored as MFMA A-operand fragments, NS bf16 planes each:
+//     entry (kk, rb): [plane][lane 0..63][8 x bf16]   (NS KiB)
+//     lane (r = lane&31, h = lane>>5) element j = Wseg[32*rb + r][16*kk + 8*h + j]
+// so a wave fetches one fragment with one fully coalesced 1-KiB load.
+#pragma once
+#include <stdint.h>
+
+namespace lush {
+
+enum { NET_MAX_LAYERS = 8 };
+
+template <int HW_, int NL_, int SKIP_>
+struct NetT {
+    static constexpr int HW = HW_, NL = NL_, SKIP = SKIP_;
+    static constexpr int HV = HW / 2;
+    static constexpr int NRB = HW / 32, NRBV = HV / 32;
+    static constexpr int KKH = HW / 16, KKV = HV / 16;
+    static constexpr int KKX = 4, KKD = 2;   // gamma(x) padded to 64, gamma(d) to 32
+
+    // ---- forward segments, offsets in entries ----
+    // L0 | L1.. (skip layer = [a: gamma(x) part][b: h part]) | FEAT | ALPHA | VA | VB | RGB
+    static constexpr int fwd_L(int l, bool part_b) {
+        int off = 0;
+        if (l == 0) return 0;
+        off += KKX * NRB;
+        for (int i = 1; i < l; ++i) off += (i == SKIP ? (KKX + KKH) : KKH) * NRB;
+        if (l == SKIP && part_b) off += KKX * NRB;
+        return off;
+    }
+    static constexpr int fwd_FEAT = fwd_L(NL, false);
+    static constexpr int fwd_ALPHA = fwd_FEAT + KKH * NRB;
+    static constexpr int fwd_VA = fwd_ALPHA + KKH;
+    static constexpr int fwd_VB = fwd_VA + KKH * NRBV;
+    static constexpr int fwd_RGB = fwd_VB + KKD * NRBV;
+    static constexpr int fwd_END = fwd_RGB + KKV;
+
+    // ---- backward (transposed) segments ----
+    // VAT (rows HW, K=HV) | VBT (rows 32, K=HV) | FEATT | L{NL-1}T .. L1T | L0T (rows 64)
+    //   skip layer T = [a: rows 64 (gamma(x) part)][b: rows HW]
+    static constexpr int bwd_VAT = fwd_END;
+    static constexpr int bwd_VBT = bwd_VAT + KKV * NRB;
+    static constexpr int bwd_FEATT = bwd_VBT + KKV;
+    static constexpr int bwd_LT(int l, bool part_b) {   // l in [0, NL-1]
+        int off = bwd_FEATT + KKH * NRB;
+        for (int i = NL - 1; i > l; --i) off += (i == SKIP ? (KKH * 2 + KKH * NRB) : KKH * NRB);
+        if (l == SKIP && part_b) off += KKH * 2;
+        return off;
+    }
+    static constexpr int bwd_END = bwd_LT(0, false) + KKH * 2;
+    static constexpr int total_entries = bwd_END;
+
+    static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
+};
+
+typedef NetT<256, 8, 5> NetNerf;
+typedef NetT<128, 4, -1> NetNoise;
+
+// One pack job: fill `n_entries` = KK*NRB fragments of a segment from an fp32
+// matrix.  Element (row, k) of the segment = src[row*sr + k*sk] if row < rows
+// and k < cols, else 0.
+struct PackJob {
+    const float* src;
+    int sr, sk;
+    int rows, cols;
+    int nrb, kk;
+    int dst_entry;       // first entry in the packed buffer
+    int first_block;     // prefix sum of (nrb*kk) over previous jobs
+};
+
+struct PackTable {
+    PackJob j[32];
+    int n;
+};
+
+struct MlpParams {       // device pointers to the fp32 nn.Linear parameters
+    const float* w[NET_MAX_LAYERS];
+    const float* b[NET_MAX_LAYERS];
+    const float *w_feat, *b_feat, *w_alpha, *b_alpha, *w_views, *b_views, *w_rgb, *b_rgb;
+};
+
+struct MlpGrads {        // same shapes as MlpParams, fp32, accumulated with atomics
+    float* w[NET_MAX_LAYERS];
+    float* b[NET_MAX_LAYERS];
+    float *w_feat, *b_feat, *w_alpha, *b_alpha, *w_views, *b_views, *w_rgb, *b_rgb;
+};
+
+// Activation stash written by the forward kernel (read by backward / dW).
+// Every array is [plane][Ppad][cols] bf16 with Ppad a multiple of the tile.
+struct MlpStash {
+    __bf16* pe;                    // [NS][Ppad][PE_ROW]
+    __bf16* h[NET_MAX_LAYERS];     // [NS][Ppad][HW]
+    __bf16* feat;                  // [NS][Ppad][HW]
+    __bf16* hv;                    // [NS][Ppad][HV]
+    unsigned long long* mask;      // ReLU sign bits, see mask_index()
+    long long plane_pe, plane_h, plane_hv;   // plane strides in elements
+};
+
+struct MlpFwdArgs {
+    const float* rays;             // [R][11]
+    const float* z;                // [R][S]
+    int S, P, n_tiles;
+    const uint4* wpk;              // packed weights, NS planes
+    MlpParams prm;                 // biases are read from here
+    float* raw;                    // [P][4]
+    MlpStash st;
+    int write_stash;
+};
+
+struct MlpBwdArgs {
+    const float* rays;
+    const float* z;
+    int S, P, n_tiles;
+    const uint4* wpk;              // packed weights with NSB planes
+    MlpParams prm;                 // w_rgb / w_alpha are read in fp32
+    const float* draw;             // [P][4]
+    const unsigned long long* mask;
+    // dZ stash (NSB planes): dz[l] [Ppad][HW], dfeat [Ppad][HW], dzv [Ppad][HV]
+    __bf16* dz[NET_MAX_LAYERS];
+    __bf16* dfeat;
+    __bf16* dzv;
+    long long plane_h, plane_hv;
+    float* dpts;                   // [P][8]: d/dx (3), pad, d/dviewdir (3), pad
+};
+
+struct DwArgs {
+    const __bf16* Z; long long z_plane; int ldz; int n_out;   // dZ [Ppad][ldz]
+    const __bf16* X; long long x_plane; int ldx; int xcol0; int k_in;
+    float* dW; int ldw; int wcol0;
+    float* db;                     // may be null
+    int Ppad;                      // multiple of 32
+    int pts_per_split;             // multiple of 32
+};
+
+}  // namespace lush

@@ -1,0 +1,851 @@
+// lush-march: fused NeRF MLP kernels for gfx950 (MI355X).
+//
+//   mlp_fwd_kernel : positional encoding -> NL x (Linear+ReLU) with skip ->
+//                    feature / alpha / views / rgb heads, one tile of MT points
+//                    per workgroup pass, activations resident in LDS, weights
+//                    streamed from L2 as pre-packed MFMA fragments.
+//   mlp_bwd_kernel : the transposed chain dX = W^T dZ with ReLU masks, down to
+//                    d/d(point) and d/d(viewdir) through the encoding.
+//   dw_gemm_kernel : dW[o][i] = sum_p dZ[p][o] X[p][i] (split over points).
+//
+// Replaces Embedder.forward + NeRF.forward / NeRF_Noise.forward
+// (utils/run_lushnerf_helpers.py:334-344, 394-423, 483-512) and
+// NeRFAll.mlpforward (models/lushnerf.py:234-266).
+//
+// Orientation: features on MFMA rows (A = weights), points on MFMA columns
+// (B = activations).  The accumulator of v_mfma_f32_32x32x16_bf16 then holds,
+// per lane, ONE point (column) and 4 consecutive features in registers
+// 4g..4g+3, so the next layer's B operand image [point][feature] is written
+// with 8-byte ds_write_b64 and read back with 16-byte ds_read_b128.
+//
+// Precision: NS bf16 planes per operand (lush_common.h): NS=1 plain bf16,
+// NS=2 ~2^-17 relative (parity mode), NS=3 ~fp32.  Accumulation is fp32.
+#include "lush_common.h"
+#include "lush_mlp.h"
+
+namespace lush {
+
+constexpr int NWAVES = 4;
+constexpr int NTHREADS = NWAVES * WAVE;
+
+// ----------------------------------------------------------------------------
+// weight packing
+// ----------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __restrict__ dst) {
+    int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < T.n && T.j[j + 1].first_block <= b) ++j;
+    const PackJob J = T.j[j];
+    const int e = b - J.first_block;          // entry inside the segment = kk*nrb + rb
+    const int kk = e / J.nrb, rb = e % J.nrb;
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int row = rb * 32 + r;
+    __bf16 out[NS][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kk * 16 + 8 * h + i;
+        float v = 0.f;
+        if (row < J.rows && k < J.cols) v = J.src[(long long)row * J.sr + (long long)k * J.sk];
+        __bf16 p[NS];
+        split_planes<NS>(v, p);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) out[s][i] = p[s];
+    }
+    __bf16* base = dst + ((long long)(J.dst_entry + e) * NS) * 64 * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = out[s][i];
+        *reinterpret_cast<bf16x8*>(base + ((long long)s * 64 + lane) * 8) = v;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// segment GEMM: acc[RB][CB] += Wseg[rows of this wave][K] * img[K][pts]
+// ----------------------------------------------------------------------------
+// Weight fragments go global(L2) -> registers through a ring of PF+1 slots (prefetch
+// distance PF k-steps); the K loop is rolled in groups of PF+1 steps so the ring
+// indices stay static (runtime-indexed register arrays would go to scratch) and
+// the compiler cannot hoist every load of the segment to the top.
+template <int NS, int RB, int CB, int KK>
+__device__ __forceinline__ void seg_gemm(f32x16 (&acc)[RB][CB], const bf16x8* __restrict__ wseg,
+                                         int nrb, int rb0, const char* img, int plane_bytes,
+                                         int row_bytes, int chunk0, int lane) {
+    constexpr int PF = NS == 1 ? 4 : 2;
+    constexpr int G = PF + 1;
+    constexpr int NG = (KK >= 2 * PF + 1) ? (KK - 2 * PF - 1) / G + 1 : 0;
+    const int r = lane & 31, h = lane >> 5;
+    bf16x8 a[G][RB][NS];
+    const bf16x8* wl = wseg + (long long)rb0 * NS * 64 + lane;
+    const int kstride = nrb * NS * 64;
+    auto load = [&](bf16x8 (&dst)[RB][NS], int kk) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) dst[i][p] = wl[(long long)kk * kstride + (i * NS + p) * 64];
+    };
+    auto compute = [&](const bf16x8 (&src)[RB][NS], int kk) {
+        bf16x8 b[CB][NS];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                b[cb][p] = *reinterpret_cast<const bf16x8*>(
+                    img + p * plane_bytes + swz(cb * 32 + r, chunk0 + 2 * kk + h, row_bytes));
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[i][cb] = mfma_planes<NS>(src[i], b[cb], acc[i][cb]);
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < KK) load(a[s], s);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        const int kb = g * G;
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            load(a[(s + PF) % G], kb + s + PF);
+            compute(a[s], kb + s);
+        }
+    }
+#pragma unroll
+    for (int k = NG * G; k < KK; ++k) {
+        if (k + PF < KK) load(a[(k + PF) % G], k + PF);
+        compute(a[k % G], k);
+    }
+}
+
+template <int RB, int CB>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[RB][CB], const float* __restrict__ bias, int rb0,
+                                         int nvalid, int h) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (rb0 + i) * 32 + acc_row(q, h);
+            const float v = (bias != nullptr && row < nvalid) ? bias[row] : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[i][cb][q] = v;
+        }
+}
+
+// Mask words: one 64-bit ballot per (tile, mask layer, row-block, col-block, q).
+__device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int nrb, int rb, int CB, int cb) {
+    return ((((long long)tile * n_ml + ml) * nrb + rb) * CB + cb) * 16;
+}
+
+// Write one 32x32 accumulator block as NS bf16 planes into the LDS image
+// [pt][feature] (+ optionally the global stash and the ReLU sign bits).
+template <int NS, bool RELU>
+__device__ __forceinline__ void store_block(const f32x16& acc, char* img, int plane_bytes, int row_bytes,
+                                            int pt, int rb, int lane, __bf16* stash, long long stash_plane,
+                                            int stash_ld, long long gpt, unsigned long long* mask_words) {
+    const int h = lane >> 5;
+    if (RELU && mask_words != nullptr) {
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned long long m = __ballot(acc[q] > 0.f);
+            if (lane == q) mine = m;
+        }
+        if (lane < 16) mask_words[lane] = mine;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __bf16 pl[4][NS];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[4 * g + e];
+            if (RELU) v = fmaxf(v, 0.f);
+            split_planes<NS>(v, pl[e]);
+        }
+        const int f = rb * 32 + 8 * g + 4 * h;          // first of 4 consecutive features
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pl[e][p];
+            *reinterpret_cast<bf16x4*>(img + p * plane_bytes + swz(pt, f >> 3, row_bytes) + (f & 7) * 2) = v;
+            if (stash != nullptr)
+                *reinterpret_cast<bf16x4*>(stash + p * stash_plane + gpt * stash_ld + f) = v;
+        }
+    }
+}
+
+// Same, applying stored ReLU sign bits (backward) instead of computing them.
+template <int NS>
+__device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int plane_bytes, int row_bytes,
+                                                   int pt, int rb, int lane, __bf16* stash,
+                                                   long long stash_plane, int stash_ld, long long gpt,
+                                                   const unsigned long long* mask_words) {
+    if (mask_words != nullptr) {
+        const unsigned long long mine = lane < 16 ? mask_words[lane] : 0ull;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)mine, q);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mine >> 32), q);
+            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+            if (!((m >> lane) & 1ull)) acc[q] = 0.f;
+        }
+    }
+    store_block<NS, false>(acc, img, plane_bytes, row_bytes, pt, rb, lane, stash, stash_plane, stash_ld, gpt,
+                           nullptr);
+}
+
+// ----------------------------------------------------------------------------
+// positional encoding of one tile into the PE image
+// ----------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void pe_put(char* peimg, int plane_bytes, int pt, int col, float v) {
+    __bf16 p[NS];
+    split_planes<NS>(v, p);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        *reinterpret_cast<__bf16*>(peimg + s * plane_bytes + swz(pt, col >> 3, PE_ROW * 2) + (col & 7) * 2) = p[s];
+}
+
+// Point position exactly as the reference forms it: o + d*z, two roundings,
+// no FMA (models/lushnerf.py:414, 525).
+__device__ __forceinline__ void point_of(const float* __restrict__ rays, const float* __restrict__ z,
+                                         int S, long long gpt, float (&x)[3], float (&d)[3]) {
+    const long long ray = gpt / S;
+    const float zz = z[gpt];
+    const float* rr = rays + ray * 11;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x[i] = __fadd_rn(rr[i], __fmul_rn(rr[3 + i], zz));
+        d[i] = rr[8 + i];
+    }
+}
+
+template <int NS, int MT>
+__device__ __forceinline__ void pe_tile(char* peimg, int plane_bytes, const float* rays, const float* z,
+                                        int S, int P, long long tile_pt0, int tid) {
+    constexpr int PARTS = NTHREADS / MT;
+    const int pt = tid % MT, part = tid / MT;
+    const long long gpt = tile_pt0 + pt;
+    float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (gpt < P) point_of(rays, z, S, gpt, x, d);
+    // units: 0..L_X-1 = frequency k of x; L_X..L_X+L_D-1 = frequency k of d; raw copies go with unit 0 / L_X
+    for (int u = part; u < L_X + L_D; u += PARTS) {
+        const bool isd = u >= L_X;
+        const int k = isd ? u - L_X : u;
+        const int base = isd ? PE_X : 0;
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float v = isd ? d[i] : x[i];
+            if (k == 0) pe_put<NS>(peimg, plane_bytes, pt, base + i, v);
+            float s, c;
+            sincosf(v * f, &s, &c);
+            pe_put<NS>(peimg, plane_bytes, pt, base + 3 + 6 * k + i, s);
+            pe_put<NS>(peimg, plane_bytes, pt, base + 3 + 6 * k + 3 + i, c);
+        }
+    }
+    if (part == PARTS - 1) {   // zero padding columns that the K loops do read
+        pe_put<NS>(peimg, plane_bytes, pt, PE_X_VALID, 0.f);
+#pragma unroll
+        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS>(peimg, plane_bytes, pt, c, 0.f);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// forward
+// ----------------------------------------------------------------------------
+template <class N, int NS, int MT, bool HAS_ALPHA>
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL;
+    constexpr int CB = MT / 32;
+    constexpr int RB = N::NRB >= NWAVES ? N::NRB / NWAVES : 1;      // row-blocks per wave, trunk
+    constexpr int RBV = N::NRBV >= NWAVES ? N::NRBV / NWAVES : 1;   // views layer
+    constexpr int ACT_ROW = HW * 2, ACT_PLANE = MT * ACT_ROW;
+    constexpr int PE_PLANE = MT * PE_ROW * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* actimg = smem;
+    char* peimg = smem + NS * ACT_PLANE;
+    float* alphabuf = reinterpret_cast<float*>(peimg + NS * PE_PLANE);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bf16x8* wpk = reinterpret_cast<const bf16x8*>(A.wpk);
+    auto seg = [&](int entry) { return wpk + (long long)entry * NS * 64; };
+    const bool stash_on = A.write_stash != 0;
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * MT;
+        pe_tile<NS, MT>(peimg, PE_PLANE, A.rays, A.z, A.S, A.P, pt0, tid);
+        __syncthreads();
+        if (stash_on) {   // de-swizzled 16-byte copies of the 96 live PE columns
+            for (int i = tid; i < NS * MT * 12; i += NTHREADS) {
+                const int c = i % 12, pt = (i / 12) % MT, p = i / (12 * MT);
+                const uint4 v = *reinterpret_cast<const uint4*>(peimg + p * PE_PLANE + swz(pt, c, PE_ROW * 2));
+                *reinterpret_cast<uint4*>(A.st.pe + p * A.st.plane_pe + (pt0 + pt) * PE_ROW + c * 8) = v;
+            }
+        }
+        f32x16 acc[RB][CB];
+        const int rb0 = w * RB;
+        const bool trunk_active = (w * RB) < N::NRB;
+        // ---- layer 0 ----
+        if (trunk_active) {
+            acc_bias<RB, CB>(acc, A.prm.b[0], rb0, HW, h);
+            seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(0, false)), N::NRB, rb0, peimg, PE_PLANE, PE_ROW * 2, 0, lane);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    store_block<NS, true>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                                          stash_on ? A.st.h[0] : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r,
+                                          stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, 0, N::NRB, rb0 + i, CB, cb) : nullptr);
+        }
+        __syncthreads();
+        // ---- layers 1 .. NL-1 ----
+#pragma unroll 1
+        for (int l = 1; l < NL; ++l) {
+            if (trunk_active) {
+                acc_bias<RB, CB>(acc, A.prm.b[l], rb0, HW, h);
+                if (l == N::SKIP)
+                    seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(l, false)), N::NRB, rb0, peimg, PE_PLANE,
+                                                 PE_ROW * 2, 0, lane);
+                seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
+                                             lane);
+            }
+            __syncthreads();
+            if (trunk_active) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        store_block<NS, true>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                                              stash_on ? A.st.h[l] : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r,
+                                              stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, l, N::NRB, rb0 + i, CB, cb) : nullptr);
+            }
+            __syncthreads();
+        }
+        // ---- feature (no activation) and alpha heads, both read h_{NL-1} ----
+        if (trunk_active) {
+            acc_bias<RB, CB>(acc, A.prm.b_feat, rb0, HW, h);
+            seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_FEAT), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+        }
+        if (HAS_ALPHA && w == NWAVES - 1) {
+            f32x16 aa[1][CB];
+            acc_bias<1, CB>(aa, A.prm.b_alpha, 0, 1, h);
+            seg_gemm<NS, 1, CB, N::KKH>(aa, seg(N::fwd_ALPHA), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            if (h == 0) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) alphabuf[cb * 32 + r] = aa[0][cb][0];
+            }
+        }
+        __syncthreads();
+        if (trunk_active) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    store_block<NS, false>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                                           stash_on ? A.st.feat : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r, nullptr);
+        }
+        __syncthreads();
+        // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
+        f32x16 av[RBV][CB];
+        const int rbv0 = w * RBV;
+        const bool views_active = rbv0 < N::NRBV;
+        if (views_active) {
+            acc_bias<RBV, CB>(av, A.prm.b_views, rbv0, HV, h);
+            seg_gemm<NS, RBV, CB, N::KKH>(av, seg(N::fwd_VA), N::NRBV, rbv0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            seg_gemm<NS, RBV, CB, N::KKD>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
+                                          lane);
+        }
+        __syncthreads();
+        if (views_active) {
+#pragma unroll
+            for (int i = 0; i < RBV; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    store_block<NS, true>(av[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rbv0 + i, lane,
+                                          stash_on ? A.st.hv : nullptr, A.st.plane_hv, HV, pt0 + cb * 32 + r,
+                                          stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, NL, N::NRB, rbv0 + i, CB, cb) : nullptr);
+        }
+        __syncthreads();
+        // ---- rgb head (3 rows) on wave 0; alpha joins from LDS ----
+        if (w == 0) {
+            f32x16 ar[1][CB];
+            acc_bias<1, CB>(ar, A.prm.b_rgb, 0, 3, h);
+            seg_gemm<NS, 1, CB, N::KKV>(ar, seg(N::fwd_RGB), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            if (h == 0) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const long long gpt = pt0 + cb * 32 + r;
+                    if (gpt < A.P) {
+                        float4 o;
+                        o.x = ar[0][cb][0];
+                        o.y = ar[0][cb][1];
+                        o.z = ar[0][cb][2];
+                        o.w = HAS_ALPHA ? alphabuf[cb * 32 + r] : 0.f;
+                        *reinterpret_cast<float4*>(A.raw + gpt * 4) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// backward
+// ----------------------------------------------------------------------------
+constexpr int DPE_LD = 100;   // fp32 words per point in the d(gamma) scratch (96 used)
+
+template <int CB>
+__device__ __forceinline__ void dpe_add(float* dpe, const f32x16 (&acc)[1][CB], int rb, int col0, int lane,
+                                        bool accumulate) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float* p = dpe + (cb * 32 + r) * DPE_LD + col0 + rb * 32 + 8 * g + 4 * h;
+            f32x4 v = {acc[0][cb][4 * g], acc[0][cb][4 * g + 1], acc[0][cb][4 * g + 2], acc[0][cb][4 * g + 3]};
+            if (accumulate) v += *reinterpret_cast<f32x4*>(p);
+            *reinterpret_cast<f32x4*>(p) = v;
+        }
+}
+
+template <class N, int NS, int MT, bool HAS_ALPHA>
+__global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL;
+    constexpr int CB = MT / 32;
+    constexpr int RB = N::NRB >= NWAVES ? N::NRB / NWAVES : 1;
+    constexpr int RBV = N::NRBV >= NWAVES ? N::NRBV / NWAVES : 1;
+    constexpr int ACT_ROW = HW * 2, ACT_PLANE = MT * ACT_ROW;
+    constexpr int PARTS = NTHREADS / MT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* dimg = smem;
+    float* dpe = reinterpret_cast<float*>(smem + NS * ACT_PLANE);
+    float* drawbuf = dpe + MT * DPE_LD;                 // [MT][4]
+    float* dxbuf = drawbuf + MT * 4;                    // [PARTS][MT][6]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bf16x8* wpk = reinterpret_cast<const bf16x8*>(A.wpk);
+    auto seg = [&](int entry) { return wpk + (long long)entry * NS * 64; };
+    const int rb0 = w * RB, rbv0 = w * RBV;
+    const bool trunk_active = rb0 < N::NRB, views_active = rbv0 < N::NRBV;
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * MT;
+        for (int i = tid; i < MT * 4; i += NTHREADS) {
+            const long long gpt = pt0 + i / 4;
+            drawbuf[i] = gpt < A.P ? A.draw[gpt * 4 + (i & 3)] : 0.f;
+        }
+        for (int i = tid; i < MT * DPE_LD; i += NTHREADS) dpe[i] = 0.f;
+        __syncthreads();
+        auto maskw = [&](int ml, int rb, int cb) {
+            return A.mask + mask_index(tile, N::n_mask_layers, ml, N::NRB, rb, CB, cb);
+        };
+        // ---- dZv = (Wrgb^T d_rgb) * relu'(hv)   (K = 3: rank-3 update on the VALU) ----
+        if (views_active) {
+#pragma unroll
+            for (int i = 0; i < RBV; ++i) {
+                f32x16 a[CB];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = (rbv0 + i) * 32 + acc_row(q, h);
+                    const float w0 = A.prm.w_rgb[row], w1 = A.prm.w_rgb[HV + row], w2 = A.prm.w_rgb[2 * HV + row];
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        const float* dr = drawbuf + (cb * 32 + r) * 4;
+                        a[cb][q] = w0 * dr[0] + w1 * dr[1] + w2 * dr[2];
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    store_block_masked<NS>(a[cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rbv0 + i, lane, A.dzv,
+                                           A.plane_hv, HV, pt0 + cb * 32 + r, maskw(NL, rbv0 + i, cb));
+            }
+        }
+        __syncthreads();
+        // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
+        f32x16 acc[RB][CB];
+        if (trunk_active) {
+            acc_bias<RB, CB>(acc, nullptr, rb0, 0, h);
+            seg_gemm<NS, RB, CB, N::KKV>(acc, seg(N::bwd_VAT), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
+        }
+        if (w == NWAVES - 1) {
+            f32x16 ad[1][CB];
+            acc_bias<1, CB>(ad, nullptr, 0, 0, h);
+            seg_gemm<NS, 1, CB, N::KKV>(ad, seg(N::bwd_VBT), 1, 0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
+            dpe_add<CB>(dpe, ad, 0, PE_X, lane, false);
+        }
+        __syncthreads();
+        if (trunk_active) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane, A.dfeat,
+                                           A.plane_h, HW, pt0 + cb * 32 + r, nullptr);
+        }
+        __syncthreads();
+        // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
+        if (trunk_active) {
+            acc_bias<RB, CB>(acc, nullptr, rb0, 0, h);
+            seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::bwd_FEATT), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
+            if (HAS_ALPHA) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float wa = A.prm.w_alpha[(rb0 + i) * 32 + acc_row(q, h)];
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) acc[i][cb][q] += wa * drawbuf[(cb * 32 + r) * 4 + 3];
+                    }
+            }
+        }
+        __syncthreads();
+        if (trunk_active) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                                           A.dz[NL - 1], A.plane_h, HW, pt0 + cb * 32 + r, maskw(NL - 1, rb0 + i, cb));
+        }
+        __syncthreads();
+        // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
+#pragma unroll 1
+        for (int l = NL - 1; l >= 1; --l) {
+            if (l == N::SKIP && w < 2) {    // gamma(x) rows of the skip layer's input
+                f32x16 ap[1][CB];
+                acc_bias<1, CB>(ap, nullptr, 0, 0, h);
+                seg_gemm<NS, 1, CB, N::KKH>(ap, seg(N::bwd_LT(l, false)), 2, w, dimg, ACT_PLANE, ACT_ROW, 0, lane);
+                dpe_add<CB>(dpe, ap, w, 0, lane, false);
+            }
+            if (trunk_active) {
+                acc_bias<RB, CB>(acc, nullptr, rb0, 0, h);
+                seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::bwd_LT(l, true)), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0,
+                                             lane);
+            }
+            __syncthreads();
+            if (trunk_active) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                                               A.dz[l - 1], A.plane_h, HW, pt0 + cb * 32 + r, maskw(l - 1, rb0 + i, cb));
+            }
+            __syncthreads();
+        }
+        // ---- layer 0: d gamma(x) += W_0^T dZ_0 ----
+        if (w < 2) {
+            f32x16 ap[1][CB];
+            acc_bias<1, CB>(ap, nullptr, 0, 0, h);
+            seg_gemm<NS, 1, CB, N::KKH>(ap, seg(N::bwd_LT(0, false)), 2, w, dimg, ACT_PLANE, ACT_ROW, 0, lane);
+            dpe_add<CB>(dpe, ap, w, 0, lane, N::SKIP >= 0);
+        }
+        __syncthreads();
+        // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos) ----
+        {
+            const int pt = tid % MT, part = tid / MT;
+            const long long gpt = pt0 + pt;
+            float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+            if (gpt < A.P) point_of(A.rays, A.z, A.S, gpt, x, d);
+            float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+            const float* g = dpe + pt * DPE_LD;
+            for (int u = part; u < L_X + L_D; u += PARTS) {
+                const bool isd = u >= L_X;
+                const int k = isd ? u - L_X : u;
+                const int base = isd ? PE_X : 0;
+                const float f = (float)(1 << k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float v = isd ? d[i] : x[i];
+                    float s, c;
+                    sincosf(v * f, &s, &c);
+                    float t = f * (c * g[base + 3 + 6 * k + i] - s * g[base + 3 + 6 * k + 3 + i]);
+                    if (k == 0) t += g[base + i];
+                    if (isd) gd[i] += t; else gx[i] += t;
+                }
+            }
+            float* o = dxbuf + (part * MT + pt) * 6;
+            o[0] = gx[0]; o[1] = gx[1]; o[2] = gx[2]; o[3] = gd[0]; o[4] = gd[1]; o[5] = gd[2];
+        }
+        __syncthreads();
+        for (int i = tid; i < MT * 6; i += NTHREADS) {
+            const int pt = i / 6, c = i % 6;
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) s += dxbuf[(p * MT + pt) * 6 + c];
+            const long long gpt = pt0 + pt;
+            if (gpt < A.P) A.dpts[gpt * 8 + (c < 3 ? c : c + 1)] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// weight gradient: dW[o][i] += sum_p dZ[p][o] * X[p][i]
+// ----------------------------------------------------------------------------
+// Tile 128 (o) x 128 (i) per workgroup, 4 waves as 2x2, contraction over points in
+// steps of 32.  Both operands are [point][feature] row-major in HBM; the MFMA wants
+// 8 consecutive POINTS per lane, so fragments are read from the LDS tile with the
+// transposing ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
+constexpr int DW_T = 128, DW_KT = 32, DW_ROW = DW_T * 2;   // LDS row = 256 B
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
+    // lane supplies the address of row (k0 + 8*(G>>1) + 4t + q), columns col0 + 16*(G&1) + 4p .. +3
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const char* a0 = tile + (k0 + 8 * (G >> 1) + q) * DW_ROW + (col0 + 16 * (G & 1) + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * DW_ROW));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.v;
+}
+
+template <int NS>
+__global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const DwArgs A) {
+    __shared__ __attribute__((aligned(16))) char tiles[2 * NS * DW_KT * DW_ROW];   // Z planes then X planes
+    char* zt = tiles;
+    char* xt = tiles + NS * DW_KT * DW_ROW;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wo = w >> 1, wi = w & 1;             // wave position in the 2x2 grid
+    const int o0 = blockIdx.x * DW_T, i0 = blockIdx.y * DW_T;
+    const long long p_begin = (long long)blockIdx.z * A.pts_per_split;
+    long long p_end = p_begin + A.pts_per_split;
+    if (p_end > A.Ppad) p_end = A.Ppad;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    const int zcols = A.n_out - o0, xcols = A.k_in - i0;   // valid columns in this tile (may exceed 128)
+    for (long long p0 = p_begin; p0 < p_end; p0 += DW_KT) {
+        // stage [32 points][128 cols] of every plane, 16 bytes per thread-load
+        for (int i = tid; i < NS * DW_KT * 16; i += NTHREADS) {
+            const int c = i & 15, row = (i >> 4) % DW_KT, pl = i / (16 * DW_KT);
+            uint4 vz = {0, 0, 0, 0}, vx = {0, 0, 0, 0};
+            if (c * 8 < zcols)
+                vz = *reinterpret_cast<const uint4*>(A.Z + pl * A.z_plane + (p0 + row) * A.ldz + o0 + c * 8);
+            if (c * 8 < xcols)
+                vx = *reinterpret_cast<const uint4*>(A.X + pl * A.x_plane + (p0 + row) * A.ldx + A.xcol0 + i0 + c * 8);
+            *reinterpret_cast<uint4*>(zt + (pl * DW_KT + row) * DW_ROW + c * 16) = vz;
+            *reinterpret_cast<uint4*>(xt + (pl * DW_KT + row) * DW_ROW + c * 16) = vx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < DW_KT / 16; ++ks) {
+            bf16x8 a[2][NS], b[2][NS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) {
+                    a[t][pl] = tr_frag(zt + pl * DW_KT * DW_ROW, ks * 16, wo * 64 + t * 32, lane);
+                    b[t][pl] = tr_frag(xt + pl * DW_KT * DW_ROW, ks * 16, wi * 64 + t * 32, lane);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = mfma_planes<NS>(a[t], b[u], acc[t][u]);
+        }
+        __syncthreads();
+    }
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = o0 + wo * 64 + t * 32 + acc_row(q, h);
+                const int i = i0 + wi * 64 + u * 32 + r;
+                if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[t][u][q]);
+            }
+}
+
+// db[o] += sum_p sum_planes dZ[p][o]
+template <int NS>
+__global__ __launch_bounds__(NTHREADS) void colsum_kernel(const __bf16* __restrict__ Z, long long plane, int ld,
+                                                          int n, long long Ppad, int pts_per_block,
+                                                          float* __restrict__ out) {
+    const long long p0 = (long long)blockIdx.x * pts_per_block;
+    long long p1 = p0 + pts_per_block;
+    if (p1 > Ppad) p1 = Ppad;
+    const int nchunk = (n + 7) / 8;            // 16-byte chunks per row
+    const int rows_par = NTHREADS / nchunk;    // rows handled concurrently
+    const int c = threadIdx.x % nchunk, rr = threadIdx.x / nchunk;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rr < rows_par) {
+        for (long long p = p0 + rr; p < p1; p += rows_par)
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Z + pl * plane + p * ld + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (c * 8 + e < n) atomicAdd(out + c * 8 + e, s[e]);
+    }
+}
+
+// Heads whose dZ is the fp32 d_raw: rgb_linear (X = hv) and alpha_linear (X = h_{NL-1}).
+template <int NS>
+__global__ __launch_bounds__(NTHREADS) void head_dw_kernel(const float* __restrict__ draw, long long P,
+                                                           const __bf16* __restrict__ hv, long long plane_hv, int HV,
+                                                           const __bf16* __restrict__ hl, long long plane_h, int HW,
+                                                           int pts_per_block, float* __restrict__ dw_rgb,
+                                                           float* __restrict__ db_rgb, float* __restrict__ dw_alpha,
+                                                           float* __restrict__ db_alpha) {
+    __shared__ float dr[64][4];
+    const long long p0 = (long long)blockIdx.x * pts_per_block;
+    long long p1 = p0 + pts_per_block;
+    if (p1 > P) p1 = P;
+    const int j = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, aa = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    for (long long pc = p0; pc < p1; pc += 64) {
+        __syncthreads();
+        if (j < 256) {
+            const long long p = pc + j / 4;
+            dr[j / 4][j & 3] = p < p1 ? draw[p * 4 + (j & 3)] : 0.f;
+        }
+        __syncthreads();
+        const int n = (int)((p1 - pc) < 64 ? (p1 - pc) : 64);
+        for (int t = 0; t < n; ++t) {
+            const long long p = pc + t;
+            if (j < HV) {
+                float x = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) x += (float)hv[pl * plane_hv + p * HV + j];
+                a0 += dr[t][0] * x; a1 += dr[t][1] * x; a2 += dr[t][2] * x;
+            }
+            if (dw_alpha != nullptr && j < HW) {
+                float x = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) x += (float)hl[pl * plane_h + p * HW + j];
+                aa += dr[t][3] * x;
+            }
+            if (j == 0) { b0 += dr[t][0]; b1 += dr[t][1]; b2 += dr[t][2]; b3 += dr[t][3]; }
+        }
+    }
+    if (j < HV) {
+        atomicAdd(dw_rgb + j, a0);
+        atomicAdd(dw_rgb + HV + j, a1);
+        atomicAdd(dw_rgb + 2 * HV + j, a2);
+    }
+    if (dw_alpha != nullptr && j < HW) atomicAdd(dw_alpha + j, aa);
+    if (j == 0) {
+        atomicAdd(db_rgb, b0); atomicAdd(db_rgb + 1, b1); atomicAdd(db_rgb + 2, b2);
+        if (db_alpha != nullptr) atomicAdd(db_alpha, b3);
+    }
+}
+
+}  // namespace lush
+
+// ============================================================================
+// host launchers (C++ linkage inside the library; the C ABI is in lush_abi.hip)
+// ============================================================================
+#include "lush_host.h"
+
+namespace lush {
+
+size_t mlp_fwd_lds_bytes(int hw, int ns, int mt) {
+    return (size_t)ns * mt * hw * 2 + (size_t)ns * mt * PE_ROW * 2 + (size_t)mt * 4;
+}
+size_t mlp_bwd_lds_bytes(int hw, int ns, int mt) {
+    return (size_t)ns * mt * hw * 2 + (size_t)mt * DPE_LD * 4 + (size_t)mt * 16 + (size_t)(NTHREADS / mt) * mt * 24;
+}
+
+template <class N, int NS, bool HAS_ALPHA>
+static int launch_fwd_t(const MlpFwdArgs& a, int grid, hipStream_t s) {
+    constexpr int MT = 64;
+    auto k = mlp_fwd_kernel<N, NS, MT, HAS_ALPHA>;
+    const size_t lds = mlp_fwd_lds_bytes(N::HW, NS, MT);
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+template <class N, int NS, bool HAS_ALPHA>
+static int launch_bwd_t(const MlpBwdArgs& a, int grid, hipStream_t s) {
+    constexpr int MT = 64;
+    auto k = mlp_bwd_kernel<N, NS, MT, HAS_ALPHA>;
+    const size_t lds = mlp_bwd_lds_bytes(N::HW, NS, MT);
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s) {
+    if (net == 0) {
+        if (ns == 1) return launch_fwd_t<NetNerf, 1, true>(a, grid, s);
+        if (ns == 2) return launch_fwd_t<NetNerf, 2, true>(a, grid, s);
+        if (ns == 3) return launch_fwd_t<NetNerf, 3, true>(a, grid, s);
+    } else {
+        if (ns == 1) return launch_fwd_t<NetNoise, 1, false>(a, grid, s);
+        if (ns == 2) return launch_fwd_t<NetNoise, 2, false>(a, grid, s);
+        if (ns == 3) return launch_fwd_t<NetNoise, 3, false>(a, grid, s);
+    }
+    return set_error("launch_mlp_fwd: bad net/planes");
+}
+int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s) {
+    if (net == 0) {
+        if (ns == 1) return launch_bwd_t<NetNerf, 1, true>(a, grid, s);
+        if (ns == 2) return launch_bwd_t<NetNerf, 2, true>(a, grid, s);
+        if (ns == 3) return launch_bwd_t<NetNerf, 3, true>(a, grid, s);
+    } else {
+        if (ns == 1) return launch_bwd_t<NetNoise, 1, false>(a, grid, s);
+        if (ns == 2) return launch_bwd_t<NetNoise, 2, false>(a, grid, s);
+        if (ns == 3) return launch_bwd_t<NetNoise, 3, false>(a, grid, s);
+    }
+    return set_error("launch_mlp_bwd: bad net/planes");
+}
+
+int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s) {
+    if (ns == 1) hipLaunchKernelGGL(pack_kernel<1>, dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    else if (ns == 2) hipLaunchKernelGGL(pack_kernel<2>, dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    else if (ns == 3) hipLaunchKernelGGL(pack_kernel<3>, dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    else return set_error("launch_pack: bad planes");
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
+    dim3 grid((a.n_out + DW_T - 1) / DW_T, (a.k_in + DW_T - 1) / DW_T, splits);
+    if (ns == 1) hipLaunchKernelGGL(dw_gemm_kernel<1>, grid, dim3(NTHREADS), 0, s, a);
+    else if (ns == 2) hipLaunchKernelGGL(dw_gemm_kernel<2>, grid, dim3(NTHREADS), 0, s, a);
+    else if (ns == 3) hipLaunchKernelGGL(dw_gemm_kernel<3>, grid, dim3(NTHREADS), 0, s, a);
+    else return set_error("launch_dw: bad planes");
+    LUSH_HIP(hipGetLastError());
+    if (a.db != nullptr) {
+        const int ppb = 4096;
+        const int blocks = (int)((a.Ppad + ppb - 1) / ppb);
+        if (ns == 1) hipLaunchKernelGGL(colsum_kernel<1>, dim3(blocks), dim3(NTHREADS), 0, s, a.Z, a.z_plane, a.ldz, a.n_out, (long long)a.Ppad, ppb, a.db);
+        else if (ns == 2) hipLaunchKernelGGL(colsum_kernel<2>, dim3(blocks), dim3(NTHREADS), 0, s, a.Z, a.z_plane, a.ldz, a.n_out, (long long)a.Ppad, ppb, a.db);
+        else hipLaunchKernelGGL(colsum_kernel<3>, dim3(blocks), dim3(NTHREADS), 0, s, a.Z, a.z_plane, a.ldz, a.n_out, (long long)a.Ppad, ppb, a.db);
+        LUSH_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
+                   const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
+                   float* db_alpha, hipStream_t s) {
+    const int ppb = 2048;
+    const int blocks = (int)((P + ppb - 1) / ppb);
+    if (ns == 1) hipLaunchKernelGGL(head_dw_kernel<1>, dim3(blocks), dim3(NTHREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else if (ns == 2) hipLaunchKernelGGL(head_dw_kernel<2>, dim3(blocks), dim3(NTHREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else hipLaunchKernelGGL(head_dw_kernel<3>, dim3(blocks), dim3(NTHREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lush

@@ -1,0 +1,158 @@
+"""Loader / builder for liblush_march.so (the hand-written HIP kernels + C ABI).
+
+The shared object is built IN-TREE by ``build()`` (hipcc --offload-arch=gfx950)
+and loaded with ctypes.  There is no fallback: if the library is missing or a
+call fails the product raises.  Signatures mirror include/lush_march.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO_PATH = os.path.join(HERE, "liblush_march.so")
+SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_abi.hip"]
+HEADERS = ["lush_common.h", "lush_mlp.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
+
+_lib = None
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into lush_nerf_amd/liblush_march.so."""
+    if not force and not needs_build():
+        return SO_PATH
+    # -ffp-contract=off: fp32 VALU expressions round op by op like the reference's torch ops
+    # (o + d*z must not become one FMA: a 1-ulp point error is amplified x512 by the encoding).
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    return SO_PATH
+
+
+class MlpParams(C.Structure):
+    _fields_ = [("w", C.c_void_p * 8), ("b", C.c_void_p * 8)] + \
+        [(n, C.c_void_p) for n in ("w_feat", "b_feat", "w_alpha", "b_alpha", "w_views", "b_views",
+                                   "w_rgb", "b_rgb")]
+
+
+class RbkParams(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("w_trunk", C.c_void_p * 4), ("b_trunk", C.c_void_p * 4)] + \
+        [(n, C.c_void_p) for n in ("w_rb", "b_rb", "w_vb", "b_vb", "w_wb", "b_wb", "w_r", "b_r",
+                                   "w_v", "b_v", "w_w", "b_w")]
+
+
+_p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+_SIGS = {
+    "lush_abi_version": ([], _i),
+    "lush_zgrid": ([_p, _i, _i, _i, _p, _p, _p], _i),
+    "lush_zfixed": ([_p, _i, _i, _i, _i, _p, _p], _i),
+    "lush_composite_fwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_composite_bwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_sample_merge": ([_p, _p, _i, _i, _i, _p, _p, _p, _p, _p], _i),
+    "lush_pack_rays_fwd": ([_p, _i, _i, _f, _f, _f, _f, _p, _p], _i),
+    "lush_pack_rays_bwd": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),
+    "lush_rbk_mlp_fwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p], _i),
+    "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, C.POINTER(RbkParams), _p, _p], _i),
+    "lush_rbk_warp_fwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
+    "lush_rbk_warp_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p], _i),
+    "lush_wsum_fwd": ([_p, _p, _i, _i, _i, _p, _p], _i),
+    "lush_wsum_bwd": ([_p, _p, _i, _i, _i, _p, _p, _p, _p], _i),
+    "lush_tonemap_fwd": ([_p, _p, _i, _i, _p, _p], _i),
+    "lush_tonemap_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
+    "lush_noise_act_fwd": ([_p, _i, _p, _p], _i),
+    "lush_noise_act_bwd": ([_p, _i, _p, _p, _p], _i),
+    "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _p, _p, _p, _p], _i),
+    "lush_mlp_packed_bytes": ([_i, _i], _sz),
+    "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
+    "lush_mlp_stash_bytes": ([_i, _i, _ll], _sz),
+    "lush_mlp_dstash_bytes": ([_i, _i, _ll], _sz),
+    "lush_mlp_fwd": ([_i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p], _i),
+    "lush_mlp_bwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p,
+                      C.POINTER(MlpParams), _p, _p], _i),
+    "lush_ray_grad_reduce": ([_p, _p, _i, _i, _p, _p], _i),
+    "lush_adam": ([_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p], _i),
+    "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
+}
+EXPORTS = ["lush_last_error"] + list(_SIGS)
+
+
+def load():
+    """Load the library (building is NOT implicit: call build() first)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is required; there is no fallback path)")
+    lib = C.CDLL(SO_PATH)
+    lib.lush_last_error.argtypes = []
+    lib.lush_last_error.restype = C.c_char_p
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point; raise with lush_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.lush_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def mlp_struct(tensors: Sequence, n_layers: int) -> MlpParams:
+    """tensors = [w0,b0,...,w{n-1},b{n-1}, views_w, views_b, feat_w, feat_b, alpha_w, alpha_b, rgb_w, rgb_b]."""
+    s = MlpParams()
+    for l in range(n_layers):
+        s.w[l] = tensors[2 * l].data_ptr()
+        s.b[l] = tensors[2 * l + 1].data_ptr()
+    o = 2 * n_layers
+    s.w_views, s.b_views = tensors[o].data_ptr(), tensors[o + 1].data_ptr()
+    s.w_feat, s.b_feat = tensors[o + 2].data_ptr(), tensors[o + 3].data_ptr()
+    s.w_alpha, s.b_alpha = tensors[o + 4].data_ptr(), tensors[o + 5].data_ptr()
+    s.w_rgb, s.b_rgb = tensors[o + 6].data_ptr(), tensors[o + 7].data_ptr()
+    return s
+
+
+def rbk_struct(tensors: Sequence) -> RbkParams:
+    """tensors = [embed, (w,b)x4 trunk, r_branch w,b, v_branch w,b, w_branch w,b, r_linear w,b,
+    v_linear w,b, w_linear w,b]."""
+    s = RbkParams()
+    s.embed = tensors[0].data_ptr()
+    for l in range(4):
+        s.w_trunk[l] = tensors[1 + 2 * l].data_ptr()
+        s.b_trunk[l] = tensors[2 + 2 * l].data_ptr()
+    names = ("w_rb", "b_rb", "w_vb", "b_vb", "w_wb", "b_wb", "w_r", "b_r", "w_v", "b_v", "w_w", "b_w")
+    for k, n in enumerate(names):
+        setattr(s, n, tensors[9 + k].data_ptr())
+    return s

@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's model interface for the ray-march path.
+
+Class, method and parameter names follow models/lushnerf.py and
+utils/run_lushnerf_helpers.py so that (a) a reference state_dict loads here and
+vice versa (same 108 keys incl. the triple-aliased RBK) and (b) the
+reference's train() can call ``nerf(H, W, K, chunk=..., rays=..., rays_info=..., ...)``
+unchanged.  The nn.Linear / nn.Embedding modules are parameter containers only:
+all arithmetic runs in the HIP kernels behind lush_nerf_amd.ops.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import MarchCfg, Precision
+
+
+def _linear_stack(dims):
+    return nn.ModuleList([nn.Linear(i, o) for i, o in dims])
+
+
+class NeRF(nn.Module):
+    """Parameter layout of utils/run_lushnerf_helpers.py:365-392 (use_viewdirs=True)."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=(4,),
+                 use_viewdirs=True, use_awp=False):
+        super().__init__()
+        if not use_viewdirs:
+            raise NotImplementedError("the MI355X path implements the use_viewdirs=True topology only")
+        if tuple(skips) != (4,) or (D, W) not in ((8, 256), (4, 128)) or input_ch != 63 or input_ch_views != 27:
+            raise NotImplementedError("kernels are built for D=8/W=256 (NeRF) and D=4/W=128 (NeRF_Noise), "
+                                      "multires=10, multires_views=4, skips=[4]")
+        self.D, self.W = D, W
+        self.pts_linears = _linear_stack(
+            [(input_ch, W)] + [(W + input_ch, W) if (i in skips) else (W, W) for i in range(D - 1)])
+        self.views_linears = _linear_stack([(input_ch_views + W, W // 2)])
+        self.feature_linear = nn.Linear(W, W)
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+
+    def tensors(self) -> List[torch.Tensor]:
+        t = []
+        for l in self.pts_linears:
+            t += [l.weight, l.bias]
+        for m in (self.views_linears[0], self.feature_linear, self.alpha_linear, self.rgb_linear):
+            t += [m.weight, m.bias]
+        return t
+
+
+class NeRF_Noise(NeRF):
+    """utils/run_lushnerf_helpers.py:456-512: same layout; alpha_linear is never used."""
+
+
+class View_Embedding(nn.Module):
+    def __init__(self, num_embed, embed_dim):
+        super().__init__()
+        self.num_embed, self.embed_dim = num_embed, embed_dim
+        self.view_embed_layer = nn.Embedding(num_embed, embed_dim)
+
+
+class Rigid_Blurring_Kernel(nn.Module):
+    """models/lushnerf.py:37-153 (parameters + the two public methods)."""
+
+    def __init__(self, D, W, D_r, W_r, D_v, W_v, D_w, W_w, output_ch_r, output_ch_v, input_ch, skips,
+                 rv_window, num_motion=2, near=0.0, far=1.0, ndc=False, warp_field=None,
+                 view_embedding_layer=None, use_origin=True):
+        super().__init__()
+        if (D, W, D_r, W_r, D_v, W_v, D_w, W_w, output_ch_r, output_ch_v, input_ch) != \
+                (4, 64, 1, 32, 1, 32, 1, 32, 3, 3, 64) or not use_origin or not (1 <= num_motion <= 4):
+            raise NotImplementedError("RBK kernels are built for the shipped config (configs/*_lushnerf:36-54)")
+        self.num_motion, self.rv_window, self.use_origin = num_motion, rv_window, use_origin
+        self.view_embedding_layer = view_embedding_layer
+        self.view_embed_linears = _linear_stack([(input_ch, W)] + [(W, W)] * (D - 1))
+        self.r_branch = _linear_stack([(W, W_r)])
+        self.r_linear = nn.Linear(W_r, output_ch_r * num_motion)
+        self.v_branch = _linear_stack([(W, W_v)])
+        self.v_linear = nn.Linear(W_v, output_ch_v * num_motion)
+        self.w_branch = _linear_stack([(W, W_w)])
+        self.w_linear = nn.Linear(W_w, num_motion + 1)
+        bound = 1e-5 * 6.0 / (W_r + output_ch_r * num_motion)      # xavier_uniform, reference gain (:62-68)
+        for lin in (self.r_linear, self.v_linear):
+            nn.init.uniform_(lin.weight, -bound, bound)
+
+    def tensors(self) -> List[torch.Tensor]:
+        t = [self.view_embedding_layer.view_embed_layer.weight]
+        for l in self.view_embed_linears:
+            t += [l.weight, l.bias]
+        for m in (self.r_branch[0], self.v_branch[0], self.w_branch[0], self.r_linear, self.v_linear, self.w_linear):
+            t += [m.weight, m.bias]
+        return t
+
+    def forward(self, rays, rays_info, grad_mask=None):
+        """rays [N,3,2], rays_info['images_idx'] [N,1] -> (new_rays [N*(M+1),3,2], ccw [N,M+1])."""
+        return ops.RbkWarp.apply(rays, rays_info['images_idx'], self.num_motion, self.rv_window, grad_mask,
+                                 *self.tensors())
+
+    def rbk_weighted_sum(self, rgb, depth, acc, extras, ccw):
+        rgb, depth, acc = ops.WSum.apply(rgb, ccw), ops.WSum.apply(depth, ccw), ops.WSum.apply(acc, ccw)
+        for k, v in extras.items():
+            if 1 <= v.dim() <= 3:
+                extras[k] = ops.WSum.apply(v, ccw)
+        return rgb, depth, acc, extras
+
+
+class RBK(nn.Module):
+    """models/lushnerf.py:156-175."""
+
+    def __init__(self, num_img, view_embed_ch, D_rbk, W_rbk, D_rbk_r, W_rbk_r, D_rbk_v, W_rbk_v, D_rbk_w, W_rbk_w,
+                 output_ch_rbk_r, output_ch_rbk_v, skips_rbk, rbk_use_origin, rbk_se_rv_window, num_motion_rbk,
+                 use_dpnerf=True, use_awp=False, near=0.0, far=1.0, ndc=False):
+        super().__init__()
+        self.use_dpnerf, self.view_embed_ch, self.use_awp = use_dpnerf, view_embed_ch, use_awp
+        self.view_embed_layer = View_Embedding(num_embed=num_img, embed_dim=view_embed_ch)
+        self.RBK = Rigid_Blurring_Kernel(
+            D=D_rbk, W=W_rbk, num_motion=num_motion_rbk, D_r=D_rbk_r, W_r=W_rbk_r, output_ch_r=output_ch_rbk_r,
+            D_v=D_rbk_v, W_v=W_rbk_v, output_ch_v=output_ch_rbk_v, D_w=D_rbk_w, W_w=W_rbk_w,
+            rv_window=rbk_se_rv_window, view_embedding_layer=self.view_embed_layer, use_origin=rbk_use_origin,
+            input_ch=view_embed_ch, skips=skips_rbk, near=near, far=far, ndc=ndc)
+
+
+class NeRFAll(nn.Module):
+    """models/lushnerf.py:177-989 restricted to the ray-march path."""
+
+    def __init__(self, args, blur_kernel_net=None, precision: Optional[Precision] = None):
+        super().__init__()
+        self.args = args
+        self.precision = precision or Precision()
+        self.blur_model_type = args.blur_model_type
+        self.blur_kernel_net = blur_kernel_net
+        if args.multires != 10 or args.multires_views != 4 or args.i_embed != 0 or not args.use_viewdirs:
+            raise NotImplementedError("kernels are built for multires=10, multires_views=4, use_viewdirs")
+        if args.rgb_activate != 'sigmoid' or args.sigma_activate != 'relu':
+            raise NotImplementedError("kernels implement rgb_activate=sigmoid, sigma_activate=relu (configs/*)")
+        if args.tone_mapping_type not in ('gamma', 'none'):
+            raise NotImplementedError("tone mapping 'gamma' and 'none' only (no config uses the learned ones)")
+        self.input_ch, self.input_ch_views = 63, 27
+        self.mlp_coarse = NeRF(D=args.netdepth, W=args.netwidth)
+        self.mlp_noise_coarse = NeRF_Noise(D=args.netdepth // 2, W=args.netwidth // 2)
+        self.mlp_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine) if args.N_importance > 0 else None
+        if blur_kernel_net is not None and self.blur_model_type == 'dpnerf':
+            self.dbk_view_embedding = blur_kernel_net.view_embed_layer
+            self.mlp_rbk = blur_kernel_net.RBK
+        self.gamma = args.tone_mapping_type == 'gamma'
+
+    # ------------------------------------------------------------------ helpers
+    def tonemapping(self, x, noise_raw=None):
+        return ops.ToneMap.apply(x, noise_raw, self.gamma)
+
+    def _draws(self, R, N_samples, N_importance, perturb, raw_noise_std, device, draws):
+        """Random draws in the reference's order and shapes (models/lushnerf.py:515, :322;
+        helpers:578) unless given explicitly (parity tests)."""
+        if draws is not None:
+            return draws
+        d = {}
+        if perturb > 0:
+            d["t_rand"] = torch.rand(R, N_samples, device=device)
+        if raw_noise_std > 0:
+            d["noise_c"] = torch.randn(R, N_samples - 1, device=device)
+        if N_importance > 0:
+            if perturb > 0:
+                d["u"] = torch.rand(R, N_importance, device=device)
+            if raw_noise_std > 0:
+                d["noise_f"] = torch.randn(R, N_samples + N_importance - 1, device=device)
+        return d
+
+    def _march(self, ray_batch, N_samples, N_importance, perturb, raw_noise_std, white_bkgd, lindisp, retraw,
+               draws=None):
+        near_mask = -1.0
+        if (not self.training) and getattr(self.args, "render_rmnearplane", 0) > 0:
+            near_mask = self.args.render_rmnearplane / 128
+        cfg = MarchCfg(N_samples=N_samples, N_importance=N_importance, perturb=float(perturb),
+                       raw_noise_std=float(raw_noise_std), white_bkgd=bool(white_bkgd), lindisp=bool(lindisp),
+                       near_mask=near_mask, precision=self.precision, has_fine=self.mlp_fine is not None,
+                       want_grad=torch.is_grad_enabled())
+        R = ray_batch.shape[0]
+        d = self._draws(R, N_samples, N_importance, perturb, raw_noise_std, ray_batch.device, draws)
+        coarse = self.mlp_coarse.tensors()
+        fine = self.mlp_fine.tensors() if (self.mlp_fine is not None and N_importance > 0) else []
+        out = ops.March.apply(ray_batch, cfg, d, len(coarse), *coarse, *fine)
+        ret = {'rgb_map': out[0], 'depth_map': out[1], 'acc_map': out[2], 'density_map': out[3]}
+        if retraw:
+            ret['raw'] = out[4]
+        if N_importance > 0:
+            ret.update(rgb0=out[7], depth0=out[8], acc0=out[9], density0=out[10], z_std=out[11])
+        return ret
+
+    def _noise(self, ray_batch, N_samples, lindisp):
+        return ops.NoiseMlp.apply(ray_batch.detach(), N_samples, 16, bool(lindisp), self.precision,
+                                  torch.is_grad_enabled(),
+                                  *self.mlp_noise_coarse.tensors())
+
+    # ------------------------------------------------------------------ render_rays trio
+    def render_rays(self, ray_batch, N_samples, img_idx=None, retraw=False, lindisp=False, perturb=0.,
+                    N_importance=0, white_bkgd=False, raw_noise_std=0., pytest=False, force_naive=False,
+                    inference=False, draws=None):
+        """models/lushnerf.py:354-479 -> (ret, ret_noise)."""
+        ret = self._march(ray_batch, N_samples, N_importance, perturb, raw_noise_std, white_bkgd, lindisp, retraw,
+                          draws)
+        noise = self._noise(ray_batch, N_samples, lindisp)
+        ret_noise = {'rgb_map': noise}
+        if retraw:
+            ret_noise['raw'] = 0
+        if N_importance > 0:
+            ret_noise['rgb0'] = noise
+        return ret, ret_noise
+
+    def render_rays_nonoise(self, ray_batch, N_samples, img_idx=None, retraw=False, lindisp=False, perturb=0.,
+                            N_importance=0, white_bkgd=False, raw_noise_std=0., pytest=False, force_naive=False,
+                            inference=False, draws=None):
+        """models/lushnerf.py:481-583 -> ret."""
+        return self._march(ray_batch, N_samples, N_importance, perturb, raw_noise_std, white_bkgd, lindisp, retraw,
+                           draws)
+
+    def render_rays_noise(self, ray_batch, N_samples, img_idx=None, retraw=False, lindisp=False, perturb=0.,
+                          N_importance=0, white_bkgd=False, raw_noise_std=0., pytest=False, force_naive=False,
+                          inference=False, draws=None):
+        """models/lushnerf.py:585-617 -> {'rgb_map'}."""
+        return {'rgb_map': self._noise(ray_batch, N_samples, lindisp)}
+
+    # ------------------------------------------------------------------ the "render()" trio
+    def _pack(self, H, W, K, rays, ndc, near, far, use_viewdirs):
+        if not use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False is not built (every config sets it)")
+        sh = rays.shape[:-2]
+        return ops.PackRays.apply(rays, H, W, float(K[0][0]), ndc, near, far), sh
+
+    @staticmethod
+    def _slice_draws(draws, i, j):
+        return None if draws is None else {k: v[i:j] for k, v in draws.items()}
+
+    def _chunks(self, fn, batch, chunk, draws):
+        outs = []
+        for i in range(0, batch.shape[0], chunk):
+            outs.append(fn(batch[i:i + chunk], self._slice_draws(draws, i, i + chunk)))
+        return outs
+
+    @staticmethod
+    def _merge(dicts, sh):
+        out = {}
+        for k in dicts[0]:
+            v = torch.cat([d[k] for d in dicts], 0) if len(dicts) > 1 else dicts[0][k]
+            out[k] = v.reshape(list(sh) + list(v.shape[1:]))
+        return out
+
+    def render_infer(self, H, W, K, chunk, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+                     c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None, render_noise=True,
+                     draws=None, **kwargs):
+        """models/lushnerf.py:679-763 -> ([rgb, depth, acc, extras], noise_rgb)."""
+        batch, sh = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
+        res = self._chunks(lambda b, d: self.render_rays(b, draws=d, **kwargs), batch, chunk, draws)
+        all_ret = self._merge([r[0] for r in res], sh)
+        noise = torch.cat([r[1]['rgb_map'] for r in res], 0)
+        k_extract = ['rgb_map', 'depth_map', 'acc_map']
+        return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}], noise
+
+    def render_train_scene(self, H, W, K, chunk, rays=None, c2w=None, ndc=True, near=0., far=1.,
+                           use_viewdirs=False, c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None,
+                           render_noise=True, draws=None, **kwargs):
+        """models/lushnerf.py:766-819 -> [rgb, depth, acc, extras]."""
+        batch, sh = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
+        res = self._chunks(lambda b, d: self.render_rays_nonoise(b, draws=d, **kwargs), batch, chunk, draws)
+        all_ret = self._merge(res, sh)
+        k_extract = ['rgb_map', 'depth_map', 'acc_map']
+        return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
+
+    def render_train_noise(self, H, W, K, chunk, rays=None, c2w=None, ndc=True, near=0., far=1.,
+                           use_viewdirs=False, c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None,
+                           render_noise=True, draws=None, **kwargs):
+        """models/lushnerf.py:821-866 -> noise rgb [N,3]."""
+        batch, _ = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
+        res = self._chunks(lambda b, d: self.render_rays_noise(b, **kwargs)['rgb_map'], batch, chunk, None)
+        return torch.cat(res, 0) if len(res) > 1 else res[0]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, H, W, K, chunk=1024 * 32, rays=None, rays_info=None, poses=None, allkernel=False,
+                kernel_pixel=None, consist_loss=False, Align_matrix=None, Align_mask=None, **kwargs):
+        """models/lushnerf.py:619-677.  Training branch returns the reference 7-tuple."""
+        if self.training and not consist_loss:
+            assert rays is not None, "Please specify rays when in the training mode"
+            force_baseline = bool(kwargs['force_naive'])
+            if self.blur_kernel_net is not None and not force_baseline and self.blur_model_type == 'dpnerf':
+                kwargs['img_idx'] = rays_info['images_idx'].squeeze(-1)
+                mask = kernel_pixel if allkernel else None      # torch.where(mask, x, x.detach()) (:641-643)
+                rays_transform, ccw = self.mlp_rbk(rays, rays_info, grad_mask=mask)
+                rgb, depth, acc, extras = self.render_train_scene(H, W, K, chunk, rays_transform, **kwargs)
+                noise_raw = self.render_train_noise(H, W, K, chunk, rays, **kwargs)
+                rgb_noise = ops.NoiseAct.apply(noise_raw)
+                rgb_pure = ops.WSum.apply(rgb, ccw)
+                rgb0_pure = ops.WSum.apply(extras['rgb0'], ccw)
+                return (self.tonemapping(rgb_pure, noise_raw), self.tonemapping(rgb0_pure, noise_raw), {},
+                        rgb_noise, rgb_noise, self.tonemapping(rgb_pure), self.tonemapping(rgb0_pure))
+            kwargs['img_idx'] = rays_info['images_idx'].squeeze(-1)
+            (rgb, depth, acc, extras), noise_raw = self.render_infer(H, W, K, chunk, rays, **kwargs)
+            rgb_noise = ops.NoiseAct.apply(noise_raw)
+            return self.tonemapping(rgb), self.tonemapping(extras['rgb0']), {}, rgb_noise, rgb_noise, {}, {}
+        if self.training and consist_loss:
+            raise NotImplementedError("consistency branch (Render_Aligned_Pixel) is SURVEY section 8(f) row 3: next")
+        assert poses is not None, "Please specify poses when in the eval model"
+        kwargs['render_kwargs'].pop('save_warped_ray_img', False)
+        rgbs, rgbs_noise, depths = self.render_path(H, W, K, chunk, poses, **kwargs)
+        rgbs_noise = ops.NoiseAct.apply(torch.reshape(rgbs_noise, [-1, H, W, 3]))
+        return self.tonemapping(rgbs), self.tonemapping(rgbs_noise), depths
+
+    def render_path(self, H, W, K, chunk, render_poses, render_kwargs, render_factor=0):
+        """models/lushnerf.py:868-896 (eval): one render_infer per pose."""
+        if render_factor != 0:
+            H, W = H // render_factor, W // render_factor
+        rgbs, depths, noises = [], [], []
+        for c2w in render_poses:
+            rays = torch.stack(get_rays(H, W, K, c2w), dim=-1)
+            with torch.no_grad():
+                (rgb, depth, acc, extras), noise = self.render_infer(H, W, K, chunk=chunk, rays=rays,
+                                                                     c2w=c2w[:3, :4], **render_kwargs)
+            rgbs.append(rgb); depths.append(depth); noises.append(noise)
+        return torch.stack(rgbs, 0), torch.stack(noises, 0), torch.stack(depths, 0)
+
+
+def get_rays(H, W, K, c2w):
+    """utils/run_lushnerf_helpers.py:517-528 (host-side ray table for the eval path; plumbing)."""
+    dev = c2w.device
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=dev), torch.linspace(0, H - 1, H, device=dev),
+                          indexing='ij')
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i + (0.5 - K[0][2])) / K[0][0], -(j + (0.5 - K[1][2])) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def load_reference_weights(model: NeRFAll, weights: Dict[str, "torch.Tensor"]):
+    """Copy a {canonical reference name -> array} dict (lush_nerf_amd.synth / a reference
+    state_dict with the 'module.' prefix stripped) into the model."""
+    sd = model.state_dict()
+    new = {}
+    for k in sd:
+        ck = k
+        if k.startswith("blur_kernel_net.RBK."):
+            ck = "mlp_rbk." + k[len("blur_kernel_net.RBK."):]
+        elif k.startswith("blur_kernel_net.view_embed_layer.") or k.startswith("dbk_view_embedding."):
+            ck = "mlp_rbk.view_embedding_layer.view_embed_layer.weight"
+        src = weights[ck] if ck in weights else weights[k]
+        new[k] = torch.as_tensor(src).to(sd[k].dtype)
+    model.load_state_dict(new, strict=True)
+    return model

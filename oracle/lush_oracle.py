@@ -121,8 +121,10 @@ def raw2outputs(raw: Tensor, z_vals: Tensor, rays_d: Tensor, raw_noise_std: floa
         density = (z_vals[:, 1:] > render_rmnearplane / 128).type_as(density) * density
     alpha = 1. - torch.exp(-density * dists)
     alpha = torch.cat([alpha, torch.ones_like(alpha[:, :1])], -1)
+    # (1. + 1e-10) is a Python double that rounds to 1.0f when added to an fp32
+    # tensor, so the reference's epsilon is a no-op (:341); keep the same form.
     trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]),
-                                     1. - alpha + 1e-10], -1), -1)[:, :-1]
+                                     -alpha + (1. + 1e-10)], -1), -1)[:, :-1]
     weights = alpha * trans
     rgb_map = torch.sum(weights[..., None] * rgb, -2)
     depth_map = torch.sum(weights * z_vals, -1)

@@ -57,3 +57,40 @@ def check_grads(named_grads, fixture, tol, skip_missing=False):
     bad = {k: v for k, v in worst.items() if not v <= tol}
     assert not bad, f"gradient mismatch (normalised max err > {tol}): {bad}"
     return worst
+
+
+def stash_planes(stash, off, ns, Ppad, cols):
+    """Decode a [ns][Ppad][cols] bf16-plane array of the forward stash into fp32 (sum of planes)."""
+    sb = stash.cpu().numpy() if isinstance(stash, torch.Tensor) else stash
+    arr = np.frombuffer(sb[off:off + ns * Ppad * cols * 2].tobytes(), dtype=np.uint16)
+    return (arr.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, cols).sum(0)
+
+
+def stash_masks(net, ns, P, stash):
+    """ReLU decisions the GPU forward took: [h_0 > 0, ..., h_{NL-1} > 0, hv > 0] as float tensors."""
+    import ctypes as C
+    from lush_nerf_amd import lib
+    off = (C.c_longlong * 16)()
+    lib.call("lush_debug_stash_layout", net, ns, P, off)
+    Ppad, HW, NL = off[12], off[14], off[15]
+    sb = stash.cpu().numpy()
+    out = [torch.from_numpy((stash_planes(sb, off[2 + l], ns, Ppad, HW)[:P] > 0).astype(np.float32)) for l in range(NL)]
+    out.append(torch.from_numpy((stash_planes(sb, off[11], ns, Ppad, HW // 2)[:P] > 0).astype(np.float32)))
+    return out
+
+
+def nerf_mlp_masked(p, prefix, x, depth, masks):
+    """oracle.nerf_mlp with every ReLU replaced by multiplication with a given 0/1 mask."""
+    import torch.nn.functional as F
+    pts, views = x[..., :63], x[..., 63:90]
+    h = pts
+    for i in range(depth):
+        h = F.linear(h, p[f"{prefix}.pts_linears.{i}.weight"], p[f"{prefix}.pts_linears.{i}.bias"]) * masks[i]
+        if i == 4:
+            h = torch.cat([pts, h], -1)
+    feat = F.linear(h, p[f"{prefix}.feature_linear.weight"], p[f"{prefix}.feature_linear.bias"])
+    hv = F.linear(torch.cat([feat, views], -1), p[f"{prefix}.views_linears.0.weight"],
+                  p[f"{prefix}.views_linears.0.bias"]) * masks[depth]
+    rgb = F.linear(hv, p[f"{prefix}.rgb_linear.weight"], p[f"{prefix}.rgb_linear.bias"])
+    alpha = F.linear(h, p[f"{prefix}.alpha_linear.weight"], p[f"{prefix}.alpha_linear.bias"])
+    return torch.cat([rgb, alpha], -1)
