@@ -174,6 +174,15 @@ int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const f
                  const void* packed_b, const lush_mlp_params* prm, const float* draw,
                  const void* stash, void* dstash, const lush_mlp_grads* grads, float* dpts,
                  lush_stream_t stream);
+/* The same in two halves (so each kernel group can be timed / overlapped separately):
+ * _chain runs the fused dX chain (writes dstash + dpts); _weights runs the weight-gradient
+ * GEMMs over stash x dstash.  lush_mlp_bwd == _chain followed by _weights. */
+int lush_mlp_bwd_chain(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                       const void* packed_b, const lush_mlp_params* prm, const float* draw,
+                       const void* stash, void* dstash, float* dpts, lush_stream_t stream);
+int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const float* draw,
+                         const void* stash, void* dstash, const lush_mlp_grads* grads,
+                         lush_stream_t stream);
 /* d rays from d points: pts = o + d*z (models/lushnerf.py:414, 525).  dpts [R*S][8]
  * -> drays [R][11] accumulate (o: 0..2, d: 3..5, viewdir: 8..10). */
 int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays,

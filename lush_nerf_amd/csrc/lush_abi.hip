@@ -175,9 +175,10 @@ int lush_mlp_fwd(int net, int planes, const float* rays, const float* z, int R, 
     return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
 }
 
-int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
-                 const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
-                 void* dstash, const lush_mlp_grads* g, float* dpts, lush_stream_t stream) {
+static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                        const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
+                        void* dstash, const lush_mlp_grads* g, float* dpts, lush_stream_t stream, int do_chain,
+                        int do_weights) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
     if (planes_b < 1 || planes_b > planes_f || planes_f > 3) return set_error("lush_mlp_bwd: need 1 <= planes_b <= planes_f <= 3");
@@ -202,8 +203,9 @@ int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const f
     a.plane_h = plane_h; a.plane_hv = plane_hv;
     a.dpts = dpts;
     const int grid = (int)(L.n_tiles < 1024 ? L.n_tiles : 1024);
-    int rc = launch_mlp_bwd(net, planes_b, a, grid, st);
-    if (rc) return rc;
+    int rc = 0;
+    if (do_chain) rc = launch_mlp_bwd(net, planes_b, a, grid, st);
+    if (rc || !do_weights) return rc;
 
     const __bf16* pe = (const __bf16*)(sb + L.pe);
     auto H = [&](int l) { return (const __bf16*)(sb + L.h[l]); };
@@ -245,6 +247,22 @@ int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const f
     const __bf16* hv = (const __bf16*)(sb + L.hv);
     return launch_head_dw(planes_b, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
                           net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
+}
+
+int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                 const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
+                 void* dstash, const lush_mlp_grads* g, float* dpts, lush_stream_t stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, g, dpts, stream, 1, 1);
+}
+int lush_mlp_bwd_chain(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                       const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
+                       void* dstash, float* dpts, lush_stream_t stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, nullptr, dpts, stream, 1, 0);
+}
+int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const float* draw, const void* stash,
+                         void* dstash, const lush_mlp_grads* g, lush_stream_t stream) {
+    lush_mlp_params dummy{};
+    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, &dummy, draw, stash, dstash, g, nullptr, stream, 0, 1);
 }
 
 }  // extern "C"

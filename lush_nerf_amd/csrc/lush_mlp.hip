@@ -25,8 +25,13 @@
 
 namespace lush {
 
-constexpr int NWAVES = 4;
+constexpr int NWAVES = 8;                 // fused MLP kernels: 2 waves per SIMD
 constexpr int NTHREADS = NWAVES * WAVE;
+constexpr int DW_THREADS = 256;           // weight-gradient GEMM / reductions: 4 waves as 2x2
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), which
+// would stall every layer on the acknowledgement of the in-flight stash stores.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ----------------------------------------------------------------------------
 // weight packing
@@ -159,7 +164,7 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = acc[4 * g + e];
-            if (RELU) v = fmaxf(v, 0.f);
+            if (RELU) asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));   // plain max: fmaxf() adds a canonicalising v_max
             split_planes<NS>(v, pl[e]);
         }
         const int f = rb * 32 + 8 * g + 4 * h;          // first of 4 consecutive features
@@ -169,9 +174,21 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = pl[e][p];
             *reinterpret_cast<bf16x4*>(img + p * plane_bytes + swz(pt, f >> 3, row_bytes) + (f & 7) * 2) = v;
-            if (stash != nullptr)
-                *reinterpret_cast<bf16x4*>(stash + p * stash_plane + gpt * stash_ld + f) = v;
         }
+    }
+}
+
+// Copy `ncols` columns of every row of an LDS image to the global stash [plane][pt][ld] with
+// 16-byte accesses: consecutive threads take consecutive chunks of a row, so each row leaves
+// as full 128-byte lines (the image is de-swizzled on the way out).
+template <int NS, int MT>
+__device__ __forceinline__ void copy_out(const char* img, int plane_bytes, int row_bytes, int ncols, __bf16* stash,
+                                         long long stash_plane, int stash_ld, long long pt0, int tid, int nthreads) {
+    const int cpr = ncols >> 3;                    // 16-byte chunks per row
+    for (int i = tid; i < NS * MT * cpr; i += nthreads) {
+        const int c = i % cpr, pt = (i / cpr) % MT, p = i / (cpr * MT);
+        const uint4 v = *reinterpret_cast<const uint4*>(img + p * plane_bytes + swz(pt, c, row_bytes));
+        *reinterpret_cast<uint4*>(stash + p * stash_plane + (pt0 + pt) * stash_ld + c * 8) = v;
     }
 }
 
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * MT;
         pe_tile<NS, MT>(peimg, PE_PLANE, A.rays, A.z, A.S, A.P, pt0, tid);
-        __syncthreads();
+        lds_barrier();
         if (stash_on) {   // de-swizzled 16-byte copies of the 96 live PE columns
             for (int i = tid; i < NS * MT * 12; i += NTHREADS) {
                 const int c = i % 12, pt = (i / 12) % MT, p = i / (12 * MT);
@@ -300,7 +317,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                                           stash_on ? A.st.h[0] : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r,
                                           stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, 0, N::NRB, rb0 + i, CB, cb) : nullptr);
         }
-        __syncthreads();
+        lds_barrier();
+        // Stash copies are issued AFTER the weight loads of the layer that consumes the image and
+        // just before the barrier that lets it be overwritten: VMEM completes in order, so a store
+        // in front of a weight load would add its acknowledgement latency to the load.
         // ---- layers 1 .. NL-1 ----
 #pragma unroll 1
         for (int l = 1; l < NL; ++l) {
@@ -312,7 +332,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
-            __syncthreads();
+            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[l - 1], A.st.plane_h, HW, pt0, tid, NTHREADS);
+            lds_barrier();
             if (trunk_active) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                                               stash_on ? A.st.h[l] : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r,
                                               stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, l, N::NRB, rb0 + i, CB, cb) : nullptr);
             }
-            __syncthreads();
+            lds_barrier();
         }
         // ---- feature (no activation) and alpha heads, both read h_{NL-1} ----
         if (trunk_active) {
@@ -338,7 +359,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 for (int cb = 0; cb < CB; ++cb) alphabuf[cb * 32 + r] = aa[0][cb][0];
             }
         }
-        __syncthreads();
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[NL - 1], A.st.plane_h, HW, pt0, tid, NTHREADS);
+        lds_barrier();
         if (trunk_active) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                     store_block<NS, false>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
                                            stash_on ? A.st.feat : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r, nullptr);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
         f32x16 av[RBV][CB];
         const int rbv0 = w * RBV;
@@ -358,7 +380,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
             seg_gemm<NS, RBV, CB, N::KKD>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
-        __syncthreads();
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.feat, A.st.plane_h, HW, pt0, tid, NTHREADS);
+        lds_barrier();
         if (views_active) {
 #pragma unroll
             for (int i = 0; i < RBV; ++i)
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                                           stash_on ? A.st.hv : nullptr, A.st.plane_hv, HV, pt0 + cb * 32 + r,
                                           stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, NL, N::NRB, rbv0 + i, CB, cb) : nullptr);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- rgb head (3 rows) on wave 0; alpha joins from LDS ----
         if (w == 0) {
             f32x16 ar[1][CB];
@@ -389,7 +412,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 }
             }
         }
-        __syncthreads();
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HV, A.st.hv, A.st.plane_hv, HV, pt0, tid, NTHREADS);
+        lds_barrier();
     }
 }
 
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
             drawbuf[i] = gpt < A.P ? A.draw[gpt * 4 + (i & 3)] : 0.f;
         }
         for (int i = tid; i < MT * DPE_LD; i += NTHREADS) dpe[i] = 0.f;
-        __syncthreads();
+        lds_barrier();
         auto maskw = [&](int ml, int rb, int cb) {
             return A.mask + mask_index(tile, N::n_mask_layers, ml, N::NRB, rb, CB, cb);
         };
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                                            A.plane_hv, HV, pt0 + cb * 32 + r, maskw(NL, rbv0 + i, cb));
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
         f32x16 acc[RB][CB];
         if (trunk_active) {
@@ -479,7 +503,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
             seg_gemm<NS, 1, CB, N::KKV>(ad, seg(N::bwd_VBT), 1, 0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
             dpe_add<CB>(dpe, ad, 0, PE_X, lane, false);
         }
-        __syncthreads();
+        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HV, A.dzv, A.plane_hv, HV, pt0, tid, NTHREADS);
+        lds_barrier();
         if (trunk_active) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                     store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane, A.dfeat,
                                            A.plane_h, HW, pt0 + cb * 32 + r, nullptr);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
         if (trunk_active) {
             acc_bias<RB, CB>(acc, nullptr, rb0, 0, h);
@@ -504,7 +529,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                     }
             }
         }
-        __syncthreads();
+        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dfeat, A.plane_h, HW, pt0, tid, NTHREADS);
+        lds_barrier();
         if (trunk_active) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                     store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
                                            A.dz[NL - 1], A.plane_h, HW, pt0 + cb * 32 + r, maskw(NL - 1, rb0 + i, cb));
         }
-        __syncthreads();
+        lds_barrier();
         // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
 #pragma unroll 1
         for (int l = NL - 1; l >= 1; --l) {
@@ -528,7 +554,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                 seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::bwd_LT(l, true)), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
-            __syncthreads();
+            copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz[l], A.plane_h, HW, pt0, tid, NTHREADS);
+            lds_barrier();
             if (trunk_active) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
@@ -537,7 +564,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                         store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
                                                A.dz[l - 1], A.plane_h, HW, pt0 + cb * 32 + r, maskw(l - 1, rb0 + i, cb));
             }
-            __syncthreads();
+            lds_barrier();
         }
         // ---- layer 0: d gamma(x) += W_0^T dZ_0 ----
         if (w < 2) {
@@ -546,7 +573,8 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
             seg_gemm<NS, 1, CB, N::KKH>(ap, seg(N::bwd_LT(0, false)), 2, w, dimg, ACT_PLANE, ACT_ROW, 0, lane);
             dpe_add<CB>(dpe, ap, w, 0, lane, N::SKIP >= 0);
         }
-        __syncthreads();
+        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz[0], A.plane_h, HW, pt0, tid, NTHREADS);
+        lds_barrier();
         // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos) ----
         {
             const int pt = tid % MT, part = tid / MT;
@@ -573,7 +601,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
             float* o = dxbuf + (part * MT + pt) * 6;
             o[0] = gx[0]; o[1] = gx[1]; o[2] = gx[2]; o[3] = gd[0]; o[4] = gd[1]; o[5] = gd[2];
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = tid; i < MT * 6; i += NTHREADS) {
             const int pt = i / 6, c = i % 6;
             float s = 0.f;
@@ -582,7 +610,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
             const long long gpt = pt0 + pt;
             if (gpt < A.P) A.dpts[gpt * 8 + (c < 3 ? c : c + 1)] = s;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -609,7 +637,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, in
 }
 
 template <int NS>
-__global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const DwArgs A) {
+__global__ __launch_bounds__(DW_THREADS) void dw_gemm_kernel(const DwArgs A) {
     __shared__ __attribute__((aligned(16))) char tiles[2 * NS * DW_KT * DW_ROW];   // Z planes then X planes
     char* zt = tiles;
     char* xt = tiles + NS * DW_KT * DW_ROW;
@@ -626,10 +654,19 @@ __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const DwArgs A) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    // bias gradient db[o] = sum_p dZ[p][o]: one extra MFMA per k-step against an all-ones B
+    // fragment, on the i-tile-0 workgroups only; wave (wo, wi) sums row-block t = wi.
+    const bool do_bias = A.db != nullptr && blockIdx.y == 0;
+    f32x16 accb;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accb[q] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const int zcols = A.n_out - o0, xcols = A.k_in - i0;   // valid columns in this tile (may exceed 128)
     for (long long p0 = p_begin; p0 < p_end; p0 += DW_KT) {
         // stage [32 points][128 cols] of every plane, 16 bytes per thread-load
-        for (int i = tid; i < NS * DW_KT * 16; i += NTHREADS) {
+        for (int i = tid; i < NS * DW_KT * 16; i += DW_THREADS) {
             const int c = i & 15, row = (i >> 4) % DW_KT, pl = i / (16 * DW_KT);
             uint4 vz = {0, 0, 0, 0}, vx = {0, 0, 0, 0};
             if (c * 8 < zcols)
@@ -654,8 +691,19 @@ __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const DwArgs A) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) acc[t][u] = mfma_planes<NS>(a[t], b[u], acc[t][u]);
+            if (do_bias) {
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) accb = mfma_bf16(wi ? a[1][pl] : a[0][pl], ones, accb);
+            }
         }
         __syncthreads();
+    }
+    if (do_bias && (lane & 31) == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int o = o0 + wo * 64 + wi * 32 + acc_row(q, lane >> 5);
+            if (o < A.n_out) atomicAdd(A.db + o, accb[q]);
+        }
     }
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -672,14 +720,14 @@ __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const DwArgs A) {
 
 // db[o] += sum_p sum_planes dZ[p][o]
 template <int NS>
-__global__ __launch_bounds__(NTHREADS) void colsum_kernel(const __bf16* __restrict__ Z, long long plane, int ld,
+__global__ __launch_bounds__(DW_THREADS) void colsum_kernel(const __bf16* __restrict__ Z, long long plane, int ld,
                                                           int n, long long Ppad, int pts_per_block,
                                                           float* __restrict__ out) {
     const long long p0 = (long long)blockIdx.x * pts_per_block;
     long long p1 = p0 + pts_per_block;
     if (p1 > Ppad) p1 = Ppad;
     const int nchunk = (n + 7) / 8;            // 16-byte chunks per row
-    const int rows_par = NTHREADS / nchunk;    // rows handled concurrently
+    const int rows_par = DW_THREADS / nchunk;    // rows handled concurrently
     const int c = threadIdx.x % nchunk, rr = threadIdx.x / nchunk;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (rr < rows_par) {
@@ -698,7 +746,7 @@ __global__ __launch_bounds__(NTHREADS) void colsum_kernel(const __bf16* __restri
 
 // Heads whose dZ is the fp32 d_raw: rgb_linear (X = hv) and alpha_linear (X = h_{NL-1}).
 template <int NS>
-__global__ __launch_bounds__(NTHREADS) void head_dw_kernel(const float* __restrict__ draw, long long P,
+__global__ __launch_bounds__(DW_THREADS) void head_dw_kernel(const float* __restrict__ draw, long long P,
                                                            const __bf16* __restrict__ hv, long long plane_hv, int HV,
                                                            const __bf16* __restrict__ hl, long long plane_h, int HW,
                                                            int pts_per_block, float* __restrict__ dw_rgb,
@@ -718,6 +766,7 @@ __global__ __launch_bounds__(NTHREADS) void head_dw_kernel(const float* __restri
         }
         __syncthreads();
         const int n = (int)((p1 - pc) < 64 ? (p1 - pc) : 64);
+#pragma unroll 8
         for (int t = 0; t < n; ++t) {
             const long long p = pc + t;
             if (j < HV) {
@@ -820,30 +869,22 @@ int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStre
 
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
     dim3 grid((a.n_out + DW_T - 1) / DW_T, (a.k_in + DW_T - 1) / DW_T, splits);
-    if (ns == 1) hipLaunchKernelGGL(dw_gemm_kernel<1>, grid, dim3(NTHREADS), 0, s, a);
-    else if (ns == 2) hipLaunchKernelGGL(dw_gemm_kernel<2>, grid, dim3(NTHREADS), 0, s, a);
-    else if (ns == 3) hipLaunchKernelGGL(dw_gemm_kernel<3>, grid, dim3(NTHREADS), 0, s, a);
+    if (ns == 1) hipLaunchKernelGGL(dw_gemm_kernel<1>, grid, dim3(DW_THREADS), 0, s, a);
+    else if (ns == 2) hipLaunchKernelGGL(dw_gemm_kernel<2>, grid, dim3(DW_THREADS), 0, s, a);
+    else if (ns == 3) hipLaunchKernelGGL(dw_gemm_kernel<3>, grid, dim3(DW_THREADS), 0, s, a);
     else return set_error("launch_dw: bad planes");
     LUSH_HIP(hipGetLastError());
-    if (a.db != nullptr) {
-        const int ppb = 4096;
-        const int blocks = (int)((a.Ppad + ppb - 1) / ppb);
-        if (ns == 1) hipLaunchKernelGGL(colsum_kernel<1>, dim3(blocks), dim3(NTHREADS), 0, s, a.Z, a.z_plane, a.ldz, a.n_out, (long long)a.Ppad, ppb, a.db);
-        else if (ns == 2) hipLaunchKernelGGL(colsum_kernel<2>, dim3(blocks), dim3(NTHREADS), 0, s, a.Z, a.z_plane, a.ldz, a.n_out, (long long)a.Ppad, ppb, a.db);
-        else hipLaunchKernelGGL(colsum_kernel<3>, dim3(blocks), dim3(NTHREADS), 0, s, a.Z, a.z_plane, a.ldz, a.n_out, (long long)a.Ppad, ppb, a.db);
-        LUSH_HIP(hipGetLastError());
-    }
     return 0;
 }
 
 int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
                    float* db_alpha, hipStream_t s) {
-    const int ppb = 2048;
+    const int ppb = 512;
     const int blocks = (int)((P + ppb - 1) / ppb);
-    if (ns == 1) hipLaunchKernelGGL(head_dw_kernel<1>, dim3(blocks), dim3(NTHREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else if (ns == 2) hipLaunchKernelGGL(head_dw_kernel<2>, dim3(blocks), dim3(NTHREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else hipLaunchKernelGGL(head_dw_kernel<3>, dim3(blocks), dim3(NTHREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    if (ns == 1) hipLaunchKernelGGL(head_dw_kernel<1>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else if (ns == 2) hipLaunchKernelGGL(head_dw_kernel<2>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else hipLaunchKernelGGL(head_dw_kernel<3>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
     LUSH_HIP(hipGetLastError());
     return 0;
 }

@@ -91,6 +91,8 @@ _SIGS = {
     "lush_mlp_fwd": ([_i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p], _i),
     "lush_mlp_bwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p,
                       C.POINTER(MlpParams), _p, _p], _i),
+    "lush_mlp_bwd_chain": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _p], _i),
+    "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, _p, _p, _p, C.POINTER(MlpParams), _p], _i),
     "lush_ray_grad_reduce": ([_p, _p, _i, _i, _p, _p], _i),
     "lush_adam": ([_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p], _i),
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
@@ -103,6 +105,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be in the process before our library is
+    # dlopen'ed, or the library binds a second HIP runtime that sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP extension is required; there is no fallback path)")

@@ -48,6 +48,30 @@ def mlp_pack(net: int, planes: int, tensors: Sequence[torch.Tensor]) -> torch.Te
     return out
 
 
+class KernelTimer:
+    """HIP-event timing of the three MLP kernel groups on the launch stream (bench.py)."""
+
+    def __init__(self):
+        self.spans = []      # (group, points, start_event, end_event)
+
+    def span(self, group, points):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.spans.append((group, points, a, b))
+        return a, b
+
+    def summary(self):
+        out = {}
+        for group, pts, a, b in self.spans:
+            d = out.setdefault(group, {"launches": 0, "ms": 0.0, "points": 0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["points"] += pts
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool):
     R, S = z.shape
     raw = torch.empty(R * S, 4, dtype=torch.float32, device=rays.device)
@@ -56,8 +80,13 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
         stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, R * S), dtype=torch.uint8,
                             device=rays.device)
     st = lib.mlp_struct(tensors, _NL[net])
+    ev = TIMER.span("mlp_fwd" if net == NET_NERF else "noise_fwd", R * S) if TIMER is not None else None
+    if ev:
+        ev[0].record()
     lib.call("lush_mlp_fwd", net, planes, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st),
              lib.ptr(raw), lib.ptr(stash), _stream())
+    if ev:
+        ev[1].record()
     return raw, stash
 
 
@@ -69,8 +98,21 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
     grads = [torch.zeros_like(t) for t in tensors]
     dpts = torch.empty(R * S, 8, dtype=torch.float32, device=dev)
     st, gs = lib.mlp_struct(tensors, _NL[net]), lib.mlp_struct(grads, _NL[net])
-    lib.call("lush_mlp_bwd", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b),
-             C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), lib.ptr(dpts), _stream())
+    timed = TIMER is not None and net == NET_NERF
+    ev = TIMER.span("mlp_bwd_chain", R * S) if timed else None
+    if ev:
+        ev[0].record()
+    lib.call("lush_mlp_bwd_chain", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b),
+             C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), _stream())
+    if ev:
+        ev[1].record()
+    ev = TIMER.span("mlp_bwd_weights", R * S) if timed else None
+    if ev:
+        ev[0].record()
+    lib.call("lush_mlp_bwd_weights", net, planes_f, planes_b, R, S, lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash),
+             C.byref(gs), _stream())
+    if ev:
+        ev[1].record()
     return grads, dpts
 
 
