@@ -99,8 +99,8 @@ void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
     add(p->w[0], 1, XV, XV, HW, 2, N::KKH, N::bwd_LT(0, false));
 }
 
-int dw_splits(long long Ppad, int tiles) {
-    int s = 1024 / tiles;
+int dw_splits(long long Ppad, int /*tiles*/) {
+    int s = 256;                                   // one 256x256-tile workgroup per CU
     const long long max_s = Ppad / 32;
     if (s > max_s) s = (int)max_s;
     return s < 1 ? 1 : s;

@@ -617,11 +617,17 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
 // ----------------------------------------------------------------------------
 // weight gradient: dW[o][i] += sum_p dZ[p][o] * X[p][i]
 // ----------------------------------------------------------------------------
-// Tile 128 (o) x 128 (i) per workgroup, 4 waves as 2x2, contraction over points in
-// steps of 32.  Both operands are [point][feature] row-major in HBM; the MFMA wants
-// 8 consecutive POINTS per lane, so fragments are read from the LDS tile with the
-// transposing ds_read_b64_tr_b16 (cdna_hip_programming.md T10).
-constexpr int DW_T = 128, DW_KT = 32, DW_ROW = DW_T * 2;   // LDS row = 256 B
+// One workgroup owns the FULL 256 x 256 output (so every stashed byte is read from HBM exactly
+// once per layer) for a slice of the points; 8 waves as 2 (o) x 4 (i), wave tile 128 x 64.
+// Both operands are [point][feature] row-major in HBM; the MFMA wants 8 consecutive POINTS per
+// lane, so fragments come out of the LDS tile through the transposing ds_read_b64_tr_b16
+// (cdna_hip_programming.md T10).  LDS rows are padded to 576 B: the 4 rows x 64 B that one
+// half-wave touches then fall on 64 distinct banks.  Tiles of 32 points are double buffered:
+// global -> registers for tile t+1 is issued before the MFMAs of tile t (T14), written to the
+// other buffer afterwards, one barrier per tile.
+constexpr int DW_T = 256, DW_ROW = DW_T * 2 + 64;
+template <int NS> struct DwKt { static constexpr int v = NS == 3 ? 16 : 32; };   // 3 planes: 16-point tiles fit 160 KB
+constexpr int DW_THREADS2 = 512;
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
     // lane supplies the address of row (k0 + 8*(G>>1) + 4t + q), columns col0 + 16*(G&1) + 4p .. +3
@@ -637,84 +643,121 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, in
 }
 
 template <int NS>
-__global__ __launch_bounds__(DW_THREADS) void dw_gemm_kernel(const DwArgs A) {
-    __shared__ __attribute__((aligned(16))) char tiles[2 * NS * DW_KT * DW_ROW];   // Z planes then X planes
-    char* zt = tiles;
-    char* xt = tiles + NS * DW_KT * DW_ROW;
+__global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
+    constexpr int DW_KT = DwKt<NS>::v;
+    extern __shared__ __attribute__((aligned(16))) char tiles[];   // [2 buffers][Z planes | X planes][KT][DW_ROW]
+    constexpr int PLANE = DW_KT * DW_ROW, OPER = NS * PLANE, BUF = 2 * OPER;
+    constexpr int LPT = NS * DW_KT * (DW_T / 8) / DW_THREADS2;     // 16-byte loads per thread and operand
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wo = w >> 1, wi = w & 1;             // wave position in the 2x2 grid
-    const int o0 = blockIdx.x * DW_T, i0 = blockIdx.y * DW_T;
-    const long long p_begin = (long long)blockIdx.z * A.pts_per_split;
+    const int wo = w >> 2, wi = w & 3;
+    const long long p_begin = (long long)blockIdx.x * A.pts_per_split;
     long long p_end = p_begin + A.pts_per_split;
     if (p_end > A.Ppad) p_end = A.Ppad;
-    f32x16 acc[2][2];
+    const int n_tiles = (int)((p_end - p_begin) / DW_KT);
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-    // bias gradient db[o] = sum_p dZ[p][o]: one extra MFMA per k-step against an all-ones B
-    // fragment, on the i-tile-0 workgroups only; wave (wo, wi) sums row-block t = wi.
-    const bool do_bias = A.db != nullptr && blockIdx.y == 0;
+    const bool do_bias = A.db != nullptr;
     f32x16 accb;
 #pragma unroll
     for (int q = 0; q < 16; ++q) accb[q] = 0.f;
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-    const int zcols = A.n_out - o0, xcols = A.k_in - i0;   // valid columns in this tile (may exceed 128)
-    for (long long p0 = p_begin; p0 < p_end; p0 += DW_KT) {
-        // stage [32 points][128 cols] of every plane, 16 bytes per thread-load
-        for (int i = tid; i < NS * DW_KT * 16; i += DW_THREADS) {
-            const int c = i & 15, row = (i >> 4) % DW_KT, pl = i / (16 * DW_KT);
-            uint4 vz = {0, 0, 0, 0}, vx = {0, 0, 0, 0};
-            if (c * 8 < zcols)
-                vz = *reinterpret_cast<const uint4*>(A.Z + pl * A.z_plane + (p0 + row) * A.ldz + o0 + c * 8);
-            if (c * 8 < xcols)
-                vx = *reinterpret_cast<const uint4*>(A.X + pl * A.x_plane + (p0 + row) * A.ldx + A.xcol0 + i0 + c * 8);
-            *reinterpret_cast<uint4*>(zt + (pl * DW_KT + row) * DW_ROW + c * 16) = vz;
-            *reinterpret_cast<uint4*>(xt + (pl * DW_KT + row) * DW_ROW + c * 16) = vx;
+    // waves whose whole column range is padding do no MFMA work
+    const bool wave_live = (wo * 128 < A.n_out) && (wi * 64 < A.k_in);
+    const bool bias_only = !wave_live && do_bias && (wo * 128 < A.n_out);
+    uint4 rz[LPT], rx[LPT];
+    auto gload = [&](long long p0) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int i = tid + j * DW_THREADS2;
+            const int c = i & 31, row = (i >> 5) % DW_KT, pl = i / (32 * DW_KT);
+            rz[j] = make_uint4(0, 0, 0, 0);
+            rx[j] = make_uint4(0, 0, 0, 0);
+            if (c * 8 < A.n_out)
+                rz[j] = *reinterpret_cast<const uint4*>(A.Z + pl * A.z_plane + (p0 + row) * A.ldz + c * 8);
+            if (c * 8 < A.k_in)
+                rx[j] = *reinterpret_cast<const uint4*>(A.X + pl * A.x_plane + (p0 + row) * A.ldx + A.xcol0 + c * 8);
         }
-        __syncthreads();
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < DW_KT / 16; ++ks) {
-            bf16x8 a[2][NS], b[2][NS];
+        for (int j = 0; j < LPT; ++j) {
+            const int i = tid + j * DW_THREADS2;
+            const int c = i & 31, row = (i >> 5) % DW_KT, pl = i / (32 * DW_KT);
+            char* base = tiles + buf * BUF + pl * PLANE + row * DW_ROW + c * 16;
+            *reinterpret_cast<uint4*>(base) = rz[j];
+            *reinterpret_cast<uint4*>(base + OPER) = rx[j];
+        }
+    };
+    if (n_tiles > 0) {
+        gload(p_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) gload(p_begin + (long long)(t + 1) * DW_KT);
+        if (wave_live) {
+            const char* zt = tiles + buf * BUF;
+            const char* xt = zt + OPER;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int ks = 0; ks < DW_KT / 16; ++ks) {
+                bf16x8 a[4][NS], b[2][NS];
 #pragma unroll
                 for (int pl = 0; pl < NS; ++pl) {
-                    a[t][pl] = tr_frag(zt + pl * DW_KT * DW_ROW, ks * 16, wo * 64 + t * 32, lane);
-                    b[t][pl] = tr_frag(xt + pl * DW_KT * DW_ROW, ks * 16, wi * 64 + t * 32, lane);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u][pl] = tr_frag(zt + pl * PLANE, ks * 16, wo * 128 + u * 32, lane);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) b[u][pl] = tr_frag(xt + pl * PLANE, ks * 16, wi * 64 + u * 32, lane);
                 }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[t][u] = mfma_planes<NS>(a[t], b[u], acc[t][u]);
-            if (do_bias) {
+                    for (int v = 0; v < 2; ++v) acc[u][v] = mfma_planes<NS>(a[u], b[v], acc[u][v]);
+                if (do_bias) {   // db[o] = sum_p dZ[p][o]: MFMA against an all-ones B; wave (wo, wi) sums block wi
 #pragma unroll
-                for (int pl = 0; pl < NS; ++pl) accb = mfma_bf16(wi ? a[1][pl] : a[0][pl], ones, accb);
+                    for (int pl = 0; pl < NS; ++pl) {
+                        const bf16x8 sel = wi == 0 ? a[0][pl] : (wi == 1 ? a[1][pl] : (wi == 2 ? a[2][pl] : a[3][pl]));
+                        accb = mfma_bf16(sel, ones, accb);
+                    }
+                }
             }
         }
+        else if (bias_only) {   // column range is padding: this wave still owns bias block wi
+            const char* zt = tiles + buf * BUF;
+#pragma unroll
+            for (int ks = 0; ks < DW_KT / 16; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    accb = mfma_bf16(tr_frag(zt + pl * PLANE, ks * 16, wo * 128 + wi * 32, lane), ones, accb);
+        }
+        if (t + 1 < n_tiles) lstore(buf ^ 1);
         __syncthreads();
     }
-    if (do_bias && (lane & 31) == 0) {
+    const int r = lane & 31, h = lane >> 5;
+    if (do_bias && r == 0 && (wave_live || bias_only)) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int o = o0 + wo * 64 + wi * 32 + acc_row(q, lane >> 5);
+            const int o = wo * 128 + wi * 32 + acc_row(q, h);
             if (o < A.n_out) atomicAdd(A.db + o, accb[q]);
         }
     }
-    const int r = lane & 31, h = lane >> 5;
+    if (!wave_live) return;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int o = o0 + wo * 64 + t * 32 + acc_row(q, h);
-                const int i = i0 + wi * 64 + u * 32 + r;
-                if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[t][u][q]);
+                const int o = wo * 128 + u * 32 + acc_row(q, h);
+                const int i = wi * 64 + v * 32 + r;
+                if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[u][v][q]);
             }
 }
 
@@ -867,14 +910,21 @@ int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStre
     return 0;
 }
 
-int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
-    dim3 grid((a.n_out + DW_T - 1) / DW_T, (a.k_in + DW_T - 1) / DW_T, splits);
-    if (ns == 1) hipLaunchKernelGGL(dw_gemm_kernel<1>, grid, dim3(DW_THREADS), 0, s, a);
-    else if (ns == 2) hipLaunchKernelGGL(dw_gemm_kernel<2>, grid, dim3(DW_THREADS), 0, s, a);
-    else if (ns == 3) hipLaunchKernelGGL(dw_gemm_kernel<3>, grid, dim3(DW_THREADS), 0, s, a);
-    else return set_error("launch_dw: bad planes");
+template <int NS>
+static int launch_dw_t(const DwArgs& a, int splits, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * NS * DwKt<NS>::v * DW_ROW;
+    auto k = dw_gemm_kernel<NS>;
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, a);
     LUSH_HIP(hipGetLastError());
     return 0;
+}
+int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
+    if (a.n_out > DW_T || a.k_in > DW_T) return set_error("launch_dw: layer wider than 256");
+    if (ns == 1) return launch_dw_t<1>(a, splits, s);
+    if (ns == 2) return launch_dw_t<2>(a, splits, s);
+    if (ns == 3) return launch_dw_t<3>(a, splits, s);
+    return set_error("launch_dw: bad planes");
 }
 
 int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
