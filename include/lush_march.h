@@ -163,13 +163,17 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
 size_t lush_mlp_stash_bytes(int net, int planes, long long P);
 size_t lush_mlp_dstash_bytes(int net, int planes, long long P);
 /* rays [R][11], z [R][S] -> raw [R*S][4] (rgb raw x3, sigma raw; sigma = 0 for
- * net 1).  stash may be NULL (inference: nothing saved). */
-int lush_mlp_fwd(int net, int planes, const float* rays, const float* z, int R, int S,
+ * net 1).  stash may be NULL (inference: nothing saved); otherwise it has
+ * lush_mlp_stash_bytes(net, stash_planes, R*S) bytes and receives the first
+ * stash_planes (<= planes) bf16 planes of every activation: the backward only needs
+ * as many planes as it computes with. */
+int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
                  const void* packed, const lush_mlp_params* prm, float* raw, void* stash,
                  lush_stream_t stream);
 /* Backward: draw [R*S][4] -> parameter gradients (accumulate, fp32 atomics) and
  * dpts [R*S][8] = d/dpoint (3), 0, d/dviewdir (3), 0 (overwritten).
- * planes_b <= planes_f; packed_b holds planes_b planes. */
+ * planes_f = the stash_planes the forward was called with; planes_b <= planes_f is the
+ * plane count of the backward arithmetic; packed_b holds planes_b planes. */
 int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                  const void* packed_b, const lush_mlp_params* prm, const float* draw,
                  const void* stash, void* dstash, const lush_mlp_grads* grads, float* dpts,

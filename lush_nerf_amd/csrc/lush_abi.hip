@@ -147,15 +147,17 @@ int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
     return 0;
 }
 
-int lush_mlp_fwd(int net, int planes, const float* rays, const float* z, int R, int S, const void* packed,
-                 const lush_mlp_params* prm, float* raw, void* stash, lush_stream_t stream) {
+int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
+                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash, lush_stream_t stream) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_fwd: bad net");
     if (planes < 1 || planes > 3) return set_error("lush_mlp_fwd: planes must be 1..3");
     if (R <= 0 || S <= 0) return set_error("lush_mlp_fwd: empty batch");
+    if (stash && (stash_planes < 1 || stash_planes > planes)) return set_error("lush_mlp_fwd: need 1 <= stash_planes <= planes");
     const long long P = (long long)R * S;
-    const StashLayout L = stash_layout(n, planes, P);
+    const StashLayout L = stash_layout(n, stash ? stash_planes : planes, P);
     MlpFwdArgs a{};
+    a.stash_planes = stash_planes;
     a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)L.n_tiles;
     if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
     a.wpk = (const uint4*)packed;

@@ -110,6 +110,7 @@ struct MlpFwdArgs {
     float* raw;                    // [P][4]
     MlpStash st;
     int write_stash;
+    int stash_planes;              // planes copied to the stash (<= NS): what the backward will use
 };
 
 struct MlpBwdArgs {

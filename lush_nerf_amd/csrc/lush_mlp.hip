@@ -183,9 +183,10 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
 // as full 128-byte lines (the image is de-swizzled on the way out).
 template <int NS, int MT>
 __device__ __forceinline__ void copy_out(const char* img, int plane_bytes, int row_bytes, int ncols, __bf16* stash,
-                                         long long stash_plane, int stash_ld, long long pt0, int tid, int nthreads) {
+                                         long long stash_plane, int stash_ld, long long pt0, int tid, int nthreads,
+                                         int planes = NS) {
     const int cpr = ncols >> 3;                    // 16-byte chunks per row
-    for (int i = tid; i < NS * MT * cpr; i += nthreads) {
+    for (int i = tid; i < planes * MT * cpr; i += nthreads) {
         const int c = i % cpr, pt = (i / cpr) % MT, p = i / (cpr * MT);
         const uint4 v = *reinterpret_cast<const uint4*>(img + p * plane_bytes + swz(pt, c, row_bytes));
         *reinterpret_cast<uint4*>(stash + p * stash_plane + (pt0 + pt) * stash_ld + c * 8) = v;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
         pe_tile<NS, MT>(peimg, PE_PLANE, A.rays, A.z, A.S, A.P, pt0, tid);
         lds_barrier();
         if (stash_on) {   // de-swizzled 16-byte copies of the 96 live PE columns
-            for (int i = tid; i < NS * MT * 12; i += NTHREADS) {
+            for (int i = tid; i < A.stash_planes * MT * 12; i += NTHREADS) {
                 const int c = i % 12, pt = (i / 12) % MT, p = i / (12 * MT);
                 const uint4 v = *reinterpret_cast<const uint4*>(peimg + p * PE_PLANE + swz(pt, c, PE_ROW * 2));
                 *reinterpret_cast<uint4*>(A.st.pe + p * A.st.plane_pe + (pt0 + pt) * PE_ROW + c * 8) = v;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
-            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[l - 1], A.st.plane_h, HW, pt0, tid, NTHREADS);
+            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[l - 1], A.st.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
             lds_barrier();
             if (trunk_active) {
 #pragma unroll
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 for (int cb = 0; cb < CB; ++cb) alphabuf[cb * 32 + r] = aa[0][cb][0];
             }
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[NL - 1], A.st.plane_h, HW, pt0, tid, NTHREADS);
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[NL - 1], A.st.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
         lds_barrier();
         if (trunk_active) {
 #pragma unroll
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
             seg_gemm<NS, RBV, CB, N::KKD>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.feat, A.st.plane_h, HW, pt0, tid, NTHREADS);
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.feat, A.st.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
         lds_barrier();
         if (views_active) {
 #pragma unroll
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 }
             }
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HV, A.st.hv, A.st.plane_hv, HV, pt0, tid, NTHREADS);
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HV, A.st.hv, A.st.plane_hv, HV, pt0, tid, NTHREADS, A.stash_planes);
         lds_barrier();
     }
 }

@@ -72,18 +72,20 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool):
+def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0):
+    """stash_planes: planes kept for the backward (default: all `planes`)."""
     R, S = z.shape
+    sp = stash_planes or planes
     raw = torch.empty(R * S, 4, dtype=torch.float32, device=rays.device)
     stash = None
     if want_stash:
-        stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, R * S), dtype=torch.uint8,
+        stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, sp, R * S), dtype=torch.uint8,
                             device=rays.device)
     st = lib.mlp_struct(tensors, _NL[net])
     ev = TIMER.span("mlp_fwd" if net == NET_NERF else "noise_fwd", R * S) if TIMER is not None else None
     if ev:
         ev[0].record()
-    lib.call("lush_mlp_fwd", net, planes, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st),
+    lib.call("lush_mlp_fwd", net, planes, sp, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st),
              lib.ptr(raw), lib.ptr(stash), _stream())
     if ev:
         ev[1].record()
@@ -232,7 +234,7 @@ class March(torch.autograd.Function):
         noise_c = _opt(draws.get("noise_c")) if cfg.raw_noise_std > 0 else None
         zc = zgrid(batch, cfg.N_samples, cfg.lindisp, t_rand)
         pk_c = mlp_pack(NET_NERF, pf, coarse)
-        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad)
+        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, min(pf, pb))
         rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, noise_c, cfg)
         outs = [rgb, depth, acc, density]
         saved = dict(zc=zc, raw_c=raw_c, noise_c=noise_c, stash_c=stash_c)
@@ -243,7 +245,7 @@ class March(torch.autograd.Function):
             zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, u)
             same = fine is coarse
             pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
-            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad)
+            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, min(pf, pb))
             rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, noise_f, cfg)
             outs = [rgb1, depth1, acc1, density1]
             saved.update(zf=zf, raw_f=raw_f, noise_f=noise_f, stash_f=stash_f)
@@ -274,7 +276,7 @@ class March(torch.autograd.Function):
         def run(tensors, z, raw, noise, stash, gg):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
             pk = mlp_pack(NET_NERF, pb, tensors)
-            gr, dpts = mlp_backward(NET_NERF, pf, pb, tensors, pk, batch, z, draw, stash)
+            gr, dpts = mlp_backward(NET_NERF, min(pf, pb), pb, tensors, pk, batch, z, draw, stash)
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays),
                      _stream())
             return gr
@@ -306,7 +308,7 @@ class NoiseMlp(torch.autograd.Function):
         lib.call("lush_zfixed", lib.ptr(batch), R, int(N_samples), int(index), int(lindisp), lib.ptr(z), _stream())
         pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
         need = bool(want_grad) and any(ctx.needs_input_grad)
-        raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need)
+        raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, min(precision.fwd, precision.bwd))
         ctx.batch, ctx.z, ctx.tensors, ctx.stash, ctx.precision = batch, z, tensors, stash, precision
         return raw[:, :3].contiguous()
 
@@ -316,7 +318,7 @@ class NoiseMlp(torch.autograd.Function):
         draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
         draw[:, :3] = g
         pk = mlp_pack(NET_NOISE, pr.bwd, ctx.tensors)
-        grads, _ = mlp_backward(NET_NOISE, pr.fwd, pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash)
+        grads, _ = mlp_backward(NET_NOISE, min(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash)
         ctx.stash = None
         o = 2 * _NL[NET_NOISE] + 4   # alpha_linear is dead in NeRF_Noise (helpers:496,505,512): grad None
         grads[o] = None

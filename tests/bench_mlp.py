@@ -35,20 +35,21 @@ for nf, nb in modes:
     pkb = pk if nb == nf else ops.mlp_pack(0, nb, tens)
     res = {}
     if "fwd" in what:
-        res["fwd"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, True))
+        res["fwd"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, True, min(nf, nb)))
     if "fwd_nostash" in what:
         res["fwd_nostash"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, False))
-    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True)
+    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True, min(nf, nb))
+    nf_s = min(nf, nb)
     import ctypes as C
     dstash = torch.empty(lib.load().lush_mlp_dstash_bytes(0, nb, R * S), dtype=torch.uint8, device=dev)
     grads = [torch.zeros_like(t) for t in tens]
     dpts = torch.empty(R * S, 8, device=dev)
     st, gs = lib.mlp_struct(tens, 8), lib.mlp_struct(grads, 8)
     def chain():
-        lib.call("lush_mlp_bwd_chain", 0, nf, nb, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pkb), C.byref(st),
+        lib.call("lush_mlp_bwd_chain", 0, nf_s, nb, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pkb), C.byref(st),
                  lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), ops._stream())
     def weights():
-        lib.call("lush_mlp_bwd_weights", 0, nf, nb, R, S, lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), ops._stream())
+        lib.call("lush_mlp_bwd_weights", 0, nf_s, nb, R, S, lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), ops._stream())
     if "chain" in what:
         res["chain"] = timeit(chain)
     else:

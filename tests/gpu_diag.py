@@ -206,15 +206,15 @@ def t_mlp_bwd():
         tens = [gpu(t.detach()) for t in nerf_tensors(p, prefix, D)]
         for nf, nb, tol in ((3, 3, 2e-5), (2, 2, 2e-4), (2, 1, 3e-2)):
             pk = ops.mlp_pack(net, nf, tens)
-            raw, stash = ops.mlp_forward(net, nf, tens, pk, gpu(batch), gpu(z), True)
+            raw, stash = ops.mlp_forward(net, nf, tens, pk, gpu(batch), gpu(z), True, min(nf, nb))
             # reference gradients with the GPU's own ReLU decisions (isolates arithmetic from kink flips)
-            masks = util.stash_masks(net, nf, R * S, stash)
+            masks = util.stash_masks(net, min(nf, nb), R * S, stash)
             for v in list(p.values()) + [br]:
                 v.grad = None
             out = util.nerf_mlp_masked(p, prefix, x, D, masks)
             (out * draw).sum().backward(retain_graph=True)
             pkb = pk if nb == nf else ops.mlp_pack(net, nb, tens)
-            grads, dpts = ops.mlp_backward(net, nf, nb, tens, pkb, gpu(batch), gpu(z), gpu(draw), stash)
+            grads, dpts = ops.mlp_backward(net, min(nf, nb), nb, tens, pkb, gpu(batch), gpu(z), gpu(draw), stash)
             worst, wname = 0.0, ""
             for n, g in zip(names, grads):
                 ref = p[f"{prefix}.{n}"].grad
