@@ -26,6 +26,9 @@ import torch.distributed as dist
 MACS_PER_EVAL = 593_408            # NeRF D=8 W=256 MLP, verified layer shapes
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# stash bytes per MLP evaluation and bf16 plane ([point][feature] rows)
+BYTES_X_STASH = 2 * (128 + 8 * 256 + 256 + 128)    # gamma row, h_0..h_7, feature, views hidden
+BYTES_DZ_STASH = 2 * (8 * 256 + 256 + 128)         # dZ_0..dZ_7, d feature, dZ views
 
 
 def make_model(args_ns, device, precision, seed=0, num_img=30):
@@ -82,7 +85,8 @@ def main():
     ap.add_argument("--n-rand", type=int, default=4096)
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--n-importance", type=int, default=64)
-    ap.add_argument("--planes", type=str, default="2,2", help="bf16 planes per MFMA operand: fwd,bwd")
+    ap.add_argument("--planes", type=str, default="2,1", help="bf16 planes per MFMA operand: fwd,bwd")
+    ap.add_argument("--also", type=str, default="2,2", help="second mode timed after the headline (rank 0 reports it under modes); empty to skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n-rand", type=int, default=64)
     a = ap.parse_args()
@@ -103,10 +107,6 @@ def main():
     from lush_nerf_amd import lib, ops, synth
     from lush_nerf_amd.trainer import Trainer
     lib.load()
-    pf, pb = (int(x) for x in a.planes.split(","))
-    net = make_model(model_args(a.n_importance), dev, ops.Precision(pf, pb))
-    tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, a.n_samples, a.n_importance, kernel_start_iter=0,
-                 allkernel_start_iter=1 << 30, distributed=world > 1)
 
     n_batches = 4
     batches = []
@@ -120,54 +120,86 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        tr.step(batches[i % n_batches], i)
-    ops.TIMER = ops.KernelTimer()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        tr.step(batches[(a.warmup + i) % n_batches], a.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    timer, ops.TIMER = ops.TIMER, None
-    if world > 1:
-        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
+    M = 5
+    evals_step = a.n_rand * M * (a.n_samples + (a.n_samples + a.n_importance if a.n_importance else 0))
+
+    def run_mode(pf, pb, steps, warmup):
+        net = make_model(model_args(a.n_importance), dev, ops.Precision(pf, pb))
+        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, a.n_samples, a.n_importance, kernel_start_iter=0,
+                     allkernel_start_iter=1 << 30, distributed=world > 1)
+        for i in range(warmup):
+            tr.step(batches[i % n_batches], i)
+        ops.TIMER = ops.KernelTimer()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(batches[(warmup + i) % n_batches], warmup + i)
+        sync()
+        dt = time.perf_counter() - t0
+        timer, ops.TIMER = ops.TIMER, None
+        if world > 1:
+            tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            dt = float(tdt.item())
+        del tr, net
+        torch.cuda.empty_cache()
+        return dt, timer.summary()
+
+    def kernel_table(groups, pf, pb, steps):
+        """Per kernel group: average launch time (HIP events on the launch stream), algorithmic
+        FLOP/s and algorithmic HBM bytes/s per launch (DESIGN.md section 5 gives the per-evaluation figures)."""
+        sp = min(pf, pb)
+        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH + 16 + 44 / 64, "mlp_bwd_chain": pb * BYTES_DZ_STASH + 288 + 16 + 32,
+                      "mlp_bwd_weights": pb * (BYTES_X_STASH + BYTES_DZ_STASH)}
+        kern = {}
+        for g, d in groups.items():
+            if g not in bytes_eval:
+                continue
+            avg_ms = d["ms"] / d["launches"]
+            pts = d["points"] / d["launches"]
+            tf = 2 * MACS_PER_EVAL * pts / (avg_ms * 1e-3) / 1e12
+            gbs = bytes_eval[g] * pts / (avg_ms * 1e-3) / 1e9
+            kern[g] = {"launches_per_step": d["launches"] / steps, "avg_ms": round(avg_ms, 4),
+                       "ms_per_step": round(d["ms"] / steps, 3), "tflops_algorithmic": round(tf, 1),
+                       "hbm_gbs_algorithmic": round(gbs, 1), "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 4),
+                       "frac_hbm": round(gbs / PEAK_HBM_GBS, 4)}
+        return kern
+
+    pf, pb = (int(x) for x in a.planes.split(","))
+    dt, groups = run_mode(pf, pb, a.steps, a.warmup)
+    other = None
+    if a.also and a.also != a.planes:
+        qf, qb = (int(x) for x in a.also.split(","))
+        odt, ogroups = run_mode(qf, qb, max(2, a.steps // 2), 1)
+        other = (qf, qb, odt, ogroups, max(2, a.steps // 2))
 
     if rank == 0:
         rays_per_s = a.n_rand * world * a.steps / dt
-        M = 5
-        evals_step = a.n_rand * M * (a.n_samples + (a.n_samples + a.n_importance if a.n_importance else 0))
         flop_step = 3 * 2 * MACS_PER_EVAL * evals_step          # fwd + dX + dW, algorithmic (counted once)
-        groups = timer.summary()
-        kern = {}
-        for g, d in groups.items():
-            if g == "noise_fwd":
-                continue
-            avg_ms = d["ms"] / d["launches"]
-            flop_launch = 2 * MACS_PER_EVAL * d["points"] / d["launches"]
-            kern[g] = {"launches_per_step": d["launches"] / a.steps, "avg_ms": round(avg_ms, 4),
-                       "tflops_algorithmic": round(flop_launch / (avg_ms * 1e-3) / 1e12, 2),
-                       "ms_per_step": round(d["ms"] / a.steps, 3)}
+        kern = kernel_table(groups, pf, pb, a.steps)
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
-        nmul = {1: 1, 2: 3, 3: 6}
         roof = None
         if dom:
-            planes_dom = pf if dom == "mlp_fwd" else pb
-            roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops_algorithmic"],
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(kern[dom]["tflops_algorithmic"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "mfma_executed_tflops": round(kern[dom]["tflops_algorithmic"] * nmul[planes_dom], 2),
-                    "note": "achieved = algorithmic 2*593408 FLOP per MLP evaluation per launch / HIP-event "
-                            "launch time; the parity mode executes 3 bf16 MFMAs per algorithmic product"}
+            k = kern[dom]
+            hbm_bound = k["frac_hbm"] >= k["frac_mfma"]      # the roof this kernel would hit first
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(f"{dom}:{pf},{pb}")
+            roof = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
+                    "achieved": k["hbm_gbs_algorithmic"] if hbm_bound else k["tflops_algorithmic"],
+                    "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": k["frac_hbm"] if hbm_bound else k["frac_mfma"], "traffic": traffic,
+                    "note": "dominant kernel group by time; achieved = algorithmic bytes (or 2*593408 FLOP) per MLP "
+                            "evaluation x evaluations per launch / average launch time from HIP events on the launch stream"}
+        dtype = {1: "bf16", 2: "bf16 MFMA, operands split in 2 bf16 planes (~2^-17, fp32-equivalent outputs), fp32 accumulate",
+                 3: "bf16 MFMA, 3 planes (~fp32), fp32 accumulate"}[pf]
+        if pb != pf:
+            dtype += f"; backward {pb}-plane bf16"
         out = {
             "metric": "training rays/sec (fwd+bwd), N_samples=64+64", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {1: "bf16", 2: "bf16x2-split (fp32-equivalent to ~2^-17), fp32 accumulate",
-                      3: "bf16x3-split (~fp32), fp32 accumulate"}[pf] + (f" fwd / {pb} plane(s) bwd" if pb != pf else ""),
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"poster_lushnerf 1xMI355X N_rand={a.n_rand} N_samples={a.n_samples} "
                                    f"N_importance={a.n_importance} blur kernel (DSK/RBK) on, fwd+bwd+Adam",
                        "rays_per_gpu": a.n_rand, "marched_rays_per_gpu": a.n_rand * M, "mlp_evals_per_step": evals_step,
@@ -175,6 +207,13 @@ def main():
             "step_tflops_algorithmic": round(flop_step * world * a.steps / dt / 1e12, 2),
             "kernels": kern, "roofline": roof,
         }
+        if other:
+            qf, qb, odt, ogroups, osteps = other
+            out["modes"] = {f"{qf},{qb}": {"value": round(a.n_rand * world * osteps / odt, 1),
+                                           "ms_per_step": round(odt / osteps * 1e3, 3),
+                                           "kernels": kernel_table(ogroups, qf, qb, osteps),
+                                           "note": "every MFMA operand in 2 bf16 planes, forward AND backward "
+                                                   "(fp32-equivalent gradients)"}}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, a.n_samples, a.n_importance)
             out["gpu_over_cpu"] = round(rays_per_s / out["cpu_baseline"]["value"], 1)

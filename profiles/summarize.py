@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into profiles/<tag>_*.{csv,md} and pmc_traffic.json.
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced stream
+(MI355X_MICROARCH.md, HBM section), so fetch bytes are doubled."""
+import csv, glob, json, os, sys, collections
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+bench = {}
+try:
+    bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+except Exception as e:
+    print("no bench json", e)
+planes = f'{bench.get("config", {}).get("planes_fwd", "?")},{bench.get("config", {}).get("planes_bwd", "?")}'
+steps = bench.get("steps", 4) + bench.get("warmup", 2)
+
+GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
+         "dw_gemm_kernel": "mlp_bwd_weights", "head_dw_kernel": "mlp_bwd_weights"}
+
+
+def group_of(name):
+    for k, g in GROUP.items():
+        if k in name:
+            return g
+    return None
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+lines = []
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    out = os.path.join(root, "profiles", f"{tag}_bench_kernel_stats.csv")
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], f'{float(r["TotalDurationNs"]) / 1e6:.3f}',
+                        f'{float(r["AverageNs"]) / 1e6:.4f}', r["Percentage"]])
+    lines.append(f"## rocprofv3 --kernel-trace --stats of `bench.py` (planes {planes}, {steps} steps incl. warm-up)\n")
+    lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
+    for r in rows[:10]:
+        lines.append(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e6:.3f} | '
+                     f'{float(r["TotalDurationNs"]) / 1e6:.1f} | {r["Percentage"]} |')
+    if bench.get("kernels"):
+        lines.append("\nHIP-event timing inside the same run (bench.py `kernels`): " +
+                     ", ".join(f'{k}: {v["avg_ms"]} ms/launch-group' for k, v in bench["kernels"].items()))
+
+traffic = {}
+per = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(src, f"pmc_{c}", "*", "*_counter_collection.csv"))
+    if not f:
+        continue
+    agg = collections.defaultdict(float)
+    for r in csv.DictReader(open(f[0])):
+        g = group_of(r["Kernel_Name"])
+        if g:
+            agg[g] += float(r["Counter_Value"]) * 1024.0 * (2.0 if c == "FETCH_SIZE" else 1.0)
+    per[c] = agg
+if per:
+    lines.append(f"\n## HBM traffic from PMC counters (separate passes; FETCH_SIZE x2 gfx950 correction)\n")
+    lines.append("| kernel group | fetch GB/step | write GB/step | total GB/step | algorithmic GB/step |\n|---|---|---|---|---|")
+    evals = bench.get("config", {}).get("mlp_evals_per_step", 3932160)
+    pf, pb = (int(x) for x in planes.split(",")) if "?" not in planes else (2, 1)
+    alg = {"mlp_fwd": evals * (min(pf, pb) * 5120 + 16), "mlp_bwd_chain": evals * (pb * 4864 + 336),
+           "mlp_bwd_weights": evals * pb * 9984}
+    lps = {k: v["launches_per_step"] for k, v in bench.get("kernels", {}).items()}
+    for g in ("mlp_fwd", "mlp_bwd_chain", "mlp_bwd_weights"):
+        fe, wr = per.get("FETCH_SIZE", {}).get(g, 0.0) / steps, per.get("WRITE_SIZE", {}).get(g, 0.0) / steps
+        lines.append(f"| {g} | {fe / 1e9:.2f} | {wr / 1e9:.2f} | {(fe + wr) / 1e9:.2f} | {alg[g] / 1e9:.2f} |")
+        traffic[f"{g}:{planes}"] = {"hbm_bytes_per_launch_group": round((fe + wr) / max(lps.get(g, 2.0), 1e-9)),
+                                    "hbm_bytes_per_step": round(fe + wr), "algorithmic_bytes_per_step": alg[g],
+                                    "source": f"profiles/{tag}_summary.md"}
+    json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+open(os.path.join(root, "profiles", f"{tag}_summary.md"), "w").write("# Profile summary " + tag + "\n\n" + "\n".join(lines) + "\n")
+print("\n".join(lines))

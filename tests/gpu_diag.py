@@ -20,6 +20,7 @@ from oracle import lush_oracle as O
 from tests import util
 
 dev = torch.device("cuda:0")
+E2E_PLANES = tuple(int(c) for c in os.environ.get("LUSH_PLANES", "2,2").split(","))
 H, W, F = util.H, util.W, util.FOCAL
 RESULTS = []
 
@@ -298,7 +299,7 @@ def t_march_e2e():
                                   rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
                                   render_rmnearplane=80)
         rbk = M.RBK(util.NUM_IMG, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4)
-        net = M.NeRFAll(args, rbk, precision=ops.Precision(2, 2))
+        net = M.NeRFAll(args, rbk, precision=ops.Precision(*E2E_PLANES))
         w = synth.all_weights(util.NUM_IMG, seed, sharp=bool(sharp))
         if Ni == 0:
             w = {k: v for k, v in w.items() if not k.startswith("mlp_fine.")}
@@ -332,7 +333,7 @@ def t_train_e2e():
                                   rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
                                   render_rmnearplane=80)
         rbk = M.RBK(util.NUM_IMG, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4)
-        net = M.NeRFAll(args, rbk, precision=ops.Precision(2, 2))
+        net = M.NeRFAll(args, rbk, precision=ops.Precision(*E2E_PLANES))
         M.load_reference_weights(net, synth.all_weights(util.NUM_IMG, seed, sharp=bool(sharp),
                                                         rbk_scale=1.0 if naive else 2.0e4))
         net = net.to(dev).train()

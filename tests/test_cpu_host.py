@@ -1,0 +1,139 @@
+"""CPU-side tests: C-ABI exports, host logic, deterministic generator, 2-rank gloo data-parallel plumbing.
+No compute call into the HIP library is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lush_nerf_amd import lib, synth
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    lib.build()
+    so = ctypes.CDLL(lib.SO_PATH)
+    header = open(os.path.join(ROOT, "include", "lush_march.h")).read()
+    declared = set(re.findall(r"\b(lush_[a-z0-9_]+)\s*\(", header))
+    declared -= {"lush_stream_t"}
+    assert len(declared) >= 30
+    missing = [n for n in sorted(declared) if not hasattr(so, n)]
+    assert not missing, missing
+    assert set(lib.EXPORTS) <= declared | {"lush_last_error"}
+    l = lib.load()
+    assert l.lush_abi_version() == 1
+    # pure host queries (no device work)
+    assert l.lush_mlp_packed_bytes(0, 1) > 2 * 593408 * 2 and l.lush_mlp_packed_bytes(0, 3) == 3 * l.lush_mlp_packed_bytes(0, 1)
+    assert l.lush_mlp_packed_bytes(7, 1) == 0
+    assert l.lush_mlp_stash_bytes(0, 2, 64) > 0 and l.lush_mlp_stash_bytes(0, 2, 65) == l.lush_mlp_stash_bytes(0, 2, 128)
+
+
+def test_product_refuses_cpu_tensors():
+    from lush_nerf_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.PackRays.apply(torch.zeros(4, 3, 2), 8, 8, 10.0, True, 0., 1.)
+
+
+def test_product_does_not_import_the_oracle():
+    for dp, dn, fn in os.walk(os.path.join(ROOT, "lush_nerf_amd")):
+        for f in fn:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|import_module\(.oracle|__import__\(.oracle", src, re.M), f
+
+
+def test_generator_is_deterministic_and_reference_shaped():
+    a, b = synth.all_weights(30, 5), synth.all_weights(30, 5)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert sum(v.size for v in a.values()) == 1301993          # flat gradient size
+    assert a["mlp_coarse.pts_linears.5.weight"].shape == (256, 319)
+    assert a["mlp_coarse.views_linears.0.weight"].shape == (128, 283)
+    assert a["mlp_noise_coarse.pts_linears.0.weight"].shape == (128, 63)
+    assert float(np.abs(a["mlp_rbk.r_linear.weight"]).max()) < 1.5e-6
+    r1, r2 = synth.ray_batch(64, 1, step=0), synth.ray_batch(64, 1, step=1)
+    assert not np.array_equal(r1["rays"], r2["rays"]) and r1["rays"].shape == (64, 3, 2)
+    u = synth.uniform01(1000, 3)
+    assert 0 <= u.min() and u.max() < 1
+
+
+def test_model_mirror_has_reference_state_dict_keys():
+    import argparse
+    from lush_nerf_amd import model as M
+    args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+                              N_importance=64, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                              rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
+                              render_rmnearplane=80)
+    net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4))
+    sd = net.state_dict()
+    assert len(sd) == 108 and sum(p.numel() for p in net.parameters()) == 1301993
+    for k in ("mlp_coarse.pts_linears.0.weight", "mlp_fine.rgb_linear.bias", "mlp_noise_coarse.alpha_linear.weight",
+              "blur_kernel_net.RBK.r_linear.weight", "dbk_view_embedding.view_embed_layer.weight",
+              "mlp_rbk.view_embed_linears.3.bias", "blur_kernel_net.view_embed_layer.view_embed_layer.weight"):
+        assert k in sd, k
+    M.load_reference_weights(net, synth.all_weights(30, 2))
+    assert np.array_equal(net.mlp_fine.pts_linears[5].weight.detach().numpy(),
+                          synth.all_weights(30, 2)["mlp_fine.pts_linears.5.weight"])
+    with pytest.raises(NotImplementedError):
+        args2 = argparse.Namespace(**{**vars(args), "multires": 6})
+        M.NeRFAll(args2, None)
+
+
+def test_flat_params_views():
+    from lush_nerf_amd.trainer import FlatParams
+    lin1, lin2 = torch.nn.Linear(3, 4), torch.nn.Linear(4, 2)
+    w0 = lin1.weight.detach().clone()
+    fp = FlatParams([list(lin1.parameters()), list(lin2.parameters()) + [lin1.weight]])   # alias is de-duplicated
+    assert fp.numel == 3 * 4 + 4 + 4 * 2 + 2 and fp.segments == [(0, 16), (16, 26)]
+    assert torch.equal(lin1.weight.detach(), w0)
+    fp.param[:12] += 1.0
+    assert torch.equal(lin1.weight.detach(), w0 + 1.0)
+    (lin2(lin1(torch.ones(5, 3))).sum()).backward()
+    assert float(fp.grad.abs().sum()) > 0 and lin1.weight.grad.data_ptr() == fp.grad.data_ptr()
+
+
+_DIST_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from lush_nerf_amd.trainer import FlatParams
+from lush_nerf_amd import synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+fp = FlatParams([list(net.parameters())])
+# every rank draws its own rays (disjoint seeds), SURVEY 8e
+b = synth.ray_batch(32, seed=1000 + rank)
+x = torch.from_numpy(b["rays"]).reshape(32, 6)
+loss = ((net(x) - torch.from_numpy(b["target"])) ** 2).mean()
+loss.backward()
+local = fp.grad.clone()
+dist.all_reduce(fp.grad)                       # the one collective of the step
+gathered = [torch.zeros_like(local) for _ in range(world)]
+dist.all_gather(gathered, local)
+assert torch.allclose(fp.grad, sum(gathered)), "all-reduce != sum of per-rank gradients"
+fp.param -= 0.1 * fp.grad / world              # redundant update on every rank
+chk = [torch.zeros_like(fp.param) for _ in range(world)]
+dist.all_gather(chk, fp.param)
+assert all(torch.equal(chk[0], c) for c in chk), "replicas diverged"
+assert not torch.equal(gathered[0], gathered[1]), "ranks must see different rays"
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_data_parallel_allreduce_two_ranks_gloo(tmp_path):
+    script = tmp_path / "dp.py"
+    script.write_text(_DIST_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
