@@ -160,13 +160,13 @@ size_t lush_mlp_packed_bytes(int net, int planes);
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream);
 /* Bytes of the activation stash for P points (forward -> backward) and of the
  * dZ workspace used inside lush_mlp_bwd. */
-size_t lush_mlp_stash_bytes(int net, int planes, long long P);
+size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P);
 size_t lush_mlp_dstash_bytes(int net, int planes, long long P);
 /* rays [R][11], z [R][S] -> raw [R*S][4] (rgb raw x3, sigma raw; sigma = 0 for
- * net 1).  stash may be NULL (inference: nothing saved); otherwise it has
- * lush_mlp_stash_bytes(net, stash_planes, R*S) bytes and receives the first
- * stash_planes (<= planes) bf16 planes of every activation: the backward only needs
- * as many planes as it computes with. */
+ * net 1).  stash has lush_mlp_stash_bytes(net, planes, stash_planes, R*S) bytes and receives
+ * the first stash_planes (<= planes) bf16 planes of every activation (the backward only needs as
+ * many planes as it computes with) plus the encoded inputs.  stash_planes = 0 is inference:
+ * the buffer is then only the kernel's gamma-row workspace and nothing is kept for a backward. */
 int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
                  const void* packed, const lush_mlp_params* prm, float* raw, void* stash,
                  lush_stream_t stream);

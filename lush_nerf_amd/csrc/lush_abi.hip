@@ -7,33 +7,34 @@ using namespace lush;
 
 namespace {
 
-struct NetInfo { int HW, NL, SKIP, HV, NRB, total_entries; };
-template <class N> NetInfo info_of() { return {N::HW, N::NL, N::SKIP, N::HV, N::NRB, N::total_entries}; }
+struct NetInfo { int HW, NL, SKIP, HV, NRB, total_entries, f32_total; };
+template <class N> NetInfo info_of() { return {N::HW, N::NL, N::SKIP, N::HV, N::NRB, N::total_entries, N::f32_total}; }
 bool net_info(int net, NetInfo& o) {
     if (net == 0) { o = info_of<NetNerf>(); return true; }
     if (net == 1) { o = info_of<NetNoise>(); return true; }
     return false;
 }
 
-constexpr int MT = 64;
-inline long long pad_pts(long long P) { return (P + MT - 1) / MT * MT; }
+constexpr int PT_PAD = 128;     // point arrays are padded to the largest tile
+inline long long pad_pts(long long P) { return (P + PT_PAD - 1) / PT_PAD * PT_PAD; }
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Byte offsets inside the forward stash.
+// Byte offsets inside the forward stash: [ReLU masks][h_0..][feature][views hidden] with
+// `sp` (stash) planes, then the gamma rows with `pf` (forward) planes -- the forward itself
+// re-reads them.  sp == 0 (inference) leaves only the gamma rows.
 struct StashLayout {
     size_t mask, pe, h[NET_MAX_LAYERS], feat, hv, total;
-    long long Ppad, n_tiles;
+    long long Ppad;
 };
-StashLayout stash_layout(const NetInfo& n, int ns, long long P) {
+StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
     StashLayout L{};
     L.Ppad = pad_pts(P);
-    L.n_tiles = L.Ppad / MT;
     size_t off = 0;
-    L.mask = off; off += al256((size_t)L.n_tiles * (n.NL + 1) * n.NRB * (MT / 32) * 16 * 8);
-    L.pe = off;   off += al256((size_t)ns * L.Ppad * PE_ROW * 2);
-    for (int l = 0; l < n.NL; ++l) { L.h[l] = off; off += al256((size_t)ns * L.Ppad * n.HW * 2); }
-    L.feat = off; off += al256((size_t)ns * L.Ppad * n.HW * 2);
-    L.hv = off;   off += al256((size_t)ns * L.Ppad * n.HV * 2);
+    L.mask = off; off += sp ? al256((size_t)(L.Ppad / 32) * (n.NL + 1) * n.NRB * 16 * 8) : 0;
+    for (int l = 0; l < n.NL; ++l) { L.h[l] = off; off += al256((size_t)sp * L.Ppad * n.HW * 2); }
+    L.feat = off; off += al256((size_t)sp * L.Ppad * n.HW * 2);
+    L.hv = off;   off += al256((size_t)sp * L.Ppad * n.HV * 2);
+    L.pe = off;   off += al256((size_t)pf * L.Ppad * PE_ROW * 2);
     L.total = off;
     return L;
 }
@@ -113,7 +114,7 @@ extern "C" {
 size_t lush_mlp_packed_bytes(int net, int planes) {
     NetInfo n;
     if (!net_info(net, n) || planes < 1 || planes > 3) return 0;
-    return (size_t)n.total_entries * planes * 1024;
+    return al256((size_t)n.total_entries * planes * 1024 + (size_t)n.f32_total * 4);
 }
 
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream) {
@@ -122,13 +123,16 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
     if (net == 0) build_pack_table<NetNerf>(prm, T, blocks);
     else if (net == 1) build_pack_table<NetNoise>(prm, T, blocks);
     else return set_error("lush_mlp_pack: bad net");
-    return launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+    if (planes < 1 || planes > 3) return set_error("lush_mlp_pack: planes must be 1..3");
+    int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_pack_f32(net, planes, to_params(prm), packed, (hipStream_t)stream);
 }
 
-size_t lush_mlp_stash_bytes(int net, int planes, long long P) {
+size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P) {
     NetInfo n;
-    if (!net_info(net, n)) return 0;
-    return stash_layout(n, planes, P).total;
+    if (!net_info(net, n) || stash_planes < 0 || stash_planes > planes_fwd) return 0;
+    return stash_layout(n, planes_fwd, stash_planes, P).total;
 }
 size_t lush_mlp_dstash_bytes(int net, int planes, long long P) {
     NetInfo n;
@@ -139,7 +143,7 @@ size_t lush_mlp_dstash_bytes(int net, int planes, long long P) {
 int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("bad net");
-    const StashLayout L = stash_layout(n, planes, P);
+    const StashLayout L = stash_layout(n, planes, planes, P);
     o[0] = (long long)L.mask; o[1] = (long long)L.pe;
     for (int l = 0; l < NET_MAX_LAYERS; ++l) o[2 + l] = l < n.NL ? (long long)L.h[l] : -1;
     o[10] = (long long)L.feat; o[11] = (long long)L.hv; o[12] = L.Ppad; o[13] = (long long)L.total;
@@ -152,28 +156,29 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_fwd: bad net");
     if (planes < 1 || planes > 3) return set_error("lush_mlp_fwd: planes must be 1..3");
+    if (stash_planes < 0 || stash_planes > planes) return set_error("lush_mlp_fwd: need 0 <= stash_planes <= planes");
+    if (!stash) return set_error("lush_mlp_fwd: stash (or the inference workspace) is required");
     if (R <= 0 || S <= 0) return set_error("lush_mlp_fwd: empty batch");
-    if (stash && (stash_planes < 1 || stash_planes > planes)) return set_error("lush_mlp_fwd: need 1 <= stash_planes <= planes");
     const long long P = (long long)R * S;
-    const StashLayout L = stash_layout(n, stash ? stash_planes : planes, P);
+    if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
+    const StashLayout L = stash_layout(n, planes, stash_planes, P);
+    const int mt = mlp_fwd_tile(planes);
     MlpFwdArgs a{};
     a.stash_planes = stash_planes;
-    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)L.n_tiles;
-    if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
+    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / mt);
     a.wpk = (const uint4*)packed;
-    a.prm = to_params(prm);
+    (void)prm;                                   // biases travel inside `packed` (lush_mlp_pack)
     a.raw = raw;
-    a.write_stash = stash != nullptr;
-    if (stash) {
-        char* b = (char*)stash;
-        a.st.mask = (unsigned long long*)(b + L.mask);
-        a.st.pe = (__bf16*)(b + L.pe);
-        for (int l = 0; l < n.NL; ++l) a.st.h[l] = (__bf16*)(b + L.h[l]);
-        a.st.feat = (__bf16*)(b + L.feat);
-        a.st.hv = (__bf16*)(b + L.hv);
-        a.st.plane_pe = L.Ppad * PE_ROW; a.st.plane_h = L.Ppad * n.HW; a.st.plane_hv = L.Ppad * n.HV;
-    }
-    const int grid = (int)(L.n_tiles < 1024 ? L.n_tiles : 1024);
+    a.write_stash = stash_planes > 0;
+    char* b = (char*)stash;
+    a.mask = (unsigned long long*)(b + L.mask);
+    a.pe = (__bf16*)(b + L.pe);
+    a.h0 = (__bf16*)(b + L.h[0]);
+    a.h_stride = n.NL > 1 ? (long long)(L.h[1] - L.h[0]) / 2 : 0;
+    a.feat = (__bf16*)(b + L.feat);
+    a.hv = (__bf16*)(b + L.hv);
+    a.plane_pe = L.Ppad * PE_ROW; a.plane_h = L.Ppad * n.HW; a.plane_hv = L.Ppad * n.HV;
+    const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
 }
 
@@ -186,7 +191,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     if (planes_b < 1 || planes_b > planes_f || planes_f > 3) return set_error("lush_mlp_bwd: need 1 <= planes_b <= planes_f <= 3");
     if (!stash || !dstash) return set_error("lush_mlp_bwd: stash and dstash are required");
     const long long P = (long long)R * S;
-    const StashLayout L = stash_layout(n, planes_f, P);
+    const StashLayout L = stash_layout(n, planes_f, planes_f, P);   // gamma rows come last: their plane count does not move the others
     const DStashLayout D = dstash_layout(n, planes_b, P);
     hipStream_t st = (hipStream_t)stream;
     const char* sb = (const char*)stash;
@@ -194,17 +199,20 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     const long long plane_h = L.Ppad * n.HW, plane_hv = L.Ppad * n.HV, plane_pe = L.Ppad * PE_ROW;
 
     MlpBwdArgs a{};
-    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)L.n_tiles;
+    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / mlp_bwd_tile(planes_b));
     a.wpk = (const uint4*)packed_b;
-    a.prm = to_params(prm);
+    (void)prm;
     a.draw = draw;
     a.mask = (const unsigned long long*)(sb + L.mask);
-    for (int l = 0; l < n.NL; ++l) a.dz[l] = (__bf16*)(db + D.dz[l]);
+    __bf16* dzp[NET_MAX_LAYERS];
+    for (int l = 0; l < n.NL; ++l) dzp[l] = (__bf16*)(db + D.dz[l]);
+    a.dz0 = dzp[0];
+    a.dz_stride = n.NL > 1 ? (long long)(D.dz[1] - D.dz[0]) / 2 : 0;
     a.dfeat = (__bf16*)(db + D.dfeat);
     a.dzv = (__bf16*)(db + D.dzv);
     a.plane_h = plane_h; a.plane_hv = plane_hv;
     a.dpts = dpts;
-    const int grid = (int)(L.n_tiles < 1024 ? L.n_tiles : 1024);
+    const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
     if (do_chain) rc = launch_mlp_bwd(net, planes_b, a, grid, st);
     if (rc || !do_weights) return rc;
@@ -228,7 +236,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         return launch_dw(planes_b, d, real_splits, st);
     };
     for (int l = 0; l < n.NL && !rc; ++l) {
-        const __bf16* Z = a.dz[l];
+        const __bf16* Z = dzp[l];
         if (l == 0) {
             rc = dw(Z, plane_h, n.HW, n.HW, pe, plane_pe, PE_ROW, 0, XV, g->w[0], XV, 0, g->b[0]);
         } else if (l == n.SKIP) {

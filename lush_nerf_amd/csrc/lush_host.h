@@ -16,10 +16,13 @@ int set_hip_error(hipError_t e, const char* what, const char* file, int line);
 
 // lush_mlp.hip
 size_t mlp_fwd_lds_bytes(int hw, int ns, int mt);
-size_t mlp_bwd_lds_bytes(int hw, int ns, int mt);
+size_t mlp_bwd_lds_bytes(int hw, int ns, int mt, int nthreads);
+int mlp_fwd_tile(int ns);
+int mlp_bwd_tile(int ns);
 int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s);
 int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s);
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
+int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s);
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);
 int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,

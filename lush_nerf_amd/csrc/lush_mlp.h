@@ -56,6 +56,17 @@ struct NetT {
     static constexpr int total_entries = bwd_END;
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
+
+    // ---- fp32 block appended to the packed fragments (offsets in floats) ----
+    // biases of every layer and the two K<=3 head matrices the backward applies on the VALU
+    static constexpr int f32_b_trunk = 0;                    // [NL][HW]
+    static constexpr int f32_b_feat = NL * HW;               // [HW]
+    static constexpr int f32_b_alpha = f32_b_feat + HW;      // [1] (32 reserved)
+    static constexpr int f32_b_views = f32_b_alpha + 32;     // [HV]
+    static constexpr int f32_b_rgb = f32_b_views + HV;       // [3] (32 reserved)
+    static constexpr int f32_w_rgb = f32_b_rgb + 32;         // [3][HV]
+    static constexpr int f32_w_alpha = f32_w_rgb + 3 * HV;   // [HW]
+    static constexpr int f32_total = f32_w_alpha + HW;
 };
 
 typedef NetT<256, 8, 5> NetNerf;
@@ -90,25 +101,23 @@ struct MlpGrads {        // same shapes as MlpParams, fp32, accumulated with ato
     float *w_feat, *b_feat, *w_alpha, *b_alpha, *w_views, *b_views, *w_rgb, *b_rgb;
 };
 
-// Activation stash written by the forward kernel (read by backward / dW).
-// Every array is [plane][Ppad][cols] bf16 with Ppad a multiple of the tile.
-struct MlpStash {
-    __bf16* pe;                    // [NS][Ppad][PE_ROW]
-    __bf16* h[NET_MAX_LAYERS];     // [NS][Ppad][HW]
-    __bf16* feat;                  // [NS][Ppad][HW]
-    __bf16* hv;                    // [NS][Ppad][HV]
-    unsigned long long* mask;      // ReLU sign bits, see mask_index()
-    long long plane_pe, plane_h, plane_hv;   // plane strides in elements
-};
-
+// Activation stash written by the forward kernel (read by backward / dW).  Every array is
+// [plane][Ppad][cols] bf16; the per-layer arrays are equally spaced (h[l] = h0 + l*h_stride) so the
+// kernels carry a handful of scalars instead of a pointer table (a 60-pointer argument block spills
+// SGPRs and puts scratch reloads into the MFMA loops).
 struct MlpFwdArgs {
     const float* rays;             // [R][11]
     const float* z;                // [R][S]
     int S, P, n_tiles;
-    const uint4* wpk;              // packed weights, NS planes
-    MlpParams prm;                 // biases are read from here
+    const uint4* wpk;              // packed fragments (NS planes) followed by the fp32 block
     float* raw;                    // [P][4]
-    MlpStash st;
+    unsigned long long* mask;      // ReLU sign bits, see mask_index()
+    __bf16* pe;                    // [NS][Ppad][PE_ROW]
+    __bf16* h0;                    // h_l = h0 + l*h_stride, each [sp][Ppad][HW]
+    __bf16* feat;                  // [sp][Ppad][HW]
+    __bf16* hv;                    // [sp][Ppad][HV]
+    long long h_stride;            // elements between consecutive layers' arrays
+    long long plane_pe, plane_h, plane_hv;   // plane strides in elements
     int write_stash;
     int stash_planes;              // planes copied to the stash (<= NS): what the backward will use
 };
@@ -117,14 +126,13 @@ struct MlpBwdArgs {
     const float* rays;
     const float* z;
     int S, P, n_tiles;
-    const uint4* wpk;              // packed weights with NSB planes
-    MlpParams prm;                 // w_rgb / w_alpha are read in fp32
+    const uint4* wpk;              // packed fragments with NSB planes + fp32 block
     const float* draw;             // [P][4]
     const unsigned long long* mask;
-    // dZ stash (NSB planes): dz[l] [Ppad][HW], dfeat [Ppad][HW], dzv [Ppad][HV]
-    __bf16* dz[NET_MAX_LAYERS];
-    __bf16* dfeat;
-    __bf16* dzv;
+    __bf16* dz0;                   // dZ_l = dz0 + l*dz_stride, each [NSB][Ppad][HW]
+    __bf16* dfeat;                 // [NSB][Ppad][HW]
+    __bf16* dzv;                   // [NSB][Ppad][HV]
+    long long dz_stride;
     long long plane_h, plane_hv;
     float* dpts;                   // [P][8]: d/dx (3), pad, d/dviewdir (3), pad
 };

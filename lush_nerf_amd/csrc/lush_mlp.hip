@@ -25,8 +25,8 @@
 
 namespace lush {
 
-constexpr int NWAVES = 8;                 // fused MLP kernels: 2 waves per SIMD
-constexpr int NTHREADS = NWAVES * WAVE;
+// fused MLP kernels take the wave count NW as a template parameter (8 = 2 waves per SIMD with a
+// 256-register budget, 4 = 1 wave per SIMD with 512 registers for the 128-point tile)
 constexpr int DW_THREADS = 256;           // weight-gradient GEMM / reductions: 4 waves as 2x2
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), which
@@ -65,6 +65,22 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __r
         for (int i = 0; i < 8; ++i) v[i] = out[s][i];
         *reinterpret_cast<bf16x8*>(base + ((long long)s * 64 + lane) * 8) = v;
     }
+}
+
+// fp32 block behind the fragments: biases + the two K<=3 head matrices (offsets: NetT::f32_*)
+template <class N>
+__global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N::f32_total) return;
+    float v = 0.f;
+    if (i < N::f32_b_feat) v = P.b[i / N::HW][i % N::HW];
+    else if (i < N::f32_b_alpha) v = P.b_feat[i - N::f32_b_feat];
+    else if (i < N::f32_b_views) v = (i == N::f32_b_alpha) ? P.b_alpha[0] : 0.f;
+    else if (i < N::f32_b_rgb) v = P.b_views[i - N::f32_b_views];
+    else if (i < N::f32_w_rgb) v = (i - N::f32_b_rgb < 3) ? P.b_rgb[i - N::f32_b_rgb] : 0.f;
+    else if (i < N::f32_w_alpha) v = P.w_rgb[i - N::f32_w_rgb];
+    else v = P.w_alpha[i - N::f32_w_alpha];
+    dst[i] = v;
 }
 
 // ----------------------------------------------------------------------------
@@ -137,9 +153,10 @@ __device__ __forceinline__ void acc_bias(f32x16 (&acc)[RB][CB], const float* __r
         }
 }
 
-// Mask words: one 64-bit ballot per (tile, mask layer, row-block, col-block, q).
+// Mask words: one 64-bit ballot per (32-point column block, mask layer, row-block, q); the
+// column block is global (tile*CB + cb) so kernels with different tile sizes agree.
 __device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int nrb, int rb, int CB, int cb) {
-    return ((((long long)tile * n_ml + ml) * nrb + rb) * CB + cb) * 16;
+    return ((((long long)tile * CB + cb) * n_ml + ml) * nrb + rb) * 16;
 }
 
 // Write one 32x32 accumulator block as NS bf16 planes into the LDS image
@@ -217,12 +234,12 @@ __device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int pl
 // positional encoding of one tile into the PE image
 // ----------------------------------------------------------------------------
 template <int NS>
-__device__ __forceinline__ void pe_put(char* peimg, int plane_bytes, int pt, int col, float v) {
+__device__ __forceinline__ void pe_put(char* img, int plane_bytes, int row_bytes, int pt, int col, float v) {
     __bf16 p[NS];
     split_planes<NS>(v, p);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        *reinterpret_cast<__bf16*>(peimg + s * plane_bytes + swz(pt, col >> 3, PE_ROW * 2) + (col & 7) * 2) = p[s];
+        *reinterpret_cast<__bf16*>(img + s * plane_bytes + swz(pt, col >> 3, row_bytes) + (col & 7) * 2) = p[s];
 }
 
 // Point position exactly as the reference forms it: o + d*z, two roundings,
@@ -239,8 +256,8 @@ __device__ __forceinline__ void point_of(const float* __restrict__ rays, const f
     }
 }
 
-template <int NS, int MT>
-__device__ __forceinline__ void pe_tile(char* peimg, int plane_bytes, const float* rays, const float* z,
+template <int NS, int MT, int NTHREADS>
+__device__ __forceinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
                                         int S, int P, long long tile_pt0, int tid) {
     constexpr int PARTS = NTHREADS / MT;
     const int pt = tid % MT, part = tid / MT;
@@ -256,25 +273,26 @@ __device__ __forceinline__ void pe_tile(char* peimg, int plane_bytes, const floa
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float v = isd ? d[i] : x[i];
-            if (k == 0) pe_put<NS>(peimg, plane_bytes, pt, base + i, v);
+            if (k == 0) pe_put<NS>(peimg, plane_bytes, row_bytes, pt, base + i, v);
             float s, c;
             sincosf(v * f, &s, &c);
-            pe_put<NS>(peimg, plane_bytes, pt, base + 3 + 6 * k + i, s);
-            pe_put<NS>(peimg, plane_bytes, pt, base + 3 + 6 * k + 3 + i, c);
+            pe_put<NS>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + i, s);
+            pe_put<NS>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + 3 + i, c);
         }
     }
     if (part == PARTS - 1) {   // zero padding columns that the K loops do read
-        pe_put<NS>(peimg, plane_bytes, pt, PE_X_VALID, 0.f);
+        pe_put<NS>(peimg, plane_bytes, row_bytes, pt, PE_X_VALID, 0.f);
 #pragma unroll
-        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS>(peimg, plane_bytes, pt, c, 0.f);
+        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS>(peimg, plane_bytes, row_bytes, pt, c, 0.f);
     }
 }
 
 // ----------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------
-template <class N, int NS, int MT, bool HAS_ALPHA>
-__global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
+template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
+__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
+    constexpr int NWAVES = NW, NTHREADS = NW * 64;
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL;
     constexpr int CB = MT / 32;
     constexpr int RB = N::NRB >= NWAVES ? N::NRB / NWAVES : 1;      // row-blocks per wave, trunk
@@ -290,17 +308,18 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
     const int r = lane & 31, h = lane >> 5;
     const bf16x8* wpk = reinterpret_cast<const bf16x8*>(A.wpk);
     auto seg = [&](int entry) { return wpk + (long long)entry * NS * 64; };
+    const float* f32 = reinterpret_cast<const float*>(A.wpk) + (long long)N::total_entries * NS * 256;
     const bool stash_on = A.write_stash != 0;
 
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * MT;
-        pe_tile<NS, MT>(peimg, PE_PLANE, A.rays, A.z, A.S, A.P, pt0, tid);
+        pe_tile<NS, MT, NTHREADS>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
         lds_barrier();
         if (stash_on) {   // de-swizzled 16-byte copies of the 96 live PE columns
             for (int i = tid; i < A.stash_planes * MT * 12; i += NTHREADS) {
                 const int c = i % 12, pt = (i / 12) % MT, p = i / (12 * MT);
                 const uint4 v = *reinterpret_cast<const uint4*>(peimg + p * PE_PLANE + swz(pt, c, PE_ROW * 2));
-                *reinterpret_cast<uint4*>(A.st.pe + p * A.st.plane_pe + (pt0 + pt) * PE_ROW + c * 8) = v;
+                *reinterpret_cast<uint4*>(A.pe + p * A.plane_pe + (pt0 + pt) * PE_ROW + c * 8) = v;
             }
         }
         f32x16 acc[RB][CB];
@@ -308,15 +327,15 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
         const bool trunk_active = (w * RB) < N::NRB;
         // ---- layer 0 ----
         if (trunk_active) {
-            acc_bias<RB, CB>(acc, A.prm.b[0], rb0, HW, h);
+            acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk, rb0, HW, h);
             seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(0, false)), N::NRB, rb0, peimg, PE_PLANE, PE_ROW * 2, 0, lane);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
                     store_block<NS, true>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
-                                          stash_on ? A.st.h[0] : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r,
-                                          stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, 0, N::NRB, rb0 + i, CB, cb) : nullptr);
+                                          nullptr, 0, HW, pt0 + cb * 32 + r,
+                                          stash_on ? A.mask + mask_index(tile, N::n_mask_layers, 0, N::NRB, rb0 + i, CB, cb) : nullptr);
         }
         lds_barrier();
         // Stash copies are issued AFTER the weight loads of the layer that consumes the image and
@@ -326,14 +345,14 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
 #pragma unroll 1
         for (int l = 1; l < NL; ++l) {
             if (trunk_active) {
-                acc_bias<RB, CB>(acc, A.prm.b[l], rb0, HW, h);
+                acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk + l * HW, rb0, HW, h);
                 if (l == N::SKIP)
                     seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(l, false)), N::NRB, rb0, peimg, PE_PLANE,
                                                  PE_ROW * 2, 0, lane);
                 seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
-            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[l - 1], A.st.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (l - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
             lds_barrier();
             if (trunk_active) {
 #pragma unroll
@@ -341,26 +360,26 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
                         store_block<NS, true>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
-                                              stash_on ? A.st.h[l] : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r,
-                                              stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, l, N::NRB, rb0 + i, CB, cb) : nullptr);
+                                              nullptr, 0, HW, pt0 + cb * 32 + r,
+                                              stash_on ? A.mask + mask_index(tile, N::n_mask_layers, l, N::NRB, rb0 + i, CB, cb) : nullptr);
             }
             lds_barrier();
         }
         // ---- feature (no activation) and alpha heads, both read h_{NL-1} ----
         if (trunk_active) {
-            acc_bias<RB, CB>(acc, A.prm.b_feat, rb0, HW, h);
+            acc_bias<RB, CB>(acc, f32 + N::f32_b_feat, rb0, HW, h);
             seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_FEAT), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
         }
         if (HAS_ALPHA && w == NWAVES - 1) {
             f32x16 aa[1][CB];
-            acc_bias<1, CB>(aa, A.prm.b_alpha, 0, 1, h);
+            acc_bias<1, CB>(aa, f32 + N::f32_b_alpha, 0, 1, h);
             seg_gemm<NS, 1, CB, N::KKH>(aa, seg(N::fwd_ALPHA), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
             if (h == 0) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) alphabuf[cb * 32 + r] = aa[0][cb][0];
             }
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.h[NL - 1], A.st.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (NL - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
         lds_barrier();
         if (trunk_active) {
 #pragma unroll
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
                     store_block<NS, false>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
-                                           stash_on ? A.st.feat : nullptr, A.st.plane_h, HW, pt0 + cb * 32 + r, nullptr);
+                                           nullptr, 0, HW, pt0 + cb * 32 + r, nullptr);
         }
         lds_barrier();
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
@@ -376,12 +395,12 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
         const int rbv0 = w * RBV;
         const bool views_active = rbv0 < N::NRBV;
         if (views_active) {
-            acc_bias<RBV, CB>(av, A.prm.b_views, rbv0, HV, h);
+            acc_bias<RBV, CB>(av, f32 + N::f32_b_views, rbv0, HV, h);
             seg_gemm<NS, RBV, CB, N::KKH>(av, seg(N::fwd_VA), N::NRBV, rbv0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
             seg_gemm<NS, RBV, CB, N::KKD>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.st.feat, A.st.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.feat, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
         lds_barrier();
         if (views_active) {
 #pragma unroll
@@ -389,14 +408,14 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
                     store_block<NS, true>(av[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rbv0 + i, lane,
-                                          stash_on ? A.st.hv : nullptr, A.st.plane_hv, HV, pt0 + cb * 32 + r,
-                                          stash_on ? A.st.mask + mask_index(tile, N::n_mask_layers, NL, N::NRB, rbv0 + i, CB, cb) : nullptr);
+                                          nullptr, 0, HV, pt0 + cb * 32 + r,
+                                          stash_on ? A.mask + mask_index(tile, N::n_mask_layers, NL, N::NRB, rbv0 + i, CB, cb) : nullptr);
         }
         lds_barrier();
         // ---- rgb head (3 rows) on wave 0; alpha joins from LDS ----
         if (w == 0) {
             f32x16 ar[1][CB];
-            acc_bias<1, CB>(ar, A.prm.b_rgb, 0, 3, h);
+            acc_bias<1, CB>(ar, f32 + N::f32_b_rgb, 0, 3, h);
             seg_gemm<NS, 1, CB, N::KKV>(ar, seg(N::fwd_RGB), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
             if (h == 0) {
 #pragma unroll
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 }
             }
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HV, A.st.hv, A.st.plane_hv, HV, pt0, tid, NTHREADS, A.stash_planes);
+        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HV, A.hv, A.plane_hv, HV, pt0, tid, NTHREADS, A.stash_planes);
         lds_barrier();
     }
 }
@@ -438,8 +457,9 @@ __device__ __forceinline__ void dpe_add(float* dpe, const f32x16 (&acc)[1][CB], 
         }
 }
 
-template <class N, int NS, int MT, bool HAS_ALPHA>
-__global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
+template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
+__global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
+    constexpr int NWAVES = NW, NTHREADS = NW * 64;
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL;
     constexpr int CB = MT / 32;
     constexpr int RB = N::NRB >= NWAVES ? N::NRB / NWAVES : 1;
@@ -456,6 +476,9 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
     const int r = lane & 31, h = lane >> 5;
     const bf16x8* wpk = reinterpret_cast<const bf16x8*>(A.wpk);
     auto seg = [&](int entry) { return wpk + (long long)entry * NS * 64; };
+    const float* f32 = reinterpret_cast<const float*>(A.wpk) + (long long)N::total_entries * NS * 256;
+    const float* w_rgb = f32 + N::f32_w_rgb;
+    const float* w_alpha = f32 + N::f32_w_alpha;
     const int rb0 = w * RB, rbv0 = w * RBV;
     const bool trunk_active = rb0 < N::NRB, views_active = rbv0 < N::NRBV;
 
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int row = (rbv0 + i) * 32 + acc_row(q, h);
-                    const float w0 = A.prm.w_rgb[row], w1 = A.prm.w_rgb[HV + row], w2 = A.prm.w_rgb[2 * HV + row];
+                    const float w0 = w_rgb[row], w1 = w_rgb[HV + row], w2 = w_rgb[2 * HV + row];
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) {
                         const float* dr = drawbuf + (cb * 32 + r) * 4;
@@ -524,7 +547,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const float wa = A.prm.w_alpha[(rb0 + i) * 32 + acc_row(q, h)];
+                        const float wa = w_alpha[(rb0 + i) * 32 + acc_row(q, h)];
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) acc[i][cb][q] += wa * drawbuf[(cb * 32 + r) * 4 + 3];
                     }
@@ -538,7 +561,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
                     store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
-                                           A.dz[NL - 1], A.plane_h, HW, pt0 + cb * 32 + r, maskw(NL - 1, rb0 + i, cb));
+                                           A.dz0 + (NL - 1) * A.dz_stride, A.plane_h, HW, pt0 + cb * 32 + r, maskw(NL - 1, rb0 + i, cb));
         }
         lds_barrier();
         // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
                 seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::bwd_LT(l, true)), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
-            copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz[l], A.plane_h, HW, pt0, tid, NTHREADS);
+            copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz0 + l * A.dz_stride, A.plane_h, HW, pt0, tid, NTHREADS);
             lds_barrier();
             if (trunk_active) {
 #pragma unroll
@@ -563,7 +586,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
                         store_block_masked<NS>(acc[i][cb], dimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
-                                               A.dz[l - 1], A.plane_h, HW, pt0 + cb * 32 + r, maskw(l - 1, rb0 + i, cb));
+                                               A.dz0 + (l - 1) * A.dz_stride, A.plane_h, HW, pt0 + cb * 32 + r, maskw(l - 1, rb0 + i, cb));
             }
             lds_barrier();
         }
@@ -574,7 +597,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_kernel(const MlpBwdArgs A) {
             seg_gemm<NS, 1, CB, N::KKH>(ap, seg(N::bwd_LT(0, false)), 2, w, dimg, ACT_PLANE, ACT_ROW, 0, lane);
             dpe_add<CB>(dpe, ap, w, 0, lane, N::SKIP >= 0);
         }
-        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz[0], A.plane_h, HW, pt0, tid, NTHREADS);
+        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz0, A.plane_h, HW, pt0, tid, NTHREADS);
         lds_barrier();
         // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos) ----
         {
@@ -762,82 +785,75 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
             }
 }
 
-// db[o] += sum_p sum_planes dZ[p][o]
-template <int NS>
-__global__ __launch_bounds__(DW_THREADS) void colsum_kernel(const __bf16* __restrict__ Z, long long plane, int ld,
-                                                          int n, long long Ppad, int pts_per_block,
-                                                          float* __restrict__ out) {
-    const long long p0 = (long long)blockIdx.x * pts_per_block;
-    long long p1 = p0 + pts_per_block;
-    if (p1 > Ppad) p1 = Ppad;
-    const int nchunk = (n + 7) / 8;            // 16-byte chunks per row
-    const int rows_par = DW_THREADS / nchunk;    // rows handled concurrently
-    const int c = threadIdx.x % nchunk, rr = threadIdx.x / nchunk;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (rr < rows_par) {
-        for (long long p = p0 + rr; p < p1; p += rows_par)
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Z + pl * plane + p * ld + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
-            }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (c * 8 + e < n) atomicAdd(out + c * 8 + e, s[e]);
-    }
-}
-
 // Heads whose dZ is the fp32 d_raw: rgb_linear (X = hv) and alpha_linear (X = h_{NL-1}).
+// Thread (c, rr): 16-byte column chunk c of [hv | h_last], every ROWS-th point; fp32 atomics at the end.
 template <int NS>
 __global__ __launch_bounds__(DW_THREADS) void head_dw_kernel(const float* __restrict__ draw, long long P,
-                                                           const __bf16* __restrict__ hv, long long plane_hv, int HV,
-                                                           const __bf16* __restrict__ hl, long long plane_h, int HW,
-                                                           int pts_per_block, float* __restrict__ dw_rgb,
-                                                           float* __restrict__ db_rgb, float* __restrict__ dw_alpha,
-                                                           float* __restrict__ db_alpha) {
-    __shared__ float dr[64][4];
+                                                            const __bf16* __restrict__ hv, long long plane_hv, int HV,
+                                                            const __bf16* __restrict__ hl, long long plane_h, int HW,
+                                                            int pts_per_block, float* __restrict__ dw_rgb,
+                                                            float* __restrict__ db_rgb, float* __restrict__ dw_alpha,
+                                                            float* __restrict__ db_alpha) {
+    const int nchv = HV / 8, nch = nchv + (dw_alpha ? HW / 8 : 0);
+    const int rows = DW_THREADS / nch;
+    const int c = threadIdx.x % nch, rr = threadIdx.x / nch;
     const long long p0 = (long long)blockIdx.x * pts_per_block;
     long long p1 = p0 + pts_per_block;
     if (p1 > P) p1 = P;
-    const int j = threadIdx.x;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, aa = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    for (long long pc = p0; pc < p1; pc += 64) {
-        __syncthreads();
-        if (j < 256) {
-            const long long p = pc + j / 4;
-            dr[j / 4][j & 3] = p < p1 ? draw[p * 4 + (j & 3)] : 0.f;
-        }
-        __syncthreads();
-        const int n = (int)((p1 - pc) < 64 ? (p1 - pc) : 64);
-#pragma unroll 8
-        for (int t = 0; t < n; ++t) {
-            const long long p = pc + t;
-            if (j < HV) {
-                float x = 0.f;
+    const bool is_rgb = c < nchv;
+    const __bf16* base = is_rgb ? hv + c * 8 : hl + (c - nchv) * 8;
+    const long long plane = is_rgb ? plane_hv : plane_h;
+    const int ld = is_rgb ? HV : HW;
+    float a0[8], a1[8], a2[8], b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int pl = 0; pl < NS; ++pl) x += (float)hv[pl * plane_hv + p * HV + j];
-                a0 += dr[t][0] * x; a1 += dr[t][1] * x; a2 += dr[t][2] * x;
-            }
-            if (dw_alpha != nullptr && j < HW) {
-                float x = 0.f;
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = a2[e] = 0.f;
+#pragma unroll 4
+    for (long long p = p0 + rr; p < (rr < rows ? p1 : p0); p += rows) {
+        const float4 d = *reinterpret_cast<const float4*>(draw + p * 4);
+        float x[8];
 #pragma unroll
-                for (int pl = 0; pl < NS; ++pl) x += (float)hl[pl * plane_h + p * HW + j];
-                aa += dr[t][3] * x;
-            }
-            if (j == 0) { b0 += dr[t][0]; b1 += dr[t][1]; b2 += dr[t][2]; b3 += dr[t][3]; }
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + pl * plane + p * ld);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += (float)v[e];
         }
+        if (is_rgb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] += d.x * x[e]; a1[e] += d.y * x[e]; a2[e] += d.z * x[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a0[e] += d.w * x[e];
+        }
+        if (c == 0) { b[0] += d.x; b[1] += d.y; b[2] += d.z; b[3] += d.w; }
     }
-    if (j < HV) {
-        atomicAdd(dw_rgb + j, a0);
-        atomicAdd(dw_rgb + HV + j, a1);
-        atomicAdd(dw_rgb + 2 * HV + j, a2);
+    // block-level reduction in LDS, then one global atomic per output element and block
+    __shared__ float red[3 * 128 + 256 + 4];
+    for (int i = threadIdx.x; i < 3 * 128 + 256 + 4; i += DW_THREADS) red[i] = 0.f;
+    __syncthreads();
+    if (rr < rows) {
+        if (is_rgb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(&red[c * 8 + e], a0[e]);
+                atomicAdd(&red[128 + c * 8 + e], a1[e]);
+                atomicAdd(&red[256 + c * 8 + e], a2[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&red[384 + (c - nchv) * 8 + e], a0[e]);
+        }
+        if (c == 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&red[640 + e], b[e]);
     }
-    if (dw_alpha != nullptr && j < HW) atomicAdd(dw_alpha + j, aa);
-    if (j == 0) {
-        atomicAdd(db_rgb, b0); atomicAdd(db_rgb + 1, b1); atomicAdd(db_rgb + 2, b2);
-        if (db_alpha != nullptr) atomicAdd(db_alpha, b3);
-    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * HV; i += DW_THREADS) atomicAdd(dw_rgb + i, red[(i / HV) * 128 + (i % HV)]);
+    if (dw_alpha != nullptr)
+        for (int i = threadIdx.x; i < HW; i += DW_THREADS) atomicAdd(dw_alpha + i, red[384 + i]);
+    if (threadIdx.x < 3) atomicAdd(db_rgb + threadIdx.x, red[640 + threadIdx.x]);
+    if (threadIdx.x == 3 && db_alpha != nullptr) atomicAdd(db_alpha, red[643]);
 }
 
 }  // namespace lush
@@ -846,35 +862,72 @@ __global__ __launch_bounds__(DW_THREADS) void head_dw_kernel(const float* __rest
 // host launchers (C++ linkage inside the library; the C ABI is in lush_abi.hip)
 // ============================================================================
 #include "lush_host.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace lush {
 
 size_t mlp_fwd_lds_bytes(int hw, int ns, int mt) {
     return (size_t)ns * mt * hw * 2 + (size_t)ns * mt * PE_ROW * 2 + (size_t)mt * 4;
 }
-size_t mlp_bwd_lds_bytes(int hw, int ns, int mt) {
-    return (size_t)ns * mt * hw * 2 + (size_t)mt * DPE_LD * 4 + (size_t)mt * 16 + (size_t)(NTHREADS / mt) * mt * 24;
+size_t mlp_bwd_lds_bytes(int hw, int ns, int mt, int nthreads) {
+    return (size_t)ns * mt * hw * 2 + (size_t)mt * DPE_LD * 4 + (size_t)mt * 16 + (size_t)(nthreads / mt) * mt * 24;
 }
+// tile / wave configuration per plane count (env LUSH_FWD_CFG / LUSH_BWD_CFG = "MT,NW" override for tuning)
+struct TileCfg { int mt, nw; };
+static TileCfg cfg_from_env(const char* name, TileCfg def) {
+    const char* e = getenv(name);
+    int a = 0, b = 0;
+    if (e && sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 4 || b == 8)) return {a, b};
+    return def;
+}
+static TileCfg fwd_cfg(int ns) {
+    TileCfg c = cfg_from_env("LUSH_FWD_CFG", TileCfg{64, 8});
+    if (ns >= 2) c.mt = 64;              // activation + gamma images: 96 KB per 64 points at 2 planes
+    return c;
+}
+static TileCfg bwd_cfg(int ns) {
+    TileCfg c = cfg_from_env("LUSH_BWD_CFG", ns == 1 ? TileCfg{128, 8} : TileCfg{64, 8});
+    if (ns >= 2) c.mt = 64;              // + 51 KB fp32 d(gamma) image
+    return c;
+}
+int mlp_fwd_tile(int ns) { return fwd_cfg(ns).mt; }
+int mlp_bwd_tile(int ns) { return bwd_cfg(ns).mt; }
 
-template <class N, int NS, bool HAS_ALPHA>
-static int launch_fwd_t(const MlpFwdArgs& a, int grid, hipStream_t s) {
-    constexpr int MT = 64;
-    auto k = mlp_fwd_kernel<N, NS, MT, HAS_ALPHA>;
+template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
+static int launch_fwd_k(const MlpFwdArgs& a, int grid, hipStream_t s) {
+    auto k = mlp_fwd_kernel<N, NS, MT, NW, HAS_ALPHA>;
     const size_t lds = mlp_fwd_lds_bytes(N::HW, NS, MT);
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+template <class N, int NS, bool HAS_ALPHA>
+static int launch_fwd_t(const MlpFwdArgs& a, int grid, hipStream_t s) {
+    const TileCfg c = fwd_cfg(NS);
+    if constexpr (NS == 1) {
+        if (c.mt == 128) return launch_fwd_k<N, NS, 128, 8, HAS_ALPHA>(a, grid, s);
+    }
+    if (c.nw == 4) return launch_fwd_k<N, NS, 64, 4, HAS_ALPHA>(a, grid, s);
+    return launch_fwd_k<N, NS, 64, 8, HAS_ALPHA>(a, grid, s);
+}
+template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
+static int launch_bwd_k(const MlpBwdArgs& a, int grid, hipStream_t s) {
+    auto k = mlp_bwd_kernel<N, NS, MT, NW, HAS_ALPHA>;
+    const size_t lds = mlp_bwd_lds_bytes(N::HW, NS, MT, NW * 64);
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, s, a);
     LUSH_HIP(hipGetLastError());
     return 0;
 }
 template <class N, int NS, bool HAS_ALPHA>
 static int launch_bwd_t(const MlpBwdArgs& a, int grid, hipStream_t s) {
-    constexpr int MT = 64;
-    auto k = mlp_bwd_kernel<N, NS, MT, HAS_ALPHA>;
-    const size_t lds = mlp_bwd_lds_bytes(N::HW, NS, MT);
-    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, s, a);
-    LUSH_HIP(hipGetLastError());
-    return 0;
+    const TileCfg c = bwd_cfg(NS);
+    if constexpr (NS == 1) {
+        if (c.mt == 128) return launch_bwd_k<N, NS, 128, 8, HAS_ALPHA>(a, grid, s);
+    }
+    return launch_bwd_k<N, NS, 64, 8, HAS_ALPHA>(a, grid, s);
 }
 
 int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s) {
@@ -900,6 +953,18 @@ int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s
         if (ns == 3) return launch_bwd_t<NetNoise, 3, false>(a, grid, s);
     }
     return set_error("launch_mlp_bwd: bad net/planes");
+}
+
+int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s) {
+    if (net == 0) {
+        float* dst = reinterpret_cast<float*>(packed) + (size_t)NetNerf::total_entries * ns * 256;
+        hipLaunchKernelGGL(pack_f32_kernel<NetNerf>, dim3((NetNerf::f32_total + 255) / 256), dim3(256), 0, s, prm, dst);
+    } else {
+        float* dst = reinterpret_cast<float*>(packed) + (size_t)NetNoise::total_entries * ns * 256;
+        hipLaunchKernelGGL(pack_f32_kernel<NetNoise>, dim3((NetNoise::f32_total + 255) / 256), dim3(256), 0, s, prm, dst);
+    }
+    LUSH_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s) {
@@ -931,7 +996,7 @@ int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
 int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
                    float* db_alpha, hipStream_t s) {
-    const int ppb = 512;
+    const int ppb = 2048;
     const int blocks = (int)((P + ppb - 1) / ppb);
     if (ns == 1) hipLaunchKernelGGL(head_dw_kernel<1>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
     else if (ns == 2) hipLaunchKernelGGL(head_dw_kernel<2>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);

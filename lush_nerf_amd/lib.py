@@ -86,7 +86,7 @@ _SIGS = {
     "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _p, _p, _p, _p], _i),
     "lush_mlp_packed_bytes": ([_i, _i], _sz),
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
-    "lush_mlp_stash_bytes": ([_i, _i, _ll], _sz),
+    "lush_mlp_stash_bytes": ([_i, _i, _i, _ll], _sz),
     "lush_mlp_dstash_bytes": ([_i, _i, _ll], _sz),
     "lush_mlp_fwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p], _i),
     "lush_mlp_bwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p,

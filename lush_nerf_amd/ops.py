@@ -75,12 +75,10 @@ TIMER: Optional[KernelTimer] = None
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0):
     """stash_planes: planes kept for the backward (default: all `planes`)."""
     R, S = z.shape
-    sp = stash_planes or planes
+    sp = (stash_planes or planes) if want_stash else 0     # 0 = inference: only the gamma-row workspace
     raw = torch.empty(R * S, 4, dtype=torch.float32, device=rays.device)
-    stash = None
-    if want_stash:
-        stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, sp, R * S), dtype=torch.uint8,
-                            device=rays.device)
+    stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, sp, R * S), dtype=torch.uint8,
+                        device=rays.device)
     st = lib.mlp_struct(tensors, _NL[net])
     ev = TIMER.span("mlp_fwd" if net == NET_NERF else "noise_fwd", R * S) if TIMER is not None else None
     if ev:
@@ -89,7 +87,7 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
              lib.ptr(raw), lib.ptr(stash), _stream())
     if ev:
         ev[1].record()
-    return raw, stash
+    return raw, (stash if want_stash else None)
 
 
 def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash):

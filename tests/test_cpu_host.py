@@ -31,7 +31,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     # pure host queries (no device work)
     assert l.lush_mlp_packed_bytes(0, 1) > 2 * 593408 * 2 and l.lush_mlp_packed_bytes(0, 3) == 3 * l.lush_mlp_packed_bytes(0, 1)
     assert l.lush_mlp_packed_bytes(7, 1) == 0
-    assert l.lush_mlp_stash_bytes(0, 2, 64) > 0 and l.lush_mlp_stash_bytes(0, 2, 65) == l.lush_mlp_stash_bytes(0, 2, 128)
+    assert l.lush_mlp_stash_bytes(0, 2, 2, 64) > 0 and l.lush_mlp_stash_bytes(0, 2, 1, 65) == l.lush_mlp_stash_bytes(0, 2, 1, 128)
+    assert 0 < l.lush_mlp_stash_bytes(0, 2, 0, 128) < l.lush_mlp_stash_bytes(0, 2, 1, 128) < l.lush_mlp_stash_bytes(0, 2, 2, 128)
 
 
 def test_product_refuses_cpu_tensors():
