@@ -86,56 +86,69 @@ __global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
 // ----------------------------------------------------------------------------
 // segment GEMM: acc[RB][CB] += Wseg[rows of this wave][K] * img[K][pts]
 // ----------------------------------------------------------------------------
-// Weight fragments go global(L2) -> registers through a ring of PF+1 slots (prefetch
-// distance PF k-steps); the K loop is rolled in groups of PF+1 steps so the ring
-// indices stay static (runtime-indexed register arrays would go to scratch) and
-// the compiler cannot hoist every load of the segment to the top.
+// Weight fragments go global(L2) -> registers through a ring of PF+1 slots (prefetch distance PF
+// k-steps); activation fragments go LDS -> registers one k-step ahead through 2 slots.  The K loop
+// is rolled in groups of G = PF+1 (even) steps so both ring indices stay static (runtime-indexed
+// register arrays would go to scratch).  __builtin_amdgcn_sched_barrier pins "issue the prefetches,
+// THEN the MFMAs of this step": without it hipcc (ROCm 7.2), under the 256-VGPR cap of a 512-thread
+// workgroup, sinks every prefetch to just before its use and the loop runs load -> wait -> MFMA
+// (measured: MFMA pipe 33 % busy, 56 % of wave cycles in s_waitcnt).
 template <int NS, int RB, int CB, int KK>
 __device__ __forceinline__ void seg_gemm(f32x16 (&acc)[RB][CB], const bf16x8* __restrict__ wseg,
                                          int nrb, int rb0, const char* img, int plane_bytes,
                                          int row_bytes, int chunk0, int lane) {
-    constexpr int PF = NS == 1 ? 4 : 2;
+    constexpr int PF = NS == 1 ? 5 : 3;
     constexpr int G = PF + 1;
+    static_assert(G % 2 == 0, "B double buffer needs an even group");
     constexpr int NG = (KK >= 2 * PF + 1) ? (KK - 2 * PF - 1) / G + 1 : 0;
     const int r = lane & 31, h = lane >> 5;
     bf16x8 a[G][RB][NS];
+    bf16x8 b[2][CB][NS];
     const bf16x8* wl = wseg + (long long)rb0 * NS * 64 + lane;
     const int kstride = nrb * NS * 64;
-    auto load = [&](bf16x8 (&dst)[RB][NS], int kk) {
+    auto loadA = [&](bf16x8 (&dst)[RB][NS], int kk) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int p = 0; p < NS; ++p) dst[i][p] = wl[(long long)kk * kstride + (i * NS + p) * 64];
     };
-    auto compute = [&](const bf16x8 (&src)[RB][NS], int kk) {
-        bf16x8 b[CB][NS];
+    auto loadB = [&](bf16x8 (&dst)[CB][NS], int kk) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int p = 0; p < NS; ++p)
-                b[cb][p] = *reinterpret_cast<const bf16x8*>(
+                dst[cb][p] = *reinterpret_cast<const bf16x8*>(
                     img + p * plane_bytes + swz(cb * 32 + r, chunk0 + 2 * kk + h, row_bytes));
+    };
+    auto mma = [&](const bf16x8 (&as)[RB][NS], const bf16x8 (&bs)[CB][NS]) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) acc[i][cb] = mfma_planes<NS>(src[i], b[cb], acc[i][cb]);
+            for (int cb = 0; cb < CB; ++cb) acc[i][cb] = mfma_planes<NS>(as[i], bs[cb], acc[i][cb]);
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s)
-        if (s < KK) load(a[s], s);
+        if (s < KK) loadA(a[s], s);
+    loadB(b[0], 0);
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         const int kb = g * G;
 #pragma unroll
         for (int s = 0; s < G; ++s) {
-            load(a[(s + PF) % G], kb + s + PF);
-            compute(a[s], kb + s);
+            loadA(a[(s + PF) % G], kb + s + PF);
+            loadB(b[(s + 1) & 1], kb + s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a[s], b[s & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
     for (int k = NG * G; k < KK; ++k) {
-        if (k + PF < KK) load(a[(k + PF) % G], k + PF);
-        compute(a[k % G], k);
+        if (k + PF < KK) loadA(a[(k + PF) % G], k + PF);
+        if (k + 1 < KK) loadB(b[(k + 1) & 1], k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[k % G], b[k & 1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -199,14 +212,22 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
 // 16-byte accesses: consecutive threads take consecutive chunks of a row, so each row leaves
 // as full 128-byte lines (the image is de-swizzled on the way out).
 template <int NS, int MT>
-__device__ __forceinline__ void copy_out(const char* img, int plane_bytes, int row_bytes, int ncols, __bf16* stash,
+__device__ __noinline__ void copy_out(const char* img, int plane_bytes, int row_bytes, int ncols, __bf16* stash,
                                          long long stash_plane, int stash_ld, long long pt0, int tid, int nthreads,
                                          int planes = NS) {
     const int cpr = ncols >> 3;                    // 16-byte chunks per row
     for (int i = tid; i < planes * MT * cpr; i += nthreads) {
         const int c = i % cpr, pt = (i / cpr) % MT, p = i / (cpr * MT);
         const uint4 v = *reinterpret_cast<const uint4*>(img + p * plane_bytes + swz(pt, c, row_bytes));
+#ifndef LUSH_NO_NT_STASH   // write-once stream: non-temporal stores (-2 % forward time)
+        {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            u32x4 vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(stash + p * stash_plane + (pt0 + pt) * stash_ld + c * 8));
+        }
+#else
         *reinterpret_cast<uint4*>(stash + p * stash_plane + (pt0 + pt) * stash_ld + c * 8) = v;
+#endif
     }
 }
 
@@ -256,8 +277,10 @@ __device__ __forceinline__ void point_of(const float* __restrict__ rays, const f
     }
 }
 
+// (not inlined on purpose: the inlined sincosf bodies otherwise leave dozens of loop-invariant
+// values live across the MFMA loops of the whole tile)
 template <int NS, int MT, int NTHREADS>
-__device__ __forceinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
+__device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
                                         int S, int P, long long tile_pt0, int tid) {
     constexpr int PARTS = NTHREADS / MT;
     const int pt = tid % MT, part = tid / MT;
@@ -286,6 +309,17 @@ __device__ __forceinline__ void pe_tile(char* peimg, int plane_bytes, int row_by
         for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS>(peimg, plane_bytes, row_bytes, pt, c, 0.f);
     }
 }
+
+// Re-derive lane / r / h from an opaque copy of the lane id at the top of every phase: everything
+// computed from them (swizzled LDS addresses, fragment pointers, mask slots) then CANNOT be hoisted
+// out of the layer loop by LICM and stays a short-lived temporary.  Without this ~150 VGPRs of
+// hoisted address math were live across every GEMM loop of the tile and the 256-register budget of
+// a 512-thread workgroup spilled inside the MFMA loops.
+#define LUSH_FRESH_LANE()                       \
+    int lane_f_ = lane;                         \
+    asm volatile("" : "+v"(lane_f_));           \
+    const int lane = lane_f_, r = lane & 31, h = lane >> 5; \
+    (void)r; (void)h;
 
 // ----------------------------------------------------------------------------
 // forward
@@ -327,6 +361,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
         const bool trunk_active = (w * RB) < N::NRB;
         // ---- layer 0 ----
         if (trunk_active) {
+            LUSH_FRESH_LANE();
             acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk, rb0, HW, h);
             seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(0, false)), N::NRB, rb0, peimg, PE_PLANE, PE_ROW * 2, 0, lane);
 #pragma unroll
@@ -344,6 +379,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
         // ---- layers 1 .. NL-1 ----
 #pragma unroll 1
         for (int l = 1; l < NL; ++l) {
+            LUSH_FRESH_LANE();
             if (trunk_active) {
                 acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk + l * HW, rb0, HW, h);
                 if (l == N::SKIP)
@@ -366,6 +402,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             lds_barrier();
         }
         // ---- feature (no activation) and alpha heads, both read h_{NL-1} ----
+        {
+        LUSH_FRESH_LANE();
         if (trunk_active) {
             acc_bias<RB, CB>(acc, f32 + N::f32_b_feat, rb0, HW, h);
             seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_FEAT), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
@@ -390,7 +428,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                                            nullptr, 0, HW, pt0 + cb * 32 + r, nullptr);
         }
         lds_barrier();
+        }
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
+        {
+        LUSH_FRESH_LANE();
         f32x16 av[RBV][CB];
         const int rbv0 = w * RBV;
         const bool views_active = rbv0 < N::NRBV;
@@ -412,8 +453,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                                           stash_on ? A.mask + mask_index(tile, N::n_mask_layers, NL, N::NRB, rbv0 + i, CB, cb) : nullptr);
         }
         lds_barrier();
+        }
         // ---- rgb head (3 rows) on wave 0; alpha joins from LDS ----
         if (w == 0) {
+            LUSH_FRESH_LANE();
             f32x16 ar[1][CB];
             acc_bias<1, CB>(ar, f32 + N::f32_b_rgb, 0, 3, h);
             seg_gemm<NS, 1, CB, N::KKV>(ar, seg(N::fwd_RGB), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
@@ -495,6 +538,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
         };
         // ---- dZv = (Wrgb^T d_rgb) * relu'(hv)   (K = 3: rank-3 update on the VALU) ----
         if (views_active) {
+            LUSH_FRESH_LANE();
 #pragma unroll
             for (int i = 0; i < RBV; ++i) {
                 f32x16 a[CB];
@@ -517,6 +561,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
         lds_barrier();
         // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
         f32x16 acc[RB][CB];
+        {
+        LUSH_FRESH_LANE();
         if (trunk_active) {
             acc_bias<RB, CB>(acc, nullptr, rb0, 0, h);
             seg_gemm<NS, RB, CB, N::KKV>(acc, seg(N::bwd_VAT), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
@@ -538,7 +584,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
                                            A.plane_h, HW, pt0 + cb * 32 + r, nullptr);
         }
         lds_barrier();
+        }
         // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
+        {
+        LUSH_FRESH_LANE();
         if (trunk_active) {
             acc_bias<RB, CB>(acc, nullptr, rb0, 0, h);
             seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::bwd_FEATT), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
@@ -564,9 +613,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
                                            A.dz0 + (NL - 1) * A.dz_stride, A.plane_h, HW, pt0 + cb * 32 + r, maskw(NL - 1, rb0 + i, cb));
         }
         lds_barrier();
+        }
         // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
 #pragma unroll 1
         for (int l = NL - 1; l >= 1; --l) {
+            LUSH_FRESH_LANE();
             if (l == N::SKIP && w < 2) {    // gamma(x) rows of the skip layer's input
                 f32x16 ap[1][CB];
                 acc_bias<1, CB>(ap, nullptr, 0, 0, h);
@@ -592,6 +643,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
         }
         // ---- layer 0: d gamma(x) += W_0^T dZ_0 ----
         if (w < 2) {
+            LUSH_FRESH_LANE();
             f32x16 ap[1][CB];
             acc_bias<1, CB>(ap, nullptr, 0, 0, h);
             seg_gemm<NS, 1, CB, N::KKH>(ap, seg(N::bwd_LT(0, false)), 2, w, dimg, ACT_PLANE, ACT_ROW, 0, lane);

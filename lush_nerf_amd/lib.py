@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -ffp-contract=off: fp32 VALU expressions round op by op like the reference's torch ops
     # (o + d*z must not become one FMA: a 1-ulp point error is amplified x512 by the encoding).
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           *os.environ.get("LUSH_HIPCC_FLAGS", "").split(),
            *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
