@@ -97,7 +97,7 @@ template <int NS, int RB, int CB, int KK>
 __device__ __forceinline__ void seg_gemm(f32x16 (&acc)[RB][CB], const bf16x8* __restrict__ wseg,
                                          int nrb, int rb0, const char* img, int plane_bytes,
                                          int row_bytes, int chunk0, int lane) {
-    constexpr int PF = NS == 1 ? 5 : 3;
+    constexpr int PF = 5;
     constexpr int G = PF + 1;
     static_assert(G % 2 == 0, "B double buffer needs an even group");
     constexpr int NG = (KK >= 2 * PF + 1) ? (KK - 2 * PF - 1) / G + 1 : 0;

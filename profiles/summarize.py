@@ -27,7 +27,7 @@ def group_of(name):
     return None
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 lines = []
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
@@ -50,7 +50,7 @@ if stats:
 traffic = {}
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(src, f"pmc_{c}", "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, f"pmc_{c}", "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
     agg = collections.defaultdict(float)

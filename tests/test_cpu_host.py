@@ -29,7 +29,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     l = lib.load()
     assert l.lush_abi_version() == 1
     # pure host queries (no device work)
-    assert l.lush_mlp_packed_bytes(0, 1) > 2 * 593408 * 2 and l.lush_mlp_packed_bytes(0, 3) == 3 * l.lush_mlp_packed_bytes(0, 1)
+    p1, p3 = l.lush_mlp_packed_bytes(0, 1), l.lush_mlp_packed_bytes(0, 3)
+    assert p1 > 2 * 593408 * 2 and 2.9 * p1 < p3 < 3 * p1      # fragments scale with planes, the fp32 bias block does not
     assert l.lush_mlp_packed_bytes(7, 1) == 0
     assert l.lush_mlp_stash_bytes(0, 2, 2, 64) > 0 and l.lush_mlp_stash_bytes(0, 2, 1, 65) == l.lush_mlp_stash_bytes(0, 2, 1, 128)
     assert 0 < l.lush_mlp_stash_bytes(0, 2, 0, 128) < l.lush_mlp_stash_bytes(0, 2, 1, 128) < l.lush_mlp_stash_bytes(0, 2, 2, 128)
