@@ -15,6 +15,9 @@ bool net_info(int net, NetInfo& o) {
     return false;
 }
 
+// plane code -> number of 16-bit planes stored / computed with
+inline bool code_ok(int c) { return (c >= 1 && c <= 3) || c == PLANES_F16; }
+inline int nplanes(int c) { return c == PLANES_F16 ? 1 : c; }
 constexpr int PT_PAD = 128;     // point arrays are padded to the largest tile
 inline long long pad_pts(long long P) { return (P + PT_PAD - 1) / PT_PAD * PT_PAD; }
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -113,8 +116,8 @@ extern "C" {
 
 size_t lush_mlp_packed_bytes(int net, int planes) {
     NetInfo n;
-    if (!net_info(net, n) || planes < 1 || planes > 3) return 0;
-    return al256((size_t)n.total_entries * planes * 1024 + (size_t)n.f32_total * 4);
+    if (!net_info(net, n) || !code_ok(planes)) return 0;
+    return al256((size_t)n.total_entries * nplanes(planes) * 1024 + (size_t)n.f32_total * 4);
 }
 
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream) {
@@ -123,16 +126,16 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
     if (net == 0) build_pack_table<NetNerf>(prm, T, blocks);
     else if (net == 1) build_pack_table<NetNoise>(prm, T, blocks);
     else return set_error("lush_mlp_pack: bad net");
-    if (planes < 1 || planes > 3) return set_error("lush_mlp_pack: planes must be 1..3");
+    if (!code_ok(planes)) return set_error("lush_mlp_pack: planes must be 1..3 or 17 (fp16)");
     int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
     if (rc) return rc;
-    return launch_pack_f32(net, planes, to_params(prm), packed, (hipStream_t)stream);
+    return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
 }
 
 size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P) {
     NetInfo n;
-    if (!net_info(net, n) || stash_planes < 0 || stash_planes > planes_fwd) return 0;
-    return stash_layout(n, planes_fwd, stash_planes, P).total;
+    if (!net_info(net, n) || !code_ok(planes_fwd) || stash_planes < 0 || nplanes(stash_planes) > nplanes(planes_fwd)) return 0;
+    return stash_layout(n, nplanes(planes_fwd), nplanes(stash_planes), P).total;
 }
 size_t lush_mlp_dstash_bytes(int net, int planes, long long P) {
     NetInfo n;
@@ -155,14 +158,15 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
                  const void* packed, const lush_mlp_params* prm, float* raw, void* stash, lush_stream_t stream) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_fwd: bad net");
-    if (planes < 1 || planes > 3) return set_error("lush_mlp_fwd: planes must be 1..3");
-    if (stash_planes < 0 || stash_planes > planes) return set_error("lush_mlp_fwd: need 0 <= stash_planes <= planes");
+    if (!code_ok(planes)) return set_error("lush_mlp_fwd: planes must be 1..3 or 17 (one fp16 plane)");
+    if (stash_planes == PLANES_F16) stash_planes = 1;
+    if (stash_planes < 0 || stash_planes > nplanes(planes)) return set_error("lush_mlp_fwd: need 0 <= stash_planes <= planes");
     if (!stash) return set_error("lush_mlp_fwd: stash (or the inference workspace) is required");
     if (R <= 0 || S <= 0) return set_error("lush_mlp_fwd: empty batch");
     const long long P = (long long)R * S;
     if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
-    const StashLayout L = stash_layout(n, planes, stash_planes, P);
-    const int mt = mlp_fwd_tile(planes);
+    const StashLayout L = stash_layout(n, nplanes(planes), stash_planes, P);
+    const int mt = planes == PLANES_F16 ? 64 : mlp_fwd_tile(planes);
     MlpFwdArgs a{};
     a.stash_planes = stash_planes;
     a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / mt);
@@ -188,6 +192,8 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
                         int do_weights) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
+    const bool x_f16 = planes_f == PLANES_F16;     // the stash was written by the fp16 forward
+    if (x_f16) planes_f = 1;
     if (planes_b < 1 || planes_b > planes_f || planes_f > 3) return set_error("lush_mlp_bwd: need 1 <= planes_b <= planes_f <= 3");
     if (!stash || !dstash) return set_error("lush_mlp_bwd: stash and dstash are required");
     const long long P = (long long)R * S;
@@ -226,6 +232,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         d.Z = Z; d.z_plane = zplane; d.ldz = ldz; d.n_out = n_out;
         d.X = X; d.x_plane = xplane; d.ldx = ldx; d.xcol0 = xcol0; d.k_in = k_in;
         d.dW = dW; d.ldw = ldw; d.wcol0 = wcol0; d.db = dbias;
+        d.x_f16 = x_f16 ? 1 : 0;
         d.Ppad = (int)L.Ppad;
         const int tiles = ((n_out + 127) / 128) * ((k_in + 127) / 128);
         const int splits = dw_splits(L.Ppad, tiles);
@@ -255,7 +262,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     rc = dw(a.dzv, plane_hv, n.HV, n.HV, pe, plane_pe, PE_ROW, PE_X, DV, g->w_views, n.HW + DV, n.HW, nullptr);
     if (rc) return rc;
     const __bf16* hv = (const __bf16*)(sb + L.hv);
-    return launch_head_dw(planes_b, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
+    return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
                           net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
 }
 

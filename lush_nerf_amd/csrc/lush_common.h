@@ -8,9 +8,11 @@ namespace lush {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPR)
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;   // 8 bytes
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator block
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+enum { DT_BF16 = 0, DT_F16 = 1 };   // 16-bit operand element type (see mfma_f16 below)
 constexpr int WAVE = 64;
 constexpr int MAX_PLANES = 3;
 
@@ -41,24 +43,43 @@ __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
 
 // Split x into NS bf16 planes: x ~= p0 + p1 (+ p2), each the round-to-nearest
 // bf16 of the running remainder.  Two planes carry 16 mantissa bits, three 24.
-template <int NS>
+template <int NS, int DT = DT_BF16>
 __device__ __forceinline__ void split_planes(float x, __bf16 (&p)[NS]) {
-    float r = x;
+    if constexpr (DT == DT_F16) {
+        static_assert(NS == 1, "fp16 is a single-plane format here");
+        p[0] = __builtin_bit_cast(__bf16, (_Float16)x);
+    } else {
+        float r = x;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        p[i] = (__bf16)r;
-        if (i + 1 < NS) r = r - (float)p[i];
+        for (int i = 0; i < NS; ++i) {
+            p[i] = (__bf16)r;
+            if (i + 1 < NS) r = r - (float)p[i];
+        }
     }
+}
+// value of a stored 16-bit element
+template <int DT>
+__device__ __forceinline__ float elem_to_f32(__bf16 v) {
+    if constexpr (DT == DT_F16) return (float)__builtin_bit_cast(_Float16, v);
+    else return (float)v;
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// 16-bit operand element type of a kernel: DT_BF16 planes (1..3 of them) or ONE fp16 plane.
+// fp16 (11-bit mantissa) in a single plane keeps render outputs within ~2.5e-5 of fp32 -- inside the
+// 1e-4 bound at one MFMA per product -- but its range is unsafe for gradients, so only the forward of
+// the 8x256 nets uses it.  Storage stays typed __bf16 (a 16-bit container); fp16 values are bit-cast.
+__device__ __forceinline__ f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 // acc += sum over plane pairs of A_i * B_j keeping every product of order
 // <= 2^-8(NS-1): NS=1 -> 1 MFMA, NS=2 -> 3, NS=3 -> 6.  Small terms first.
-template <int NS>
+template <int NS, int DT = DT_BF16>
 __device__ __forceinline__ f32x16 mfma_planes(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x16 c) {
+    if constexpr (DT == DT_F16) return mfma_f16(a[0], b[0], c);
     if constexpr (NS == 3) {
         c = mfma_bf16(a[1], b[1], c);
         c = mfma_bf16(a[2], b[0], c);

@@ -14,6 +14,7 @@
 namespace lush {
 
 enum { NET_MAX_LAYERS = 8 };
+enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -142,6 +143,7 @@ struct DwArgs {
     const __bf16* X; long long x_plane; int ldx; int xcol0; int k_in;
     float* dW; int ldw; int wcol0;
     float* db;                     // may be null
+    int x_f16;                     // X stash holds fp16 (one plane) instead of bf16 planes
     int Ppad;                      // multiple of 32
     int pts_per_split;             // multiple of 32
 };

@@ -36,7 +36,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ----------------------------------------------------------------------------
 // weight packing
 // ----------------------------------------------------------------------------
-template <int NS>
+template <int NS, int DT>
 __global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __restrict__ dst) {
     int b = blockIdx.x;
     int j = 0;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __r
         float v = 0.f;
         if (row < J.rows && k < J.cols) v = J.src[(long long)row * J.sr + (long long)k * J.sk];
         __bf16 p[NS];
-        split_planes<NS>(v, p);
+        split_planes<NS, DT>(v, p);
 #pragma unroll
         for (int s = 0; s < NS; ++s) out[s][i] = p[s];
     }
@@ -93,7 +93,7 @@ __global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
 // THEN the MFMAs of this step": without it hipcc (ROCm 7.2), under the 256-VGPR cap of a 512-thread
 // workgroup, sinks every prefetch to just before its use and the loop runs load -> wait -> MFMA
 // (measured: MFMA pipe 33 % busy, 56 % of wave cycles in s_waitcnt).
-template <int NS, int RB, int CB, int KK>
+template <int NS, int RB, int CB, int KK, int DT = DT_BF16>
 __device__ __forceinline__ void seg_gemm(f32x16 (&acc)[RB][CB], const bf16x8* __restrict__ wseg,
                                          int nrb, int rb0, const char* img, int plane_bytes,
                                          int row_bytes, int chunk0, int lane) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void seg_gemm(f32x16 (&acc)[RB][CB], const bf16x8* __
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) acc[i][cb] = mfma_planes<NS>(as[i], bs[cb], acc[i][cb]);
+            for (int cb = 0; cb < CB; ++cb) acc[i][cb] = mfma_planes<NS, DT>(as[i], bs[cb], acc[i][cb]);
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s)
@@ -174,7 +174,7 @@ __device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int 
 
 // Write one 32x32 accumulator block as NS bf16 planes into the LDS image
 // [pt][feature] (+ optionally the global stash and the ReLU sign bits).
-template <int NS, bool RELU>
+template <int NS, bool RELU, int DT = DT_BF16>
 __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int plane_bytes, int row_bytes,
                                             int pt, int rb, int lane, __bf16* stash, long long stash_plane,
                                             int stash_ld, long long gpt, unsigned long long* mask_words) {
@@ -195,7 +195,7 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
         for (int e = 0; e < 4; ++e) {
             float v = acc[4 * g + e];
             if (RELU) asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));   // plain max: fmaxf() adds a canonicalising v_max
-            split_planes<NS>(v, pl[e]);
+            split_planes<NS, DT>(v, pl[e]);
         }
         const int f = rb * 32 + 8 * g + 4 * h;          // first of 4 consecutive features
 #pragma unroll
@@ -254,10 +254,10 @@ __device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int pl
 // ----------------------------------------------------------------------------
 // positional encoding of one tile into the PE image
 // ----------------------------------------------------------------------------
-template <int NS>
+template <int NS, int DT>
 __device__ __forceinline__ void pe_put(char* img, int plane_bytes, int row_bytes, int pt, int col, float v) {
     __bf16 p[NS];
-    split_planes<NS>(v, p);
+    split_planes<NS, DT>(v, p);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         *reinterpret_cast<__bf16*>(img + s * plane_bytes + swz(pt, col >> 3, row_bytes) + (col & 7) * 2) = p[s];
@@ -279,7 +279,7 @@ __device__ __forceinline__ void point_of(const float* __restrict__ rays, const f
 
 // (not inlined on purpose: the inlined sincosf bodies otherwise leave dozens of loop-invariant
 // values live across the MFMA loops of the whole tile)
-template <int NS, int MT, int NTHREADS>
+template <int NS, int MT, int NTHREADS, int DT>
 __device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
                                         int S, int P, long long tile_pt0, int tid) {
     constexpr int PARTS = NTHREADS / MT;
@@ -296,17 +296,17 @@ __device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float v = isd ? d[i] : x[i];
-            if (k == 0) pe_put<NS>(peimg, plane_bytes, row_bytes, pt, base + i, v);
+            if (k == 0) pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + i, v);
             float s, c;
             sincosf(v * f, &s, &c);
-            pe_put<NS>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + i, s);
-            pe_put<NS>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + 3 + i, c);
+            pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + i, s);
+            pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + 3 + i, c);
         }
     }
     if (part == PARTS - 1) {   // zero padding columns that the K loops do read
-        pe_put<NS>(peimg, plane_bytes, row_bytes, pt, PE_X_VALID, 0.f);
+        pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, PE_X_VALID, 0.f);
 #pragma unroll
-        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS>(peimg, plane_bytes, row_bytes, pt, c, 0.f);
+        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, c, 0.f);
     }
 }
 
@@ -324,7 +324,7 @@ __device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes
 // ----------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------
-template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
+template <class N, int NS, int MT, int NW, bool HAS_ALPHA, int DT>
 __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
     constexpr int NWAVES = NW, NTHREADS = NW * 64;
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
 
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * MT;
-        pe_tile<NS, MT, NTHREADS>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
+        pe_tile<NS, MT, NTHREADS, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
         lds_barrier();
         if (stash_on) {   // de-swizzled 16-byte copies of the 96 live PE columns
             for (int i = tid; i < A.stash_planes * MT * 12; i += NTHREADS) {
@@ -363,12 +363,12 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
         if (trunk_active) {
             LUSH_FRESH_LANE();
             acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk, rb0, HW, h);
-            seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(0, false)), N::NRB, rb0, peimg, PE_PLANE, PE_ROW * 2, 0, lane);
+            seg_gemm<NS, RB, CB, N::KKX, DT>(acc, seg(N::fwd_L(0, false)), N::NRB, rb0, peimg, PE_PLANE, PE_ROW * 2, 0, lane);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
-                    store_block<NS, true>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                    store_block<NS, true, DT>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
                                           nullptr, 0, HW, pt0 + cb * 32 + r,
                                           stash_on ? A.mask + mask_index(tile, N::n_mask_layers, 0, N::NRB, rb0 + i, CB, cb) : nullptr);
         }
@@ -383,9 +383,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             if (trunk_active) {
                 acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk + l * HW, rb0, HW, h);
                 if (l == N::SKIP)
-                    seg_gemm<NS, RB, CB, N::KKX>(acc, seg(N::fwd_L(l, false)), N::NRB, rb0, peimg, PE_PLANE,
+                    seg_gemm<NS, RB, CB, N::KKX, DT>(acc, seg(N::fwd_L(l, false)), N::NRB, rb0, peimg, PE_PLANE,
                                                  PE_ROW * 2, 0, lane);
-                seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
+                seg_gemm<NS, RB, CB, N::KKH, DT>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
             if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (l - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
-                        store_block<NS, true>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                        store_block<NS, true, DT>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
                                               nullptr, 0, HW, pt0 + cb * 32 + r,
                                               stash_on ? A.mask + mask_index(tile, N::n_mask_layers, l, N::NRB, rb0 + i, CB, cb) : nullptr);
             }
@@ -406,12 +406,12 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
         LUSH_FRESH_LANE();
         if (trunk_active) {
             acc_bias<RB, CB>(acc, f32 + N::f32_b_feat, rb0, HW, h);
-            seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::fwd_FEAT), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            seg_gemm<NS, RB, CB, N::KKH, DT>(acc, seg(N::fwd_FEAT), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
         }
         if (HAS_ALPHA && w == NWAVES - 1) {
             f32x16 aa[1][CB];
             acc_bias<1, CB>(aa, f32 + N::f32_b_alpha, 0, 1, h);
-            seg_gemm<NS, 1, CB, N::KKH>(aa, seg(N::fwd_ALPHA), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            seg_gemm<NS, 1, CB, N::KKH, DT>(aa, seg(N::fwd_ALPHA), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
             if (h == 0) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) alphabuf[cb * 32 + r] = aa[0][cb][0];
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
-                    store_block<NS, false>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
+                    store_block<NS, false, DT>(acc[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rb0 + i, lane,
                                            nullptr, 0, HW, pt0 + cb * 32 + r, nullptr);
         }
         lds_barrier();
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
         const bool views_active = rbv0 < N::NRBV;
         if (views_active) {
             acc_bias<RBV, CB>(av, f32 + N::f32_b_views, rbv0, HV, h);
-            seg_gemm<NS, RBV, CB, N::KKH>(av, seg(N::fwd_VA), N::NRBV, rbv0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
-            seg_gemm<NS, RBV, CB, N::KKD>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
+            seg_gemm<NS, RBV, CB, N::KKH, DT>(av, seg(N::fwd_VA), N::NRBV, rbv0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            seg_gemm<NS, RBV, CB, N::KKD, DT>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
         if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.feat, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             for (int i = 0; i < RBV; ++i)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
-                    store_block<NS, true>(av[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rbv0 + i, lane,
+                    store_block<NS, true, DT>(av[i][cb], actimg, ACT_PLANE, ACT_ROW, cb * 32 + r, rbv0 + i, lane,
                                           nullptr, 0, HV, pt0 + cb * 32 + r,
                                           stash_on ? A.mask + mask_index(tile, N::n_mask_layers, NL, N::NRB, rbv0 + i, CB, cb) : nullptr);
         }
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             LUSH_FRESH_LANE();
             f32x16 ar[1][CB];
             acc_bias<1, CB>(ar, f32 + N::f32_b_rgb, 0, 3, h);
-            seg_gemm<NS, 1, CB, N::KKV>(ar, seg(N::fwd_RGB), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
+            seg_gemm<NS, 1, CB, N::KKV, DT>(ar, seg(N::fwd_RGB), 1, 0, actimg, ACT_PLANE, ACT_ROW, 0, lane);
             if (h == 0) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
@@ -718,7 +718,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, in
     return u.v;
 }
 
-template <int NS>
+// fp16 X stash (written by the fp16 forward) -> bf16 fragment (the gradients are bf16: fp16's range is
+// unsafe for dZ); 8 elements, two conversions each
+__device__ __forceinline__ bf16x8 f16_frag_to_bf16(bf16x8 v) {
+    const f16x8 hv = __builtin_bit_cast(f16x8, v);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(float)hv[e];
+    return o;
+}
+
+template <int NS, bool XF16>
 __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
     constexpr int DW_KT = DwKt<NS>::v;
     extern __shared__ __attribute__((aligned(16))) char tiles[];   // [2 buffers][Z planes | X planes][KT][DW_ROW]
@@ -790,7 +800,10 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) a[u][pl] = tr_frag(zt + pl * PLANE, ks * 16, wo * 128 + u * 32, lane);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) b[u][pl] = tr_frag(xt + pl * PLANE, ks * 16, wi * 64 + u * 32, lane);
+                    for (int u = 0; u < 2; ++u) {
+                        b[u][pl] = tr_frag(xt + pl * PLANE, ks * 16, wi * 64 + u * 32, lane);
+                        if constexpr (XF16) b[u][pl] = f16_frag_to_bf16(b[u][pl]);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -839,7 +852,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
 
 // Heads whose dZ is the fp32 d_raw: rgb_linear (X = hv) and alpha_linear (X = h_{NL-1}).
 // Thread (c, rr): 16-byte column chunk c of [hv | h_last], every ROWS-th point; fp32 atomics at the end.
-template <int NS>
+template <int NS, bool XF16>
 __global__ __launch_bounds__(DW_THREADS) void head_dw_kernel(const float* __restrict__ draw, long long P,
                                                             const __bf16* __restrict__ hv, long long plane_hv, int HV,
                                                             const __bf16* __restrict__ hl, long long plane_h, int HW,
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(DW_THREADS) void head_dw_kernel(const float* __rest
         for (int pl = 0; pl < NS; ++pl) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + pl * plane + p * ld);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) x[e] += elem_to_f32<XF16 ? DT_F16 : DT_BF16>(v[e]);
         }
         if (is_rgb) {
 #pragma unroll
@@ -946,9 +959,9 @@ static TileCfg bwd_cfg(int ns) {
 int mlp_fwd_tile(int ns) { return fwd_cfg(ns).mt; }
 int mlp_bwd_tile(int ns) { return bwd_cfg(ns).mt; }
 
-template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
+template <class N, int NS, int MT, int NW, bool HAS_ALPHA, int DT = DT_BF16>
 static int launch_fwd_k(const MlpFwdArgs& a, int grid, hipStream_t s) {
-    auto k = mlp_fwd_kernel<N, NS, MT, NW, HAS_ALPHA>;
+    auto k = mlp_fwd_kernel<N, NS, MT, NW, HAS_ALPHA, DT>;
     const size_t lds = mlp_fwd_lds_bytes(N::HW, NS, MT);
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, s, a);
@@ -983,6 +996,10 @@ static int launch_bwd_t(const MlpBwdArgs& a, int grid, hipStream_t s) {
 }
 
 int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s) {
+    if (ns == PLANES_F16) {   // one fp16 plane
+        if (net == 0) return launch_fwd_k<NetNerf, 1, 64, 8, true, DT_F16>(a, grid, s);
+        return launch_fwd_k<NetNoise, 1, 64, 8, false, DT_F16>(a, grid, s);
+    }
     if (net == 0) {
         if (ns == 1) return launch_fwd_t<NetNerf, 1, true>(a, grid, s);
         if (ns == 2) return launch_fwd_t<NetNerf, 2, true>(a, grid, s);
@@ -1020,18 +1037,19 @@ int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStre
 }
 
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s) {
-    if (ns == 1) hipLaunchKernelGGL(pack_kernel<1>, dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
-    else if (ns == 2) hipLaunchKernelGGL(pack_kernel<2>, dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
-    else if (ns == 3) hipLaunchKernelGGL(pack_kernel<3>, dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    if (ns == PLANES_F16) hipLaunchKernelGGL((pack_kernel<1, DT_F16>), dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    else if (ns == 1) hipLaunchKernelGGL((pack_kernel<1, DT_BF16>), dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    else if (ns == 2) hipLaunchKernelGGL((pack_kernel<2, DT_BF16>), dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
+    else if (ns == 3) hipLaunchKernelGGL((pack_kernel<3, DT_BF16>), dim3(total_blocks), dim3(64), 0, s, t, (__bf16*)dst);
     else return set_error("launch_pack: bad planes");
     LUSH_HIP(hipGetLastError());
     return 0;
 }
 
-template <int NS>
+template <int NS, bool XF16 = false>
 static int launch_dw_t(const DwArgs& a, int splits, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * NS * DwKt<NS>::v * DW_ROW;
-    auto k = dw_gemm_kernel<NS>;
+    auto k = dw_gemm_kernel<NS, XF16>;
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, a);
     LUSH_HIP(hipGetLastError());
@@ -1039,20 +1057,25 @@ static int launch_dw_t(const DwArgs& a, int splits, hipStream_t s) {
 }
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
     if (a.n_out > DW_T || a.k_in > DW_T) return set_error("launch_dw: layer wider than 256");
+    if (a.x_f16) {
+        if (ns != 1) return set_error("launch_dw: an fp16 stash has one plane");
+        return launch_dw_t<1, true>(a, splits, s);
+    }
     if (ns == 1) return launch_dw_t<1>(a, splits, s);
     if (ns == 2) return launch_dw_t<2>(a, splits, s);
     if (ns == 3) return launch_dw_t<3>(a, splits, s);
     return set_error("launch_dw: bad planes");
 }
 
-int launch_head_dw(int ns, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
+int launch_head_dw(int ns, bool x_f16, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
                    float* db_alpha, hipStream_t s) {
     const int ppb = 2048;
     const int blocks = (int)((P + ppb - 1) / ppb);
-    if (ns == 1) hipLaunchKernelGGL(head_dw_kernel<1>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else if (ns == 2) hipLaunchKernelGGL(head_dw_kernel<2>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else hipLaunchKernelGGL(head_dw_kernel<3>, dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    if (x_f16) hipLaunchKernelGGL((head_dw_kernel<1, true>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else if (ns == 1) hipLaunchKernelGGL((head_dw_kernel<1, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else if (ns == 2) hipLaunchKernelGGL((head_dw_kernel<2, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    else hipLaunchKernelGGL((head_dw_kernel<3, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
     LUSH_HIP(hipGetLastError());
     return 0;
 }

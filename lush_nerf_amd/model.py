@@ -188,7 +188,7 @@ class NeRFAll(nn.Module):
         return ret
 
     def _noise(self, ray_batch, N_samples, lindisp):
-        return ops.NoiseMlp.apply(ray_batch.detach(), N_samples, 16, bool(lindisp), self.precision,
+        return ops.NoiseMlp.apply(ray_batch.detach(), N_samples, 16, bool(lindisp), self.precision.noise(),
                                   torch.is_grad_enabled(),
                                   *self.mlp_noise_coarse.tensors())
 

@@ -15,6 +15,23 @@ import torch
 from . import lib
 
 NET_NERF, NET_NOISE = 0, 1
+PLANES_F16 = 17          # plane code of the C ABI: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward only)
+
+
+def nplanes(code: int) -> int:
+    return 1 if code == PLANES_F16 else code
+
+
+def stash_code(pf: int, pb: int) -> int:
+    """What the forward keeps for the backward: an fp16 forward stashes its single fp16 plane (the dW
+    GEMM converts it to bf16 in registers), otherwise the first min(pf, pb) bf16 planes."""
+    return PLANES_F16 if pf == PLANES_F16 else min(pf, pb)
+
+
+def parse_planes(text: str):
+    """'2,1' / 'h,1' -> (fwd code, bwd planes)."""
+    f, b = text.split(",")
+    return (PLANES_F16 if f.strip() in ("h", "17") else int(f)), int(b)
 _NL = {NET_NERF: 8, NET_NOISE: 4}
 N_MLP_TENSORS = {NET_NERF: 24, NET_NOISE: 16}
 
@@ -33,10 +50,15 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 @dataclass
 class Precision:
-    """bf16 planes per MFMA operand: forward / backward.  (2, 2) is the parity mode
-    (render outputs within 1e-4 of the fp32 reference), (1, 1) plain bf16, (3, 3) ~fp32."""
+    """16-bit planes per MFMA operand: forward / backward.  fwd = 2 (two bf16 planes, outputs within
+    5e-7 of fp32) or PLANES_F16 (one fp16 plane, outputs within ~3e-5; the tiny noise MLP then stays on
+    two bf16 planes) satisfy the 1e-4 bound; (1, 1) plain bf16 does not; (3, 3) is ~fp32.  The backward
+    is always bf16 (1 plane = plain bf16, 2 = fp32-equivalent): fp16's range is unsafe for gradients."""
     fwd: int = 2
     bwd: int = 2
+
+    def noise(self) -> "Precision":
+        return Precision(2, self.bwd) if self.fwd == PLANES_F16 else self
 
 
 # ----------------------------------------------------------------------------- MLP plumbing
@@ -75,7 +97,7 @@ TIMER: Optional[KernelTimer] = None
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0):
     """stash_planes: planes kept for the backward (default: all `planes`)."""
     R, S = z.shape
-    sp = (stash_planes or planes) if want_stash else 0     # 0 = inference: only the gamma-row workspace
+    sp = nplanes(stash_planes or planes) if want_stash else 0   # 0 = inference: only the gamma-row workspace
     raw = torch.empty(R * S, 4, dtype=torch.float32, device=rays.device)
     stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, sp, R * S), dtype=torch.uint8,
                         device=rays.device)
@@ -232,7 +254,7 @@ class March(torch.autograd.Function):
         noise_c = _opt(draws.get("noise_c")) if cfg.raw_noise_std > 0 else None
         zc = zgrid(batch, cfg.N_samples, cfg.lindisp, t_rand)
         pk_c = mlp_pack(NET_NERF, pf, coarse)
-        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, min(pf, pb))
+        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb))
         rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, noise_c, cfg)
         outs = [rgb, depth, acc, density]
         saved = dict(zc=zc, raw_c=raw_c, noise_c=noise_c, stash_c=stash_c)
@@ -243,7 +265,7 @@ class March(torch.autograd.Function):
             zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, u)
             same = fine is coarse
             pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
-            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, min(pf, pb))
+            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb))
             rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, noise_f, cfg)
             outs = [rgb1, depth1, acc1, density1]
             saved.update(zf=zf, raw_f=raw_f, noise_f=noise_f, stash_f=stash_f)
@@ -274,7 +296,7 @@ class March(torch.autograd.Function):
         def run(tensors, z, raw, noise, stash, gg):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
             pk = mlp_pack(NET_NERF, pb, tensors)
-            gr, dpts = mlp_backward(NET_NERF, min(pf, pb), pb, tensors, pk, batch, z, draw, stash)
+            gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash)
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays),
                      _stream())
             return gr
@@ -306,7 +328,7 @@ class NoiseMlp(torch.autograd.Function):
         lib.call("lush_zfixed", lib.ptr(batch), R, int(N_samples), int(index), int(lindisp), lib.ptr(z), _stream())
         pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
         need = bool(want_grad) and any(ctx.needs_input_grad)
-        raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, min(precision.fwd, precision.bwd))
+        raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, stash_code(precision.fwd, precision.bwd))
         ctx.batch, ctx.z, ctx.tensors, ctx.stash, ctx.precision = batch, z, tensors, stash, precision
         return raw[:, :3].contiguous()
 
@@ -316,7 +338,7 @@ class NoiseMlp(torch.autograd.Function):
         draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
         draw[:, :3] = g
         pk = mlp_pack(NET_NOISE, pr.bwd, ctx.tensors)
-        grads, _ = mlp_backward(NET_NOISE, min(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash)
+        grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash)
         ctx.stash = None
         o = 2 * _NL[NET_NOISE] + 4   # alpha_linear is dead in NeRF_Noise (helpers:496,505,512): grad None
         grads[o] = None

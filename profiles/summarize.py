@@ -13,7 +13,8 @@ try:
     bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 except Exception as e:
     print("no bench json", e)
-planes = f'{bench.get("config", {}).get("planes_fwd", "?")},{bench.get("config", {}).get("planes_bwd", "?")}'
+_pf, _pb = str(bench.get("config", {}).get("planes_fwd", "?")), str(bench.get("config", {}).get("planes_bwd", "?"))
+planes = ("h" if _pf.startswith("fp16") else _pf.replace("bf16x", "")) + "," + _pb.replace("bf16x", "")
 steps = bench.get("steps", 4) + bench.get("warmup", 2)
 
 GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
@@ -63,7 +64,7 @@ if per:
     lines.append(f"\n## HBM traffic from PMC counters (separate passes; FETCH_SIZE x2 gfx950 correction)\n")
     lines.append("| kernel group | fetch GB/step | write GB/step | total GB/step | algorithmic GB/step |\n|---|---|---|---|---|")
     evals = bench.get("config", {}).get("mlp_evals_per_step", 3932160)
-    pf, pb = (int(x) for x in planes.split(",")) if "?" not in planes else (2, 1)
+    pf, pb = ((1 if planes.split(",")[0] == "h" else int(planes.split(",")[0])), int(planes.split(",")[1])) if "?" not in planes else (2, 1)
     alg = {"mlp_fwd": evals * (min(pf, pb) * 5120 + 16), "mlp_bwd_chain": evals * (pb * 4864 + 336),
            "mlp_bwd_weights": evals * pb * 9984}
     lps = {k: v["launches_per_step"] for k, v in bench.get("kernels", {}).items()}

@@ -9,7 +9,7 @@ from oracle import lush_oracle as O
 
 dev = torch.device("cuda:0")
 R = int(os.environ.get("R", 20480)); S = int(os.environ.get("S", 128))
-modes = [tuple(int(c) for c in m.split(",")) for m in os.environ.get("MODES", "2,2;1,1").split(";")]
+modes = [ops.parse_planes(m) for m in os.environ.get("MODES", "2,2;1,1").split(";")]
 what = os.environ.get("WHAT", "fwd,fwd_nostash,chain,weights").split(",")
 reps = int(os.environ.get("REPS", 3))
 w = synth.all_weights(30, 0)
@@ -35,11 +35,11 @@ for nf, nb in modes:
     pkb = pk if nb == nf else ops.mlp_pack(0, nb, tens)
     res = {}
     if "fwd" in what:
-        res["fwd"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, True, min(nf, nb)))
+        res["fwd"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb)))
     if "fwd_nostash" in what:
         res["fwd_nostash"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, False))
-    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True, min(nf, nb))
-    nf_s = min(nf, nb)
+    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb))
+    nf_s = ops.stash_code(nf, nb)
     import ctypes as C
     dstash = torch.empty(lib.load().lush_mlp_dstash_bytes(0, nb, R * S), dtype=torch.uint8, device=dev)
     grads = [torch.zeros_like(t) for t in tens]

@@ -20,7 +20,7 @@ from oracle import lush_oracle as O
 from tests import util
 
 dev = torch.device("cuda:0")
-E2E_PLANES = tuple(int(c) for c in os.environ.get("LUSH_PLANES", "2,2").split(","))
+E2E_PLANES = ops.parse_planes(os.environ.get("LUSH_PLANES", "2,2"))
 H, W, F = util.H, util.W, util.FOCAL
 RESULTS = []
 
@@ -156,14 +156,14 @@ def t_mlp_fwd():
         with torch.no_grad():
             full = O.nerf_mlp(p, prefix, torch.cat([e, d], -1), 63, 27, D)
         tens = [gpu(t) for t in nerf_tensors(p, prefix, D)]
-        for ns, tol in ((3, 3e-6), (2, 3e-5), (1, 3e-2)):
+        for ns, tol in ((3, 3e-6), (2, 3e-5), (1, 3e-2), (ops.PLANES_F16, 4e-3)):
             pk = ops.mlp_pack(net, ns, tens)
             raw, stash = ops.mlp_forward(net, ns, tens, pk, gpu(batch), gpu(z), True)
             ncmp = 4 if net == ops.NET_NERF else 3
             rep(f"mlp fwd net={net} planes={ns} rgb", raw[:, :3], full[:, :3], tol)
             if net == ops.NET_NERF:
                 rep(f"mlp fwd net={net} planes={ns} sigma", raw[:, 3], full[:, 3], tol)
-            if ns == 3:   # layer-wise stash check localises a wrong layer
+            if ns == 3:   # layer-wise stash check localises a wrong layer (bf16 planes)
                 off = (lib.C.c_longlong * 16)()
                 lib.call("lush_debug_stash_layout", net, ns, R * S, off)
                 Ppad, HW = off[12], off[14]
@@ -205,17 +205,17 @@ def t_mlp_bwd():
                 [f"{n}.{s}" for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear")
                  for s in ("weight", "bias")]
         tens = [gpu(t.detach()) for t in nerf_tensors(p, prefix, D)]
-        for nf, nb, tol in ((3, 3, 2e-5), (2, 2, 2e-4), (2, 1, 3e-2)):
+        for nf, nb, tol in ((3, 3, 2e-5), (2, 2, 2e-4), (2, 1, 3e-2), (ops.PLANES_F16, 1, 3e-2)):
             pk = ops.mlp_pack(net, nf, tens)
-            raw, stash = ops.mlp_forward(net, nf, tens, pk, gpu(batch), gpu(z), True, min(nf, nb))
+            raw, stash = ops.mlp_forward(net, nf, tens, pk, gpu(batch), gpu(z), True, ops.stash_code(nf, nb))
             # reference gradients with the GPU's own ReLU decisions (isolates arithmetic from kink flips)
-            masks = util.stash_masks(net, min(nf, nb), R * S, stash)
+            masks = util.stash_masks(net, ops.nplanes(ops.stash_code(nf, nb)), R * S, stash, f16=(nf == ops.PLANES_F16))
             for v in list(p.values()) + [br]:
                 v.grad = None
             out = util.nerf_mlp_masked(p, prefix, x, D, masks)
             (out * draw).sum().backward(retain_graph=True)
             pkb = pk if nb == nf else ops.mlp_pack(net, nb, tens)
-            grads, dpts = ops.mlp_backward(net, min(nf, nb), nb, tens, pkb, gpu(batch), gpu(z), gpu(draw), stash)
+            grads, dpts = ops.mlp_backward(net, ops.stash_code(nf, nb), nb, tens, pkb, gpu(batch), gpu(z), gpu(draw), stash)
             worst, wname = 0.0, ""
             for n, g in zip(names, grads):
                 ref = p[f"{prefix}.{n}"].grad

@@ -38,11 +38,38 @@ def test_kernel_parity(diag, section):
     assert not bad, f"{len(bad)} of {len(diag.RESULTS)} checks failed: {bad[:8]}"
 
 
+def test_fp16_forward_mode(diag, monkeypatch):
+    """Optional mode (h,1): ONE fp16 plane in the forward.  Render outputs stay inside the 1e-4 bound
+    (measured 2.7e-5) at a third of the MFMA work; the price is gradient noise from ReLU kinks flipped
+    by the larger forward rounding (measured 4e-2..7e-2 vs the reference fixtures, gated at 1e-1) and a
+    looser z_std (sample_pdf conditioning), which is why it is not the bench headline."""
+    monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes("h,1"))
+    diag.RESULTS.clear()
+    diag.t_march_e2e()
+    res = {n: e for n, e, t, ok in diag.RESULTS}
+    for n, e in res.items():
+        if n.endswith("rgb_map") or n.endswith("rgb0") or n.endswith("noise_rgb") or n.endswith("acc_map"):
+            assert e < 1e-4, (n, e)
+        if n.endswith("depth_map"):
+            assert e < 1e-3, (n, e)
+        if n.endswith("z_std"):
+            assert e < 3e-2, (n, e)
+    diag.RESULTS.clear()
+    diag.t_train_e2e()
+    for n, e, t, ok in diag.RESULTS:
+        if "worst grad" in n or n.endswith("grad_rays"):
+            assert e < 1e-1, (n, e)
+        elif "grad-None" in n:
+            assert ok, n
+        else:
+            assert e < 1e-4, (n, e)
+
+
 @pytest.mark.parametrize("planes", ["2,1"])
 def test_headline_mode_end_to_end(diag, planes, monkeypatch):
     """The bench headline mode (2 planes forward, bf16 backward): forward within 1e-4 of the reference
     fixtures, end-to-end gradients inside the same 3e-2 gate as the fp32-equivalent mode."""
-    monkeypatch.setattr(diag, "E2E_PLANES", tuple(int(c) for c in planes.split(",")))
+    monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes(planes))
     for section in ("t_march_e2e", "t_train_e2e"):
         diag.RESULTS.clear()
         getattr(diag, section)()

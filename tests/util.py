@@ -59,14 +59,17 @@ def check_grads(named_grads, fixture, tol, skip_missing=False):
     return worst
 
 
-def stash_planes(stash, off, ns, Ppad, cols):
-    """Decode a [ns][Ppad][cols] bf16-plane array of the forward stash into fp32 (sum of planes)."""
+def stash_planes(stash, off, ns, Ppad, cols, f16=False):
+    """Decode a [ns][Ppad][cols] bf16-plane (or one fp16 plane) array of the forward stash into fp32."""
     sb = stash.cpu().numpy() if isinstance(stash, torch.Tensor) else stash
-    arr = np.frombuffer(sb[off:off + ns * Ppad * cols * 2].tobytes(), dtype=np.uint16)
+    raw = sb[off:off + ns * Ppad * cols * 2].tobytes()
+    if f16:
+        return np.frombuffer(raw, dtype=np.float16).astype(np.float32).reshape(ns, Ppad, cols).sum(0)
+    arr = np.frombuffer(raw, dtype=np.uint16)
     return (arr.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, cols).sum(0)
 
 
-def stash_masks(net, ns, P, stash):
+def stash_masks(net, ns, P, stash, f16=False):
     """ReLU decisions the GPU forward took: [h_0 > 0, ..., h_{NL-1} > 0, hv > 0] as float tensors."""
     import ctypes as C
     from lush_nerf_amd import lib
@@ -74,8 +77,8 @@ def stash_masks(net, ns, P, stash):
     lib.call("lush_debug_stash_layout", net, ns, P, off)
     Ppad, HW, NL = off[12], off[14], off[15]
     sb = stash.cpu().numpy()
-    out = [torch.from_numpy((stash_planes(sb, off[2 + l], ns, Ppad, HW)[:P] > 0).astype(np.float32)) for l in range(NL)]
-    out.append(torch.from_numpy((stash_planes(sb, off[11], ns, Ppad, HW // 2)[:P] > 0).astype(np.float32)))
+    out = [torch.from_numpy((stash_planes(sb, off[2 + l], ns, Ppad, HW, f16)[:P] > 0).astype(np.float32)) for l in range(NL)]
+    out.append(torch.from_numpy((stash_planes(sb, off[11], ns, Ppad, HW // 2, f16)[:P] > 0).astype(np.float32)))
     return out
 
 
