@@ -76,6 +76,13 @@ int lush_pack_rays_fwd(const float* rays, int N, int ndc, float cx, float cy, fl
 int lush_pack_rays_bwd(const float* rays, int N, int ndc, float cx, float cy, const float* dbatch,
                        float* drays, lush_stream_t stream);
 
+/* Device-side ray table: get_rays / get_rays_np
+ * (utils/run_lushnerf_helpers.py:517-539) for N (view, pixel) pairs instead of the pre-materialised
+ * [N_img*H*W, 2, 3] table and its host permutation (run_lushnerf.py:561-589, 610-614).
+ * c2w [V][3][4]; view, px, py [N] int64; rays [N][3][2]. */
+int lush_gen_rays(const float* c2w, const int64_t* view, const int64_t* px, const int64_t* py, int N,
+                  float fx, float fy, float cx, float cy, float* rays, lush_stream_t stream);
+
 /* ----------------------------------------------------------- blur kernel (RBK)
  * View_Embedding + Rigid_Blurring_Kernel.forward trunk/heads,
  * models/lushnerf.py:27-35, 118-148.  The MLP input is the image embedding only,

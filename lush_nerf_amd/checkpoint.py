@@ -1,0 +1,95 @@
+"""Checkpoint interop with the reference's .tar files.
+
+The reference saves ``{'global_step', 'network_state_dict', 'optimizer_state_dict'}`` where the
+network is an ``nn.DataParallel(NeRFAll)`` -- every key carries a ``module.`` prefix and the RBK
+appears under three aliases (run_lushnerf.py:687-694; models/lushnerf.py:184, 219-220) -- and
+reloads with ``smart_load_state_dict`` (utils/run_lushnerf_helpers.py:612-628: strip 7 characters,
+``strict=False``).  The optimizer is ``torch.optim.Adam`` over two parameter groups: everything
+except the noise MLP, then the noise MLP (run_lushnerf.py:359-371).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .model import NeRFAll
+
+
+def reference_state_dict(model: NeRFAll) -> Dict[str, torch.Tensor]:
+    """What ``nn.DataParallel(nerf).state_dict()`` holds in the reference."""
+    return {"module." + k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _param_groups(model: NeRFAll):
+    noise_ids = {id(p) for p in model.mlp_noise_coarse.parameters()}
+    base = [p for p in model.parameters() if id(p) not in noise_ids]
+    return base, list(model.mlp_noise_coarse.parameters())
+
+
+def adam_state_to_reference(trainer) -> dict:
+    """The trainer's flat Adam moments as a ``torch.optim.Adam.state_dict()`` in the reference's group order."""
+    flat = trainer.flat
+    base, noise = _param_groups(trainer.model)
+    seg_of = {}
+    for s, (a, b) in enumerate(flat.segments):
+        seg_of[s] = (a, b)
+    state, idx = {}, 0
+    groups = []
+    for params in (base, noise):
+        ids = []
+        for p in params:
+            off = (p.data_ptr() - flat.param.data_ptr()) // 4
+            seg = next(s for s, (a, b) in seg_of.items() if a <= off < b)
+            step = trainer.steps[seg]
+            if step > 0:            # torch keeps no state for parameters that never received a gradient
+                n = p.numel()
+                state[idx] = {"step": torch.tensor(float(step)),
+                              "exp_avg": trainer.m[off:off + n].view_as(p).detach().clone(),
+                              "exp_avg_sq": trainer.v[off:off + n].view_as(p).detach().clone()}
+            ids.append(idx)
+            idx += 1
+        groups.append({"lr": trainer.lr(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                       "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                       "fused": None, "decoupled_weight_decay": False, "params": ids})
+    return {"state": state, "param_groups": groups}
+
+
+def load_adam_state(trainer, opt_state: dict):
+    """Inverse of adam_state_to_reference (accepts a reference checkpoint's optimizer_state_dict)."""
+    flat = trainer.flat
+    base, noise = _param_groups(trainer.model)
+    params = base + noise
+    seg_steps = [0] * len(flat.segments)
+    for idx, st in opt_state["state"].items():
+        p = params[int(idx)]
+        off = (p.data_ptr() - flat.param.data_ptr()) // 4
+        n = p.numel()
+        trainer.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(trainer.m.device))
+        trainer.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(trainer.v.device))
+        seg = next(s for s, (a, b) in enumerate(flat.segments) if a <= off < b)
+        seg_steps[seg] = max(seg_steps[seg], int(float(st["step"])))
+    trainer.steps = seg_steps
+
+
+def save_checkpoint(path: str, model: NeRFAll, global_step: int, trainer=None):
+    """Write a file the reference's loader (run_lushnerf.py:373-389) accepts."""
+    ck = {"global_step": int(global_step), "network_state_dict": reference_state_dict(model)}
+    ck["optimizer_state_dict"] = adam_state_to_reference(trainer) if trainer is not None else {"state": {}, "param_groups": []}
+    torch.save(ck, path)
+
+
+def load_checkpoint(path: str, model: NeRFAll, trainer=None, map_location="cpu") -> int:
+    """smart_load_state_dict semantics (helpers:612-628): strip the 7-character 'module.' prefix,
+    load non-strictly; returns global_step."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    sd = {k[7:]: v for k, v in ck["network_state_dict"].items()}
+    own = model.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k in own:
+                own[k].copy_(v.to(own[k].device))       # in place: parameters may be views of the flat buffer
+    if trainer is not None and ck.get("optimizer_state_dict", {}).get("state"):
+        load_adam_state(trainer, ck["optimizer_state_dict"])
+        trainer.global_step = int(ck.get("global_step", 0))
+    return int(ck.get("global_step", 0))

@@ -358,6 +358,28 @@ __global__ void pack_rays_bwd_kernel(const float* __restrict__ rays, int N, int 
     for (int i = 0; i < 3; ++i) { out[2 * i] = go[i]; out[2 * i + 1] = gd[i]; }
 }
 
+// ------------------------------------------------------- device-side ray table
+// get_rays / get_rays_np (utils/run_lushnerf_helpers.py:517-539) evaluated for N (view, pixel) pairs:
+// dirs = [(i + 0.5 - cx)/fx, -(j + 0.5 - cy)/fy, -1], rays_d = R dirs (sum over the last axis of
+// dirs[None,:] * c2w[:3,:3]), rays_o = c2w[:3,3].  Replaces the pre-materialised [N_img*H*W, 2, 3] table
+// and its per-epoch host permutation (run_lushnerf.py:561-589, 610-614).
+__global__ void gen_rays_kernel(const float* __restrict__ c2w, const int64_t* __restrict__ view,
+                                const int64_t* __restrict__ px, const int64_t* __restrict__ py, int N, float fx,
+                                float fy, float cx, float cy, float* __restrict__ rays) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* M = c2w + view[n] * 12;                       // [3][4] row-major
+    const float d0 = ((float)px[n] + (0.5f - cx)) / fx;
+    const float d1 = -((float)py[n] + (0.5f - cy)) / fy;
+    const float d2 = -1.f;
+    float* o = rays + (long long)n * 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o[2 * i] = M[i * 4 + 3];
+        o[2 * i + 1] = (d0 * M[i * 4 + 0] + d1 * M[i * 4 + 1]) + d2 * M[i * 4 + 2];
+    }
+}
+
 // ---------------------------------------------------------------- SE(3) warp
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -788,6 +810,14 @@ int lush_pack_rays_fwd(const float* rays, int N, int ndc, float cx, float cy, fl
 int lush_pack_rays_bwd(const float* rays, int N, int ndc, float cx, float cy, const float* dbatch, float* drays,
                        lush_stream_t st) {
     hipLaunchKernelGGL(pack_rays_bwd_kernel, dim3(cdiv(N, 256)), dim3(256), 0, S_(st), rays, N, ndc, cx, cy, dbatch, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_gen_rays(const float* c2w, const int64_t* view, const int64_t* px, const int64_t* py, int N, float fx,
+                  float fy, float cx, float cy, float* rays, lush_stream_t st) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(gen_rays_kernel, dim3(cdiv(N, 256)), dim3(256), 0, S_(st), c2w, view, px, py, N, fx, fy, cx, cy, rays);
     CHECK_LAUNCH();
     return 0;
 }

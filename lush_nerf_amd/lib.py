@@ -74,6 +74,7 @@ _SIGS = {
     "lush_sample_merge": ([_p, _p, _i, _i, _i, _p, _p, _p, _p, _p], _i),
     "lush_pack_rays_fwd": ([_p, _i, _i, _f, _f, _f, _f, _p, _p], _i),
     "lush_pack_rays_bwd": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),
+    "lush_gen_rays": ([_p, _p, _p, _p, _i, _f, _f, _f, _f, _p, _p], _i),
     "lush_rbk_mlp_fwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p], _i),
     "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, C.POINTER(RbkParams), _p, _p], _i),
     "lush_rbk_warp_fwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),

@@ -484,3 +484,15 @@ def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gra
     """torch.optim.Adam semantics on flat fp32 buffers (run_lushnerf.py:368-371)."""
     lib.call("lush_adam", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), param.numel(), float(lr),
              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def gen_rays(c2w, view, px, py, K):
+    """Device-side get_rays for (view, pixel) pairs: c2w [V,3,4], view/px/py [N] -> rays [N,3,2]
+    (utils/run_lushnerf_helpers.py:517-539)."""
+    c2w = _f32(c2w[:, :3, :4])
+    view, px, py = (t.reshape(-1).to(torch.int64).contiguous() for t in (view, px, py))
+    N = view.numel()
+    rays = torch.empty(N, 3, 2, dtype=torch.float32, device=c2w.device)
+    lib.call("lush_gen_rays", lib.ptr(c2w), lib.ptr(view), lib.ptr(px), lib.ptr(py), N, float(K[0][0]), float(K[1][1]),
+             float(K[0][2]), float(K[1][2]), lib.ptr(rays), _stream())
+    return rays

@@ -214,9 +214,29 @@ def case_rbk(seed=6):
          ndc_o=o.numpy(), ndc_d=d.numpy())
 
 
+def case_checkpoint_layout():
+    """Key names / shapes of the reference checkpoint (run_lushnerf.py:687-694) and the Adam parameter-group
+    sizes (:359-371).  Structure only: no weights are stored."""
+    net = build_ref(64, synth.all_weights(NUM_IMG, 1))
+    dp = torch.nn.DataParallel(net, [])
+    sd = dp.state_dict()
+    noise = list(dp.module.mlp_noise_coarse.parameters())
+    ids = set(map(id, noise))
+    base = [p for p in dp.parameters() if id(p) not in ids]
+    opt = torch.optim.Adam([{"params": base}, {"params": noise, "lr": 5e-4}], lr=5e-4)
+    osd = opt.state_dict()
+    save("checkpoint_layout", keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
+         group_sizes=np.array([len(g["params"]) for g in osd["param_groups"]]),
+         group0_numel=np.array([p.numel() for p in base]), group1_numel=np.array([p.numel() for p in noise]))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
+        case_checkpoint_layout()
+        sys.exit(0)
+    case_checkpoint_layout()
     case_sample_pdf()
     case_rbk()
     case_render_rays("rays_c1_train", 64, 32, 0, True, False, 11)

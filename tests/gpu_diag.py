@@ -91,6 +91,24 @@ def t_zgrid_pack():
         rep(f"zgrid S={S} jitter", ops.zgrid(got.detach(), S, False, t_rand.to(dev)), O._stratify(zc, t_rand), 1e-7)
 
 
+def t_gen_rays():
+    n = 500
+    c2w = synth.poses(30, 2)
+    view = (synth.uniform01(n, 3, 1) * 30).astype(np.int64)
+    px = np.floor(synth.uniform01(n, 3, 2) * W).astype(np.int64)
+    py = np.floor(synth.uniform01(n, 3, 3) * H).astype(np.int64)
+    K = [[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]]
+    ro, rd = O.get_rays_np_formula(H, W, F, c2w[view].astype(np.float64), px.astype(np.float64), py.astype(np.float64))
+    got = ops.gen_rays(gpu(c2w), gpu(view), gpu(px), gpu(py), K)
+    rep("gen_rays origins", got[..., 0], ro, 0.0)
+    rep("gen_rays directions", got[..., 1], rd, 2e-7)
+    # the bench generator builds its batches with the same formula on the host
+    b = synth.ray_batch(64, 9)
+    rep("gen_rays vs synth.ray_batch", ops.gen_rays(gpu(synth.poses(30, 9)), gpu(b["images_idx"].reshape(-1)),
+        gpu(np.floor(synth.uniform01(64, 9, synth._stream("batch") + 1) * W).astype(np.int64)),
+        gpu(np.floor(synth.uniform01(64, 9, synth._stream("batch") + 2) * H).astype(np.int64)), K), b["rays"], 2e-7)
+
+
 def t_composite():
     for S, train in ((64, True), (128, True), (32, False)):
         R = 70
@@ -382,7 +400,7 @@ if __name__ == "__main__":
     lib.load()
     print("device:", torch.cuda.get_device_name(0))
     only = sys.argv[1:]
-    for fn in (t_zgrid_pack, t_composite, t_sample, t_mlp_fwd, t_mlp_bwd, t_rbk, t_mix, t_march_e2e, t_train_e2e):
+    for fn in (t_zgrid_pack, t_gen_rays, t_composite, t_sample, t_mlp_fwd, t_mlp_bwd, t_rbk, t_mix, t_march_e2e, t_train_e2e):
         if not only or fn.__name__ in only:
             section(fn)
     bad = [r for r in RESULTS if not r[3]]
