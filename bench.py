@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--n-importance", type=int, default=64)
     ap.add_argument("--planes", type=str, default="2,1", help="planes per MFMA operand fwd,bwd: h = one fp16 plane, 1..3 = bf16 planes")
     ap.add_argument("--also", type=str, default="h,1;2,2", help="second mode timed after the headline (rank 0 reports it under modes); empty to skip")
+    ap.add_argument("--micro-batch", type=int, default=0, help="input rays per forward+backward slice (0 = whole batch); "
+                    "bounds the activation stash for the larger BASELINE configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n-rand", type=int, default=64)
     a = ap.parse_args()
@@ -126,7 +128,7 @@ def main():
     def run_mode(pf, pb, steps, warmup):
         net = make_model(model_args(a.n_importance), dev, ops.Precision(pf, pb))
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, a.n_samples, a.n_importance, kernel_start_iter=0,
-                     allkernel_start_iter=1 << 30, distributed=world > 1)
+                     allkernel_start_iter=1 << 30, distributed=world > 1, micro_batch=a.micro_batch)
         for i in range(warmup):
             tr.step(batches[i % n_batches], i)
         ops.TIMER = ops.KernelTimer()

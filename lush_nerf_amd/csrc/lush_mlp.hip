@@ -380,6 +380,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
 #pragma unroll 1
         for (int l = 1; l < NL; ++l) {
             LUSH_FRESH_LANE();
+#ifdef LUSH_STASH_EARLY
+            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (l - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+#endif
             if (trunk_active) {
                 acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk + l * HW, rb0, HW, h);
                 if (l == N::SKIP)
@@ -388,7 +391,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 seg_gemm<NS, RB, CB, N::KKH, DT>(acc, seg(N::fwd_L(l, true)), N::NRB, rb0, actimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
+#ifndef LUSH_STASH_EARLY
             if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (l - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+#endif
             lds_barrier();
             if (trunk_active) {
 #pragma unroll
@@ -757,38 +762,35 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
     // waves whose whole column range is padding do no MFMA work
     const bool wave_live = (wo * 128 < A.n_out) && (wi * 64 < A.k_in);
     const bool bias_only = !wave_live && do_bias && (wo * 128 < A.n_out);
-    uint4 rz[LPT], rx[LPT];
-    auto gload = [&](long long p0) {
+    // Register staging with TWO tiles in flight when the staging set is small (1 plane: 16 VGPRs per
+    // tile): loads of tile t+2 are issued before the MFMAs of tile t, tile t+1 is written to the other
+    // LDS buffer after them.  One tile in flight per CU pulled only ~3.9 TB/s from HBM.
+    constexpr int SETS = NS == 1 ? 2 : 1;
+    uint4 rz[SETS][LPT], rx[SETS][LPT];
+    auto gload = [&](uint4 (&dz)[LPT], uint4 (&dx)[LPT], long long p0) {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             const int i = tid + j * DW_THREADS2;
             const int c = i & 31, row = (i >> 5) % DW_KT, pl = i / (32 * DW_KT);
-            rz[j] = make_uint4(0, 0, 0, 0);
-            rx[j] = make_uint4(0, 0, 0, 0);
+            dz[j] = make_uint4(0, 0, 0, 0);
+            dx[j] = make_uint4(0, 0, 0, 0);
             if (c * 8 < A.n_out)
-                rz[j] = *reinterpret_cast<const uint4*>(A.Z + pl * A.z_plane + (p0 + row) * A.ldz + c * 8);
+                dz[j] = *reinterpret_cast<const uint4*>(A.Z + pl * A.z_plane + (p0 + row) * A.ldz + c * 8);
             if (c * 8 < A.k_in)
-                rx[j] = *reinterpret_cast<const uint4*>(A.X + pl * A.x_plane + (p0 + row) * A.ldx + A.xcol0 + c * 8);
+                dx[j] = *reinterpret_cast<const uint4*>(A.X + pl * A.x_plane + (p0 + row) * A.ldx + A.xcol0 + c * 8);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const uint4 (&dz)[LPT], const uint4 (&dx)[LPT], int buf) {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             const int i = tid + j * DW_THREADS2;
             const int c = i & 31, row = (i >> 5) % DW_KT, pl = i / (32 * DW_KT);
             char* base = tiles + buf * BUF + pl * PLANE + row * DW_ROW + c * 16;
-            *reinterpret_cast<uint4*>(base) = rz[j];
-            *reinterpret_cast<uint4*>(base + OPER) = rx[j];
+            *reinterpret_cast<uint4*>(base) = dz[j];
+            *reinterpret_cast<uint4*>(base + OPER) = dx[j];
         }
     };
-    if (n_tiles > 0) {
-        gload(p_begin);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) gload(p_begin + (long long)(t + 1) * DW_KT);
+    auto compute = [&](int buf) {
         if (wave_live) {
             const char* zt = tiles + buf * BUF;
             const char* xt = zt + OPER;
@@ -817,8 +819,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
                     }
                 }
             }
-        }
-        else if (bias_only) {   // column range is padding: this wave still owns bias block wi
+        } else if (bias_only) {   // column range is padding: this wave still owns bias block wi
             const char* zt = tiles + buf * BUF;
 #pragma unroll
             for (int ks = 0; ks < DW_KT / 16; ++ks)
@@ -826,8 +827,41 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
                 for (int pl = 0; pl < NS; ++pl)
                     accb = mfma_bf16(tr_frag(zt + pl * PLANE, ks * 16, wo * 128 + wi * 32, lane), ones, accb);
         }
-        if (t + 1 < n_tiles) lstore(buf ^ 1);
-        __syncthreads();
+    };
+    auto tile_p0 = [&](int t) { return p_begin + (long long)t * DW_KT; };
+    if constexpr (SETS == 1) {
+        if (n_tiles > 0) {
+            gload(rz[0], rx[0], tile_p0(0));
+            lstore(rz[0], rx[0], 0);
+        }
+        lds_barrier();   // LDS-only: must not drain the tiles still in flight
+        for (int t = 0; t < n_tiles; ++t) {
+            if (t + 1 < n_tiles) gload(rz[0], rx[0], tile_p0(t + 1));
+            compute(t & 1);
+            if (t + 1 < n_tiles) lstore(rz[0], rx[0], (t & 1) ^ 1);
+            lds_barrier();   // LDS-only: must not drain the tiles still in flight
+        }
+    } else {
+        // tile t lives in LDS buffer t&1; register set s holds tile with (t & 1) == s
+        if (n_tiles > 0) {
+            gload(rz[0], rx[0], tile_p0(0));
+            if (n_tiles > 1) gload(rz[1], rx[1], tile_p0(1));
+            lstore(rz[0], rx[0], 0);
+        }
+        lds_barrier();   // LDS-only: must not drain the tiles still in flight
+        for (int t = 0; t < n_tiles; t += 2) {
+            // even step: set 0 is free (tile t is already in LDS), set 1 holds tile t+1
+            if (t + 2 < n_tiles) gload(rz[0], rx[0], tile_p0(t + 2));
+            compute(0);
+            if (t + 1 < n_tiles) lstore(rz[1], rx[1], 1);
+            lds_barrier();   // LDS-only: must not drain the tiles still in flight
+            if (t + 1 >= n_tiles) break;
+            // odd step: set 1 is free, set 0 holds tile t+2
+            if (t + 3 < n_tiles) gload(rz[1], rx[1], tile_p0(t + 3));
+            compute(1);
+            if (t + 2 < n_tiles) lstore(rz[0], rx[0], 0);
+            lds_barrier();   // LDS-only: must not drain the tiles still in flight
+        }
     }
     const int r = lane & 31, h = lane >> 5;
     if (do_bias && r == 0 && (wave_live || bias_only)) {

@@ -57,7 +57,7 @@ class Trainer:
     def __init__(self, model: NeRFAll, H: int, W: int, focal: float, N_samples: int = 64, N_importance: int = 64,
                  lrate: float = 5e-4, lrate_decay: int = 250, perturb: float = 1., raw_noise_std: float = 1.,
                  kernel_start_iter: int = 0, allkernel_start_iter: int = 0, chunk: int = 1024 * 32,
-                 distributed: bool = False):
+                 distributed: bool = False, micro_batch: int = 0):
         self.model = model
         self.H, self.W = H, W
         self.K = [[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]]
@@ -66,6 +66,11 @@ class Trainer:
         self.lrate, self.lrate_decay = lrate, lrate_decay
         self.kernel_start_iter, self.allkernel_start_iter = kernel_start_iter, allkernel_start_iter
         self.chunk = chunk
+        # micro_batch > 0: forward+backward run per slice of that many INPUT rays and gradients accumulate in
+        # the flat buffer (the loss is a mean over rays, so this is exact up to summation order).  It bounds the
+        # activation stash: BASELINE config 5 (16 384 rays, 128+128) would otherwise hold ~260 GB between
+        # forward and backward.
+        self.micro_batch = micro_batch
         self.distributed = distributed and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.distributed else 1
         base = list(model.mlp_coarse.parameters()) + (list(model.mlp_fine.parameters()) if model.mlp_fine else [])
@@ -89,12 +94,20 @@ class Trainer:
         self.model.train()
         self.flat.grad.zero_()
         force_naive = i < self.kernel_start_iter
-        out = self.model(self.H, self.W, self.K, chunk=self.chunk, rays=batch["rays"],
-                         rays_info={"images_idx": batch["images_idx"]}, retraw=True, force_naive=force_naive,
-                         allkernel=i < self.allkernel_start_iter, kernel_pixel=batch["fq_mask"], draws=draws,
-                         **self.kw)
-        loss = ops.TrainLoss.apply(out[0], out[1], batch["target"])
-        loss.backward()
+        N = batch["rays"].shape[0]
+        mb = self.micro_batch if 0 < self.micro_batch < N else N
+        M = 1 if force_naive else self.model.mlp_rbk.num_motion + 1
+        loss = None
+        for a in range(0, N, mb):
+            b = min(a + mb, N)
+            d = None if draws is None else {k: v[a * M:b * M] for k, v in draws.items()}
+            out = self.model(self.H, self.W, self.K, chunk=self.chunk, rays=batch["rays"][a:b],
+                             rays_info={"images_idx": batch["images_idx"][a:b]}, retraw=True,
+                             force_naive=force_naive, allkernel=i < self.allkernel_start_iter,
+                             kernel_pixel=batch["fq_mask"][a:b], draws=d, **self.kw)
+            part = ops.TrainLoss.apply(out[0], out[1], batch["target"][a:b]) * ((b - a) / N)
+            part.backward()
+            loss = part.detach() if loss is None else loss + part.detach()
         if self.distributed:
             dist.all_reduce(self.flat.grad)          # RCCL sum over xGMI; the 1/world mean is folded into Adam
         lr = self.lr()
@@ -105,4 +118,4 @@ class Trainer:
                 ops.adam_step(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
                               grad_scale=1.0 / self.world)
         self.global_step += 1
-        return loss.detach()
+        return loss
