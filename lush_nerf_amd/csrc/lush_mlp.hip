@@ -884,6 +884,144 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1-plane variant with an LDS-DMA ring.  Ablation of the register-staged kernel above (MFMAs
+// removed: 6.41 vs 6.54 ms) showed it is paced by the global -> VGPR -> LDS path at ~4.1 TB/s with
+// 64 KB in flight per CU.  Here tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPRs, no
+// ds_write) into a 4-stage ring, so 3 tiles (96 KB) are in flight while one is consumed.
+//  * DMA writes LDS linearly (M0 base + lane*16), so rows cannot be padded; the bank-conflict fix for
+//    the transposing reads is an XOR swizzle of the 16-byte chunk index with (row & 3) << 2, applied
+//    to the per-lane SOURCE address and again on the read (cdna_hip_programming.md rule 21).
+//  * Columns beyond the valid width are never written (lanes masked): the ring is zeroed once, and a
+//    given (row, position) is either always or never written, so it stays zero.
+//  * Completion: each wave waits its own DMAs with a counted s_waitcnt vmcnt(4 * younger stages),
+//    then ONE raw s_barrier per tile makes every wave's rows visible; the slot refilled after that
+//    barrier was last read in the previous iteration, which every wave has left.
+constexpr int DMA_STAGES = 4, DMA_KT = 32, DMA_ROWB = 512, DMA_OPER = DMA_KT * DMA_ROWB, DMA_STAGE = 2 * DMA_OPER;
+
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_base /* wave-uniform byte offset */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(lds_base) : "memory");
+}
+
+__device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int k0, int col0, int lane) {
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row = k0 + 8 * (G >> 1) + q;                 // (row + 4) & 3 == row & 3: same swizzle for both reads
+    const int col = col0 + 16 * (G & 1) + 4 * p;
+    const char* a0 = tile + row * DMA_ROWB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * DMA_ROWB));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.v;
+}
+
+template <bool XF16>
+__global__ __launch_bounds__(DW_THREADS2) void dw_gemm_dma_kernel(const DwArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char tiles[];   // [4 stages][Z 32x512 B | X 32x512 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = w >> 2, wi = w & 3;
+    const long long p_begin = (long long)blockIdx.x * A.pts_per_split;
+    long long p_end = p_begin + A.pts_per_split;
+    if (p_end > A.Ppad) p_end = A.Ppad;
+    const int n_tiles = (int)((p_end - p_begin) / DMA_KT);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    const bool do_bias = A.db != nullptr;
+    f32x16 accb;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accb[q] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const bool wave_live = (wo * 128 < A.n_out) && (wi * 64 < A.k_in);
+    const bool bias_only = !wave_live && do_bias && (wo * 128 < A.n_out);
+    for (int i = tid; i < DMA_STAGES * DMA_STAGE / 16; i += DW_THREADS2)
+        reinterpret_cast<uint4*>(tiles)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)tiles;
+    // this wave's 4 DMA instructions per stage: j = 4w + i; j < 16 -> Z rows (2j, 2j+1), else X rows
+    auto issue = [&](int t) {
+        const long long p0 = p_begin + (long long)t * DMA_KT;
+        const unsigned stage = lds0 + (unsigned)((t % DMA_STAGES) * DMA_STAGE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = w * 4 + i;
+            const int op = j >> 4, rp = j & 15;
+            const int row = 2 * rp + (lane >> 5);
+            const int gch = (lane & 31) ^ ((row & 3) << 2);            // source chunk that belongs at this position
+            const int ncols = op ? A.k_in : A.n_out;
+            const __bf16* src = op ? A.X + (p0 + row) * A.ldx + A.xcol0 + gch * 8 : A.Z + (p0 + row) * A.ldz + gch * 8;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)(op * DMA_OPER + 2 * rp * DMA_ROWB));
+            if (gch * 8 < ncols) dma16(src, dst);
+        }
+    };
+    for (int t = 0; t < DMA_STAGES - 1 && t < n_tiles; ++t) issue(t);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int younger = n_tiles - 1 - t < DMA_STAGES - 2 ? n_tiles - 1 - t : DMA_STAGES - 2;   // stages issued after tile t
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + DMA_STAGES - 1 < n_tiles) issue(t + DMA_STAGES - 1);
+        const char* zt = tiles + (t % DMA_STAGES) * DMA_STAGE;
+        const char* xt = zt + DMA_OPER;
+        if (wave_live) {
+#pragma unroll
+            for (int ks = 0; ks < DMA_KT / 16; ++ks) {
+                bf16x8 a[4][1], b[2][1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u][0] = tr_frag_sw(zt, ks * 16, wo * 128 + u * 32, lane);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    b[u][0] = tr_frag_sw(xt, ks * 16, wi * 64 + u * 32, lane);
+                    if constexpr (XF16) b[u][0] = f16_frag_to_bf16(b[u][0]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) acc[u][v] = mfma_bf16(a[u][0], b[v][0], acc[u][v]);
+                if (do_bias) {
+                    const bf16x8 sel = wi == 0 ? a[0][0] : (wi == 1 ? a[1][0] : (wi == 2 ? a[2][0] : a[3][0]));
+                    accb = mfma_bf16(sel, ones, accb);
+                }
+            }
+        } else if (bias_only) {
+#pragma unroll
+            for (int ks = 0; ks < DMA_KT / 16; ++ks)
+                accb = mfma_bf16(tr_frag_sw(zt, ks * 16, wo * 128 + wi * 32, lane), ones, accb);
+        }
+    }
+    const int r = lane & 31, h = lane >> 5;
+    if (do_bias && r == 0 && (wave_live || bias_only)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int o = wo * 128 + wi * 32 + acc_row(q, h);
+            if (o < A.n_out) atomicAdd(A.db + o, accb[q]);
+        }
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = wo * 128 + u * 32 + acc_row(q, h);
+                const int i = wi * 64 + v * 32 + r;
+                if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[u][v][q]);
+            }
+}
+
 // Heads whose dZ is the fp32 d_raw: rgb_linear (X = hv) and alpha_linear (X = h_{NL-1}).
 // Thread (c, rr): 16-byte column chunk c of [hv | h_last], every ROWS-th point; fp32 atomics at the end.
 template <int NS, bool XF16>
@@ -1089,8 +1227,19 @@ static int launch_dw_t(const DwArgs& a, int splits, hipStream_t s) {
     LUSH_HIP(hipGetLastError());
     return 0;
 }
+template <bool XF16>
+static int launch_dw_dma(const DwArgs& a, int splits, hipStream_t s) {
+    const size_t lds = (size_t)DMA_STAGES * DMA_STAGE;
+    auto k = dw_gemm_dma_kernel<XF16>;
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
     if (a.n_out > DW_T || a.k_in > DW_T) return set_error("launch_dw: layer wider than 256");
+    static const bool no_dma = getenv("LUSH_DW_NODMA") != nullptr;
+    if (ns == 1 && !no_dma) return a.x_f16 ? launch_dw_dma<true>(a, splits, s) : launch_dw_dma<false>(a, splits, s);
     if (a.x_f16) {
         if (ns != 1) return set_error("launch_dw: an fp16 stash has one plane");
         return launch_dw_t<1, true>(a, splits, s);
