@@ -166,8 +166,10 @@ __device__ __forceinline__ void acc_bias(f32x16 (&acc)[RB][CB], const float* __r
         }
 }
 
-// Mask words: one 64-bit ballot per (32-point column block, mask layer, row-block, q); the
-// column block is global (tile*CB + cb) so kernels with different tile sizes agree.
+// ReLU decisions: per (32-point column block, mask layer, row-block) one 128-byte record = a 16-bit
+// word per lane, bit q = "accumulator register q of this lane was > 0".  The backward (same lane <->
+// (point, rows) mapping) applies it with v_bfe_i32 + v_and per element.  The column block is global
+// (tile*CB + cb) so kernels with different tile sizes agree.  (Index is in 8-byte units.)
 __device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int nrb, int rb, int CB, int cb) {
     return ((((long long)tile * CB + cb) * n_ml + ml) * nrb + rb) * 16;
 }
@@ -180,13 +182,10 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
                                             int stash_ld, long long gpt, unsigned long long* mask_words) {
     const int h = lane >> 5;
     if (RELU && mask_words != nullptr) {
-        unsigned long long mine = 0;
+        unsigned bits = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const unsigned long long m = __ballot(acc[q] > 0.f);
-            if (lane == q) mine = m;
-        }
-        if (lane < 16) mask_words[lane] = mine;
+        for (int q = 0; q < 16; ++q) bits |= (acc[q] > 0.f ? 1u : 0u) << q;
+        reinterpret_cast<unsigned short*>(mask_words)[lane] = (unsigned short)bits;
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -238,13 +237,10 @@ __device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int pl
                                                    long long stash_plane, int stash_ld, long long gpt,
                                                    const unsigned long long* mask_words) {
     if (mask_words != nullptr) {
-        const unsigned long long mine = lane < 16 ? mask_words[lane] : 0ull;
+        const int bits = reinterpret_cast<const unsigned short*>(mask_words)[lane];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)mine, q);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mine >> 32), q);
-            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-            if (!((m >> lane) & 1ull)) acc[q] = 0.f;
+            if (!((bits >> q) & 1)) acc[q] = 0.f;
         }
     }
     store_block<NS, false>(acc, img, plane_bytes, row_bytes, pt, rb, lane, stash, stash_plane, stash_ld, gpt,

@@ -131,11 +131,15 @@ print("rank", rank, "ok")
 
 
 def test_data_parallel_allreduce_two_ranks_gloo(tmp_path):
+    import socket
     script = tmp_path / "dp.py"
     script.write_text(_DIST_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    with socket.socket() as sk:                      # a free rendezvous port (a fixed one can sit in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29577", str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
