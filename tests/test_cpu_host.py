@@ -126,7 +126,7 @@ dist.all_gather(chk, fp.param)
 assert all(torch.equal(chk[0], c) for c in chk), "replicas diverged"
 assert not torch.equal(gathered[0], gathered[1]), "ranks must see different rays"
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(sys.argv[2], f"rank{rank}.ok"), "w").write("ok")     # stdout of the two ranks interleaves
 '''
 
 
@@ -139,10 +139,10 @@ def test_data_parallel_allreduce_two_ranks_gloo(tmp_path):
         port = str(sk.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT, str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-1000:]
 
 
 def _small_trainer(seed=0):
