@@ -66,28 +66,33 @@ void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP;
     T.n = 0;
     blocks = 0;
+    int perm = 0, base = 0;
     auto add = [&](const float* src, int sr, int sk, int rows, int cols, int nrb, int kk, int dst) {
         PackJob& j = T.j[T.n++];
-        j.src = src; j.sr = sr; j.sk = sk; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk;
-        j.dst_entry = dst; j.first_block = blocks;
+        j.src = src; j.sr = sr; j.sk = sk; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk; j.perm = perm;
+        j.dst_entry = base + dst; j.first_block = blocks;
         blocks += nrb * kk;
     };
     const int XV = PE_X_VALID, DV = PE_D_VALID;
-    // forward
-    add(p->w[0], XV, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(0, false));
-    for (int l = 1; l < NL; ++l) {
-        if (l == SK) {
-            add(p->w[l], XV + HW, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(l, false));
-            add(p->w[l] + XV, XV + HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_L(l, true));
-        } else {
-            add(p->w[l], HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_L(l, true));
+    // forward: natural rows for mlp_fwd_kernel, then the row-permuted copy for the chain kernel
+    for (int copy = 0; copy < 2; ++copy) {
+        perm = copy; base = copy ? N::fwd2_base : 0;
+        add(p->w[0], XV, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(0, false));
+        for (int l = 1; l < NL; ++l) {
+            if (l == SK) {
+                add(p->w[l], XV + HW, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(l, false));
+                add(p->w[l] + XV, XV + HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_L(l, true));
+            } else {
+                add(p->w[l], HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_L(l, true));
+            }
         }
+        add(p->w_feat, HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_FEAT);
+        add(p->w_alpha, HW, 1, 1, HW, 1, N::KKH, N::fwd_ALPHA);
+        add(p->w_views, HW + DV, 1, HV, HW, N::NRBV, N::KKH, N::fwd_VA);
+        add(p->w_views + HW, HW + DV, 1, HV, DV, N::NRBV, N::KKD, N::fwd_VB);
+        add(p->w_rgb, HV, 1, 3, HV, 1, N::KKV, N::fwd_RGB);
     }
-    add(p->w_feat, HW, 1, HW, HW, N::NRB, N::KKH, N::fwd_FEAT);
-    add(p->w_alpha, HW, 1, 1, HW, 1, N::KKH, N::fwd_ALPHA);
-    add(p->w_views, HW + DV, 1, HV, HW, N::NRBV, N::KKH, N::fwd_VA);
-    add(p->w_views + HW, HW + DV, 1, HV, DV, N::NRBV, N::KKD, N::fwd_VB);
-    add(p->w_rgb, HV, 1, 3, HV, 1, N::KKV, N::fwd_RGB);
+    perm = 0; base = 0;
     // transposed: element (row, k) = W[k][c0 + row]
     add(p->w_views, 1, HW + DV, HW, HV, N::NRB, N::KKV, N::bwd_VAT);
     add(p->w_views + HW, 1, HW + DV, DV, HV, 1, N::KKV, N::bwd_VBT);
@@ -166,7 +171,8 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     const long long P = (long long)R * S;
     if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
     const StashLayout L = stash_layout(n, nplanes(planes), stash_planes, P);
-    const int mt = planes == PLANES_F16 ? 64 : mlp_fwd_tile(planes);
+    const bool chain = mlp_fwd_chain_enabled(planes);
+    const int mt = chain ? 128 : (planes == PLANES_F16 ? 64 : mlp_fwd_tile(planes));
     MlpFwdArgs a{};
     a.stash_planes = stash_planes;
     a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / mt);
@@ -182,6 +188,7 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     a.feat = (__bf16*)(b + L.feat);
     a.hv = (__bf16*)(b + L.hv);
     a.plane_pe = L.Ppad * PE_ROW; a.plane_h = L.Ppad * n.HW; a.plane_hv = L.Ppad * n.HV;
+    if (chain) return launch_mlp_chain_fwd(net, planes, a, (hipStream_t)stream);
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
 }

@@ -54,7 +54,12 @@ struct NetT {
         return off;
     }
     static constexpr int bwd_END = bwd_LT(0, false) + KKH * 2;
-    static constexpr int total_entries = bwd_END;
+    // ---- second copy of the forward segments for the register-resident chain kernel
+    // (lush_mlp_chain.hip): same order and offsets, output rows permuted inside each 32-row block
+    // (chain_row()) so that a lane's 16 accumulators are the 2 x 8 consecutive features it supplies
+    // as the next layer's B operand ----
+    static constexpr int fwd2_base = bwd_END;
+    static constexpr int total_entries = bwd_END + fwd_END;
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
 
@@ -76,17 +81,25 @@ typedef NetT<128, 4, -1> NetNoise;
 // One pack job: fill `n_entries` = KK*NRB fragments of a segment from an fp32
 // matrix.  Element (row, k) of the segment = src[row*sr + k*sk] if row < rows
 // and k < cols, else 0.
+// MFMA row rho (0..31) of a permuted block holds feature chain_row(rho): the lane (col, h) that owns
+// rows (q&3) + 8*(q>>2) + 4h, q = 0..15, then owns features 16*(q>>3) + 8h + (q&7).
+__host__ __device__ constexpr int chain_row(int rho) {
+    const int h = (rho >> 2) & 1, q = (rho & 3) + 4 * (rho >> 3);
+    return 16 * (q >> 3) + 8 * h + (q & 7);
+}
+
 struct PackJob {
     const float* src;
     int sr, sk;
     int rows, cols;
     int nrb, kk;
+    int perm;            // 1: rows of each 32-row block permuted by chain_row()
     int dst_entry;       // first entry in the packed buffer
     int first_block;     // prefix sum of (nrb*kk) over previous jobs
 };
 
 struct PackTable {
-    PackJob j[32];
+    PackJob j[48];
     int n;
 };
 

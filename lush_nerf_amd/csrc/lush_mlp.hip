@@ -22,16 +22,13 @@
 // NS=2 ~2^-17 relative (parity mode), NS=3 ~fp32.  Accumulation is fp32.
 #include "lush_common.h"
 #include "lush_mlp.h"
+#include "lush_mlp_dev.h"
 
 namespace lush {
 
 // fused MLP kernels take the wave count NW as a template parameter (8 = 2 waves per SIMD with a
 // 256-register budget, 4 = 1 wave per SIMD with 512 registers for the 128-point tile)
 constexpr int DW_THREADS = 256;           // weight-gradient GEMM / reductions: 4 waves as 2x2
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), which
-// would stall every layer on the acknowledgement of the in-flight stash stores.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ----------------------------------------------------------------------------
 // weight packing
@@ -45,7 +42,7 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __r
     const int e = b - J.first_block;          // entry inside the segment = kk*nrb + rb
     const int kk = e / J.nrb, rb = e % J.nrb;
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int row = rb * 32 + r;
+    const int row = rb * 32 + (J.perm ? chain_row(r) : r);
     __bf16 out[NS][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -124,7 +121,14 @@ __device__ __forceinline__ void seg_gemm(f32x16 (&acc)[RB][CB], const bf16x8* __
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) acc[i][cb] = mfma_planes<NS, DT>(as[i], bs[cb], acc[i][cb]);
+            for (int cb = 0; cb < CB; ++cb) {
+#ifdef LUSH_ABL_NOMFMA   // timing ablation only (wrong results): keep the operand loads, drop the MFMAs
+#pragma unroll
+                for (int p = 0; p < NS; ++p) asm volatile("" ::"v"(as[i][p]), "v"(bs[cb][p]));
+#else
+                acc[i][cb] = mfma_planes<NS, DT>(as[i], bs[cb], acc[i][cb]);
+#endif
+            }
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s)
@@ -166,14 +170,6 @@ __device__ __forceinline__ void acc_bias(f32x16 (&acc)[RB][CB], const float* __r
         }
 }
 
-// ReLU decisions: per (32-point column block, mask layer, row-block) one 128-byte record = a 16-bit
-// word per lane, bit q = "accumulator register q of this lane was > 0".  The backward (same lane <->
-// (point, rows) mapping) applies it with v_bfe_i32 + v_and per element.  The column block is global
-// (tile*CB + cb) so kernels with different tile sizes agree.  (Index is in 8-byte units.)
-__device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int nrb, int rb, int CB, int cb) {
-    return ((((long long)tile * CB + cb) * n_ml + ml) * nrb + rb) * 16;
-}
-
 // Write one 32x32 accumulator block as NS bf16 planes into the LDS image
 // [pt][feature] (+ optionally the global stash and the ReLU sign bits).
 template <int NS, bool RELU, int DT = DT_BF16>
@@ -181,6 +177,10 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
                                             int pt, int rb, int lane, __bf16* stash, long long stash_plane,
                                             int stash_ld, long long gpt, unsigned long long* mask_words) {
     const int h = lane >> 5;
+#ifdef LUSH_ABL_NOEPI   // timing ablation only (wrong results)
+    asm volatile("" ::"v"(acc));
+    return;
+#endif
     if (RELU && mask_words != nullptr) {
         unsigned bits = 0;
 #pragma unroll
@@ -230,6 +230,33 @@ __device__ __noinline__ void copy_out(const char* img, int plane_bytes, int row_
     }
 }
 
+// Inlined form with static shapes: every LDS read of a plane is issued before its stores, nothing
+// waits for the stores (a non-inlined callee drains vmcnt at entry and return, i.e. pays the full
+// write-acknowledge latency once per layer).
+template <int MT, int NCOLS, int NTHREADS>
+__device__ __forceinline__ void copy_out_fast(const char* img, int plane_bytes, int row_bytes, __bf16* stash,
+                                              long long stash_plane, long long pt0, int tid_in, int planes) {
+    constexpr int CPR = NCOLS / 8;
+    constexpr int PER = MT * CPR / NTHREADS;
+    static_assert(MT * CPR % NTHREADS == 0, "copy_out_fast: ragged tile");
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    int tid = tid_in;
+    asm volatile("" : "+v"(tid));
+    for (int p = 0; p < planes; ++p) {
+        u32x4 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * NTHREADS, c = i % CPR, pt = i / CPR;
+            v[j] = *reinterpret_cast<const u32x4*>(img + p * plane_bytes + swz(pt, c, row_bytes));
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * NTHREADS, c = i % CPR, pt = i / CPR;
+            __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(stash + p * stash_plane + (pt0 + pt) * NCOLS + c * 8));
+        }
+    }
+}
+
 // Same, applying stored ReLU sign bits (backward) instead of computing them.
 template <int NS>
 __device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int plane_bytes, int row_bytes,
@@ -245,65 +272,6 @@ __device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int pl
     }
     store_block<NS, false>(acc, img, plane_bytes, row_bytes, pt, rb, lane, stash, stash_plane, stash_ld, gpt,
                            nullptr);
-}
-
-// ----------------------------------------------------------------------------
-// positional encoding of one tile into the PE image
-// ----------------------------------------------------------------------------
-template <int NS, int DT>
-__device__ __forceinline__ void pe_put(char* img, int plane_bytes, int row_bytes, int pt, int col, float v) {
-    __bf16 p[NS];
-    split_planes<NS, DT>(v, p);
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-        *reinterpret_cast<__bf16*>(img + s * plane_bytes + swz(pt, col >> 3, row_bytes) + (col & 7) * 2) = p[s];
-}
-
-// Point position exactly as the reference forms it: o + d*z, two roundings,
-// no FMA (models/lushnerf.py:414, 525).
-__device__ __forceinline__ void point_of(const float* __restrict__ rays, const float* __restrict__ z,
-                                         int S, long long gpt, float (&x)[3], float (&d)[3]) {
-    const long long ray = gpt / S;
-    const float zz = z[gpt];
-    const float* rr = rays + ray * 11;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        x[i] = __fadd_rn(rr[i], __fmul_rn(rr[3 + i], zz));
-        d[i] = rr[8 + i];
-    }
-}
-
-// (not inlined on purpose: the inlined sincosf bodies otherwise leave dozens of loop-invariant
-// values live across the MFMA loops of the whole tile)
-template <int NS, int MT, int NTHREADS, int DT>
-__device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
-                                        int S, int P, long long tile_pt0, int tid) {
-    constexpr int PARTS = NTHREADS / MT;
-    const int pt = tid % MT, part = tid / MT;
-    const long long gpt = tile_pt0 + pt;
-    float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-    if (gpt < P) point_of(rays, z, S, gpt, x, d);
-    // units: 0..L_X-1 = frequency k of x; L_X..L_X+L_D-1 = frequency k of d; raw copies go with unit 0 / L_X
-    for (int u = part; u < L_X + L_D; u += PARTS) {
-        const bool isd = u >= L_X;
-        const int k = isd ? u - L_X : u;
-        const int base = isd ? PE_X : 0;
-        const float f = (float)(1 << k);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float v = isd ? d[i] : x[i];
-            if (k == 0) pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + i, v);
-            float s, c;
-            sincosf(v * f, &s, &c);
-            pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + i, s);
-            pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + 3 + i, c);
-        }
-    }
-    if (part == PARTS - 1) {   // zero padding columns that the K loops do read
-        pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, PE_X_VALID, 0.f);
-#pragma unroll
-        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, c, 0.f);
-    }
 }
 
 // Re-derive lane / r / h from an opaque copy of the lane id at the top of every phase: everything
@@ -377,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
         for (int l = 1; l < NL; ++l) {
             LUSH_FRESH_LANE();
 #ifdef LUSH_STASH_EARLY
-            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (l - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+            if (stash_on) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.h0 + (l - 1) * A.h_stride, A.plane_h, pt0, tid, A.stash_planes);
 #endif
             if (trunk_active) {
                 acc_bias<RB, CB>(acc, f32 + N::f32_b_trunk + l * HW, rb0, HW, h);
@@ -388,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                                              lane);
             }
 #ifndef LUSH_STASH_EARLY
-            if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (l - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+            if (stash_on) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.h0 + (l - 1) * A.h_stride, A.plane_h, pt0, tid, A.stash_planes);
 #endif
             lds_barrier();
             if (trunk_active) {
@@ -418,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 for (int cb = 0; cb < CB; ++cb) alphabuf[cb * 32 + r] = aa[0][cb][0];
             }
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.h0 + (NL - 1) * A.h_stride, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+        if (stash_on) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.h0 + (NL - 1) * A.h_stride, A.plane_h, pt0, tid, A.stash_planes);
         lds_barrier();
         if (trunk_active) {
 #pragma unroll
@@ -442,7 +410,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             seg_gemm<NS, RBV, CB, N::KKD, DT>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HW, A.feat, A.plane_h, HW, pt0, tid, NTHREADS, A.stash_planes);
+        if (stash_on) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.feat, A.plane_h, pt0, tid, A.stash_planes);
         lds_barrier();
         if (views_active) {
 #pragma unroll
@@ -476,7 +444,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
                 }
             }
         }
-        if (stash_on) copy_out<NS, MT>(actimg, ACT_PLANE, ACT_ROW, HV, A.hv, A.plane_hv, HV, pt0, tid, NTHREADS, A.stash_planes);
+        if (stash_on) copy_out_fast<MT, HV, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.hv, A.plane_hv, pt0, tid, A.stash_planes);
         lds_barrier();
     }
 }
@@ -574,7 +542,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
             seg_gemm<NS, 1, CB, N::KKV>(ad, seg(N::bwd_VBT), 1, 0, dimg, ACT_PLANE, ACT_ROW, 0, lane);
             dpe_add<CB>(dpe, ad, 0, PE_X, lane, false);
         }
-        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HV, A.dzv, A.plane_hv, HV, pt0, tid, NTHREADS);
+        copy_out_fast<MT, HV, NTHREADS>(dimg, ACT_PLANE, ACT_ROW, A.dzv, A.plane_hv, pt0, tid, NS);
         lds_barrier();
         if (trunk_active) {
 #pragma unroll
@@ -603,7 +571,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
                     }
             }
         }
-        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dfeat, A.plane_h, HW, pt0, tid, NTHREADS);
+        copy_out_fast<MT, HW, NTHREADS>(dimg, ACT_PLANE, ACT_ROW, A.dfeat, A.plane_h, pt0, tid, NS);
         lds_barrier();
         if (trunk_active) {
 #pragma unroll
@@ -630,7 +598,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
                 seg_gemm<NS, RB, CB, N::KKH>(acc, seg(N::bwd_LT(l, true)), N::NRB, rb0, dimg, ACT_PLANE, ACT_ROW, 0,
                                              lane);
             }
-            copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz0 + l * A.dz_stride, A.plane_h, HW, pt0, tid, NTHREADS);
+            copy_out_fast<MT, HW, NTHREADS>(dimg, ACT_PLANE, ACT_ROW, A.dz0 + l * A.dz_stride, A.plane_h, pt0, tid, NS);
             lds_barrier();
             if (trunk_active) {
 #pragma unroll
@@ -650,7 +618,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
             seg_gemm<NS, 1, CB, N::KKH>(ap, seg(N::bwd_LT(0, false)), 2, w, dimg, ACT_PLANE, ACT_ROW, 0, lane);
             dpe_add<CB>(dpe, ap, w, 0, lane, N::SKIP >= 0);
         }
-        copy_out<NS, MT>(dimg, ACT_PLANE, ACT_ROW, HW, A.dz0, A.plane_h, HW, pt0, tid, NTHREADS);
+        copy_out_fast<MT, HW, NTHREADS>(dimg, ACT_PLANE, ACT_ROW, A.dz0, A.plane_h, pt0, tid, NS);
         lds_barrier();
         // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos) ----
         {
@@ -894,12 +862,6 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
 //    then ONE raw s_barrier per tile makes every wave's rows visible; the slot refilled after that
 //    barrier was last read in the previous iteration, which every wave has left.
 constexpr int DMA_STAGES = 4, DMA_KT = 32, DMA_ROWB = 512, DMA_OPER = DMA_KT * DMA_ROWB, DMA_STAGE = 2 * DMA_OPER;
-
-__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_base /* wave-uniform byte offset */) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gptr), "s"(lds_base) : "memory");
-}
 
 __device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int k0, int col0, int lane) {
     const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;

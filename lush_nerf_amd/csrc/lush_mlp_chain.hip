@@ -1,0 +1,576 @@
+// lush-march: register-resident forward chain of the NeRF MLPs for gfx950 (MI355X).
+//
+// Same function as mlp_fwd_kernel (lush_mlp.hip; utils/run_lushnerf_helpers.py:334-344, 394-423,
+// 483-512 and NeRFAll.mlpforward, models/lushnerf.py:234-266) with the operand roles of the on-chip
+// memories swapped:
+//
+//   * a wave owns 32 points for the whole network.  Their activations never leave its registers: the
+//     32x32 MFMA accumulator of a layer (rows = features, columns = points) is turned into bf16
+//     planes in place and IS the B operand of the next layer.  This works because the contraction
+//     index may be permuted freely: the weights are packed with the rows of every 32-row block
+//     permuted by chain_row() (lush_mlp.h), so that the 16 accumulators of a lane are the 2 x 8
+//     consecutive features that lane supplies for two 16-wide k-blocks.  No activation image in LDS,
+//     no ds_write epilogue, no barrier between layers.
+//   * the WEIGHTS are the shared operand: one stream of 1-KiB A fragments per network, in consumption
+//     order, moved L2 -> LDS by LDS-DMA into a ring of CH_S slots (one k-block of all row blocks per
+//     slot) and read by the 4 waves of the workgroup.  128 points share every weight byte: a quarter
+//     of the L2 -> CU traffic per point of the 64-point/8-wave kernel, which was co-limiting there
+//     (weights streamed at ~45 B/clk/CU against 64 peak while the MFMAs waited).
+//
+// One wave per SIMD, 512 registers: 128 accumulators + 128 activation-plane registers + A fragments.
+// Synchronisation: one raw s_barrier per stream position ("mid-step"), between the two halves of the
+// position's MFMAs: it publishes the DMA of the NEXT position (each wave first waits for its own
+// pieces with a counted s_waitcnt vmcnt) and frees the slot of the CURRENT one (its second-half
+// fragments are already in registers), which is refilled at once with position +CH_S.
+#include "lush_common.h"
+#include "lush_mlp.h"
+#include "lush_mlp_dev.h"
+#include "lush_host.h"
+
+#include <cstdlib>
+#include <utility>
+
+namespace lush {
+
+constexpr int CH_S = 4;                       // ring slots = prefetch distance in stream positions
+constexpr int CH_MT = 128, CH_NW = 4, CH_NT = 256;
+enum { B_REG = 0, B_PEX = 1, B_PED = 2 };     // where a phase takes its B operand from
+
+// Stream schedule of one network.  A "position" is what one ring slot holds: G consecutive k-blocks of
+// all row blocks of a segment, G chosen so that every position is a multiple of 4 one-KiB pieces
+// (each wave issues the same number of DMAs per position, so vmcnt immediates are static).
+// Trunk positions (L0 .. L{NL-1}, FEAT) all have the same shape and sit at p * SLOT in the stream;
+// the "tail" list is FEAT | ALPHA | VA | VB | RGB | first CH_S positions of the next tile.
+template <class N, int NS, bool HAS_ALPHA>
+struct ChSched {
+    static constexpr int grp(int nrb) { return nrb * NS >= 4 ? 1 : 4 / (nrb * NS); }
+    static constexpr int ENTRY = NS * 1024;
+    static constexpr int TRUNK_PIECES = N::NRB * NS;
+    static constexpr int SLOT = TRUNK_PIECES * 1024;
+    static constexpr int PT = N::KKX + (N::NL - 1) * N::KKH + (N::SKIP > 0 ? N::KKX : 0);
+    static constexpr int G_A = grp(1), G_V = grp(N::NRBV), G_R = grp(1);
+    static constexpr int NP_F = N::KKH;
+    static constexpr int NP_A = HAS_ALPHA ? N::KKH / G_A : 0;
+    static constexpr int NP_VA = N::KKH / G_V, NP_VB = N::KKD / G_V, NP_R = N::KKV / G_R;
+    static constexpr int T_A = NP_F, T_VA = T_A + NP_A, T_VB = T_VA + NP_VA, T_R = T_VB + NP_VB, T_END = T_R + NP_R;
+    static_assert(N::fwd_FEAT == PT * N::NRB, "FEAT must follow the trunk in the stream");
+    static_assert(TRUNK_PIECES % 4 == 0 && N::KKH % G_A == 0 && N::KKH % G_V == 0 && N::KKD % G_V == 0 && N::KKV % G_R == 0,
+                  "stream positions must be whole multiples of 4 pieces");
+    static constexpr int tail_pieces(int t) {
+        if (t < T_A) return TRUNK_PIECES;
+        if (t < T_VA) return NS * G_A;
+        if (t < T_R) return N::NRBV * NS * G_V;
+        if (t < T_END) return NS * G_R;
+        return TRUNK_PIECES;
+    }
+    static constexpr unsigned tail_off(int t) {        // bytes from the start of the stream
+        if (t < T_A) return (unsigned)(PT + t) * SLOT;
+        if (t < T_VA) return (unsigned)N::fwd_ALPHA * ENTRY + (unsigned)(t - T_A) * G_A * ENTRY;
+        if (t < T_VB) return (unsigned)N::fwd_VA * ENTRY + (unsigned)(t - T_VA) * (N::NRBV * G_V) * ENTRY;
+        if (t < T_R) return (unsigned)N::fwd_VB * ENTRY + (unsigned)(t - T_VB) * (N::NRBV * G_V) * ENTRY;
+        if (t < T_END) return (unsigned)N::fwd_RGB * ENTRY + (unsigned)(t - T_R) * G_R * ENTRY;
+        return (unsigned)(t - T_END) * SLOT;
+    }
+    // vmcnt that means "my pieces of position t+1 have landed" at the mid-step of tail position t: the
+    // DMAs of t+2 .. t+CH_S-1 are younger.  (Other vector-memory operations issued since -- stash and
+    // mask stores -- only make the true count larger, i.e. the wait conservative.)
+    static constexpr int tail_wait(int t) {
+        int n = 0;
+        for (int j = 2; j < CH_S; ++j) n += tail_pieces(t + j) / 4;
+        return n;
+    }
+    static constexpr int trunk_wait = (CH_S - 2) * TRUNK_PIECES / 4;
+};
+
+template <int N_>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+struct ChCtx {
+    const char* ring;      // LDS ring (generic pointer, for the fragment reads)
+    unsigned ring_lds;     // its LDS byte address (DMA destination)
+    const char* gbase;     // stream base (wave-uniform)
+    int cslot;             // slot of the position being consumed
+    unsigned trunk_pos;    // index of the trunk position being consumed
+    int w, lane;
+};
+
+template <int PIECES, int SLOT>
+__device__ __forceinline__ void ch_issue(const ChCtx& cx, unsigned off, int slot) {
+    const unsigned dst = cx.ring_lds + (unsigned)slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < PIECES / 4; ++i) {
+        const int j = cx.w + 4 * i;
+        dma16s(cx.gbase + (off + (unsigned)j * 1024u), (unsigned)cx.lane * 16u, __builtin_amdgcn_readfirstlane(dst + (unsigned)j * 1024u));
+    }
+}
+
+template <int NS, int NU>
+__device__ __forceinline__ void ch_loadA(bf16x8 (&a)[NU][NS], const char* slot, int u0, int lane) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+            a[i][p] = *reinterpret_cast<const bf16x8*>(slot + ((u0 + i) * NS + p) * 1024 + lane * 16);
+}
+
+// One segment: acc[rb] += W[rb rows][K] * B[K][this wave's 32 points], K = NPOS * G k-blocks.
+// Unit u of a position = (k-block u / NRBS, row block u % NRBS); the position's units are processed
+// in two halves around the "mid-step" (counted vmcnt wait + one s_barrier) that publishes the DMA of
+// the next position and frees this position's slot.
+//
+// With ONE wave per SIMD every instruction of the wave costs an issue slot (~4 cycles) and only what
+// sits between two MFMAs is hidden (about 5 instructions per 32-cycle MFMA).  So the schedule is
+// written out: each MFMA is followed by at most a few "fillers" and pinned with sched_barrier --
+//   half 1: fragment reads of half 2 (one per MFMA), then the global stores of a stash job;
+//   half 2: the DMAs that refill the freed slot with position +CH_S, interleaved with the fragment
+//           reads of the next position's half 1, then the LDS write + read-back of a stash job.
+// MFMAs of a half run term by term over its units so consecutive MFMAs hit different accumulators.
+//
+// Stash (SP > 0: the planes this phase consumes are the previous layer's activations, which the
+// backward needs as [plane][point][LD] rows).  A lane holds 16 bytes of a row per k-block, so
+// stores straight from registers would write 32-byte pieces.  Instead a "job" = (group of 4
+// k-blocks, plane) goes through a 4-KiB per-wave LDS tile [32 rows][128 B] (XOR-swizzled): 4
+// ds_write_b128, 4 ds_read_b128 that return 8 rows x 128 B each, 4 global stores of full 128-byte
+// row segments.  Wave-private, so LDS ordering alone synchronises it.  Jobs are spread evenly over
+// the positions of the phase.
+template <class N, int NS, int DT, bool HAS_ALPHA, int NRBS, int G, int NPOS, int BSRC, bool TRUNK, int T0, int KX, int SP, int LD>
+struct ChPhase {
+    using SC = ChSched<N, NS, HAS_ALPHA>;
+    static constexpr int U = NRBS * G, H = U / 2;
+    static_assert(U % 2 == 0, "a position needs an even number of units");
+    static_assert(NS == 1 || NS == 2, "chain kernel: 1 or 2 planes");
+    static_assert(SP <= NS, "cannot stash more planes than computed");
+    static constexpr int PE_PLANE = CH_MT * PE_ROW * 2;
+    static constexpr int TERMS = NS == 2 ? 3 : 1;
+    static constexpr int NM = H * TERMS;                      // MFMAs per half
+    static constexpr int NF = H * NS;                         // fragments per half
+    static constexpr int NJOB = SP > 0 ? (NPOS * G / 4) * SP : 0;
+    static_assert(SP == 0 || ((NPOS * G) % 4 == 0 && NJOB <= NPOS), "stash jobs must fit the positions of the phase");
+    static constexpr int SPACING = NJOB > 0 ? NPOS / NJOB : 1;
+    // job whose LDS write + read-back runs in position i (-1: none); its global stores run in position
+    // i + 1 when the jobs are at least 2 positions apart, else at the end of the same position
+    static constexpr int job_wr(int i) { return (NJOB > 0 && i % SPACING == 0 && i / SPACING < NJOB) ? i / SPACING : -1; }
+    static constexpr int job_st1(int i) { return (SPACING >= 2 && i >= 1) ? job_wr(i - 1) : -1; }   // stores in half 1
+    static constexpr int job_st2(int i) { return SPACING >= 2 ? -1 : job_wr(i); }                   // stores in half 2
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+    struct Regs {
+        bf16x8 a0[H][NS], a1[H][NS];
+        bf16x8 bpe[G][NS];
+        u32x4 sb[4];
+    };
+    struct Stash {
+        char* tile;            // this wave's 4-KiB LDS tile
+        __bf16* rows;          // stash array, at this wave's first point
+        long long plane;       // plane stride (elements)
+    };
+
+    // MFMA m of a half whose first unit is U0: term-major over the units
+    template <int I, int U0, int M>
+    static __device__ __forceinline__ void mfma_m(f32x16 (&acc)[NRBS], const bf16x8 (&a)[H][NS], const bf16x8 (&xin)[KX][NS],
+                                                  const bf16x8 (&bpe)[G][NS]) {
+        constexpr int term = M / H, u = M % H, uu = U0 + u, rb = uu % NRBS, kbl = uu / NRBS;
+        constexpr int pa = NS == 2 ? (term == 0 ? 1 : 0) : 0;     // A plane: lo, hi, hi
+        constexpr int pb = NS == 2 ? (term == 1 ? 1 : 0) : 0;     // B plane: hi, lo, hi
+        const bf16x8& bv = [&]() -> const bf16x8& {
+            if constexpr (BSRC != B_REG) return bpe[kbl][pb];
+            else return xin[I * G + kbl][pb];
+        }();
+        if constexpr (DT == DT_F16) acc[rb] = mfma_f16(a[u][pa], bv, acc[rb]);
+        else acc[rb] = mfma_bf16(a[u][pa], bv, acc[rb]);
+    }
+
+    static __device__ __forceinline__ void st_write(const Stash& st, const bf16x8 (&xin)[KX][NS], int job, int kq, int lane) {
+        const int n = lane & 31, hh = lane >> 5, j = job / SP, p = job % SP;
+        *reinterpret_cast<u32x4*>(st.tile + n * 128 + (((2 * kq + hh) ^ (n & 7)) << 4)) = __builtin_bit_cast(u32x4, xin[4 * j + kq][p]);
+    }
+    static __device__ __forceinline__ void st_read(const Stash& st, Regs& r, int i, int lane) {
+        const int row = 8 * i + (lane >> 3);
+        r.sb[i] = *reinterpret_cast<const u32x4*>(st.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+    }
+    static __device__ __forceinline__ void st_store(const Stash& st, const Regs& r, int job, int i, int lane) {
+        const int j = job / SP, p = job % SP;
+        u32x4* dst = reinterpret_cast<u32x4*>(st.rows + p * st.plane + (long long)(8 * i + (lane >> 3)) * LD + j * 64 + (lane & 7) * 8);
+#if defined(LUSH_ABL_NOSTORE)     // timing ablation only
+        asm volatile("" ::"v"(r.sb[i]), "v"(dst));
+#elif defined(LUSH_ABL_PLAINST)
+        *dst = r.sb[i];
+#else
+        __builtin_nontemporal_store(r.sb[i], dst);
+#endif
+    }
+
+    // ---- half 1 of position I: MFMAs on a0; fillers: read a1 (units H..U-1), then a job's global stores ----
+    template <int I, int M>
+    static __device__ __forceinline__ void h1_step(f32x16 (&acc)[NRBS], Regs& r, const bf16x8 (&xin)[KX][NS], const char* rd,
+                                                   int lane, const Stash& st) {
+        mfma_m<I, 0, M>(acc, r.a0, xin, r.bpe);
+        constexpr int JS = job_st1(I);
+        constexpr int NFILL = NF + (JS >= 0 ? 4 : 0);
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            if ((k * NM) / NFILL == M) {
+                if (k < NF) r.a1[k / NS][k % NS] = *reinterpret_cast<const bf16x8*>(rd + (H * NS + k) * 1024 + lane * 16);
+                else if constexpr (JS >= 0) st_store(st, r, JS, k - NF, lane);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int I, int... M>
+    static __device__ __forceinline__ void h1(f32x16 (&acc)[NRBS], Regs& r, const bf16x8 (&xin)[KX][NS], const char* rd, int lane,
+                                              const Stash& st, std::integer_sequence<int, M...>) {
+        (h1_step<I, M>(acc, r, xin, rd, lane, st), ...);
+    }
+
+    // ---- half 2: MFMAs on a1; fillers: D0 L0 D1 L1 ... (refill DMAs / next position's a0 reads), then a
+    // stash job's 4 LDS writes and 4 read-backs (and its stores, when jobs come every position) ----
+    static constexpr int dma_count(int i) { return (TRUNK ? SC::TRUNK_PIECES : SC::tail_pieces(T0 + i + CH_S)) / 4; }
+    template <int I, int M>
+    static __device__ __forceinline__ void h2_step(ChCtx& cx, f32x16 (&acc)[NRBS], Regs& r, const bf16x8 (&xin)[KX][NS],
+                                                   const char* rd_next, unsigned dma_off, unsigned dma_dst, const Stash& st) {
+        mfma_m<I, H, M>(acc, r.a1, xin, r.bpe);
+        constexpr int ND = dma_count(I);
+        constexpr int NL = (I + 1 < NPOS) ? NF : 0;
+        constexpr int PAIRS = ND < NL ? ND : NL;
+        constexpr int JW = job_wr(I), JS = job_st2(I);
+        constexpr int NST = (JW >= 0 ? 8 : 0) + (JS >= 0 ? 4 : 0);
+        constexpr int NFILL = ND + NL + NST;
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+            if ((k * NM) / (NFILL > 0 ? NFILL : 1) == M) {
+                if (k < ND + NL) {
+                    const bool is_dma = (k < 2 * PAIRS) ? (k % 2 == 0) : (ND > NL);
+                    const int d = (k < 2 * PAIRS) ? k / 2 : k - PAIRS;
+                    if (is_dma) {
+                        const unsigned j = (unsigned)cx.w + 4u * (unsigned)d;
+                        dma16s(cx.gbase + (dma_off + j * 1024u), (unsigned)cx.lane * 16u,
+                               __builtin_amdgcn_readfirstlane(dma_dst + j * 1024u));
+                    } else {
+                        r.a0[d / NS][d % NS] = *reinterpret_cast<const bf16x8*>(rd_next + d * 1024 + cx.lane * 16);
+                    }
+                } else {
+                    const int q = k - ND - NL;
+                    if constexpr (JW >= 0) {
+                        if (q < 4) st_write(st, xin, JW, q, cx.lane);
+                        else if (q < 8) st_read(st, r, q - 4, cx.lane);
+                    }
+                    if constexpr (JS >= 0) {
+                        if (q >= 8) st_store(st, r, JS, q - 8, cx.lane);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int I, int... M>
+    static __device__ __forceinline__ void h2(ChCtx& cx, f32x16 (&acc)[NRBS], Regs& r, const bf16x8 (&xin)[KX][NS],
+                                              const char* rd_next, unsigned dma_off, unsigned dma_dst, const Stash& st,
+                                              std::integer_sequence<int, M...>) {
+        (h2_step<I, M>(cx, acc, r, xin, rd_next, dma_off, dma_dst, st), ...);
+    }
+
+    template <int I>
+    static __device__ __forceinline__ void pos(ChCtx& cx, f32x16 (&acc)[NRBS], const bf16x8 (&xin)[KX][NS], Regs& r,
+                                               const char* peimg, int row, const Stash& st) {
+        const int lane = cx.lane, hh = lane >> 5;
+        if constexpr (BSRC != B_REG) {
+#pragma unroll
+            for (int kbl = 0; kbl < G; ++kbl)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    r.bpe[kbl][p] = *reinterpret_cast<const bf16x8*>(
+                        peimg + p * PE_PLANE + swz(row, (BSRC == B_PED ? PE_X / 8 : 0) + 2 * (I * G + kbl) + hh, PE_ROW * 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h1<I>(acc, r, xin, cx.ring + cx.cslot * SC::SLOT, lane, st, std::make_integer_sequence<int, NM>{});
+        // mid-step: my pieces of position +1 have landed; after the barrier everyone's have, and nobody
+        // reads this position's slot any more (a1 is in registers: lgkmcnt(0) inside lds_barrier)
+        wait_vm<TRUNK ? SC::trunk_wait : SC::tail_wait(T0 + I)>();
+        lds_barrier();
+        const unsigned dma_dst = cx.ring_lds + (unsigned)cx.cslot * SC::SLOT;
+        unsigned dma_off;
+        if constexpr (TRUNK) {
+            dma_off = (cx.trunk_pos + CH_S) * (unsigned)SC::SLOT;
+            cx.trunk_pos += 1;
+        } else {
+            dma_off = SC::tail_off(T0 + I + CH_S);
+        }
+        cx.cslot = cx.cslot + 1 == CH_S ? 0 : cx.cslot + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        h2<I>(cx, acc, r, xin, cx.ring + cx.cslot * SC::SLOT, dma_off, dma_dst, st, std::make_integer_sequence<int, NM>{});
+    }
+
+    template <int... I>
+    static __device__ __forceinline__ void run_seq(ChCtx& cx, f32x16 (&acc)[NRBS], const bf16x8 (&xin)[KX][NS], const char* peimg,
+                                                   int row, const Stash& st, std::integer_sequence<int, I...>) {
+        Regs r;
+        ch_loadA<NS, H>(r.a0, cx.ring + cx.cslot * SC::SLOT, 0, cx.lane);
+        (pos<I>(cx, acc, xin, r, peimg, row, st), ...);
+        // a job scheduled on the last position still owes its stores
+        if constexpr (job_st1(NPOS) >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_store(st, r, job_st1(NPOS), i, cx.lane);
+        }
+    }
+    static __device__ __forceinline__ void run(ChCtx& cx, f32x16 (&acc)[NRBS], const bf16x8 (&xin)[KX][NS], const char* peimg,
+                                               int row, char* tile, __bf16* rows, long long plane) {
+        Stash st{tile, rows, plane};
+        run_seq(cx, acc, xin, peimg, row, st, std::make_integer_sequence<int, NPOS>{});
+    }
+};
+
+template <class N, int NS, int DT, bool HAS_ALPHA, int NRBS, int G, int NPOS, int BSRC, bool TRUNK, int T0, int KX, int SP = 0, int LD = 1>
+__device__ __forceinline__ void ch_phase(ChCtx& cx, f32x16 (&acc)[NRBS], const bf16x8 (&xin)[KX][NS], const char* peimg,
+                                         int row, char* tile = nullptr, __bf16* rows = nullptr, long long plane = 0) {
+    ChPhase<N, NS, DT, HAS_ALPHA, NRBS, G, NPOS, BSRC, TRUNK, T0, KX, SP, LD>::run(cx, acc, xin, peimg, row, tile, rows, plane);
+}
+
+// acc[rb][q] = bias[32 rb + 16 (q>>3) + 8 h + (q&7)]  (the permuted row order), from the LDS copy
+template <int NB>
+__device__ __forceinline__ void ch_bias(f32x16 (&acc)[NB], const float* b, int h) {
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(b + rb * 32 + 8 * h);
+        const f32x4 v0 = p[0], v1 = p[1], v2 = p[4], v3 = p[5];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[rb][e] = v0[e];
+            acc[rb][4 + e] = v1[e];
+            acc[rb][8 + e] = v2[e];
+            acc[rb][12 + e] = v3[e];
+        }
+    }
+}
+
+// Accumulators -> (ReLU) -> NS planes, in place as the next B operand: block rb gives k-blocks 2rb, 2rb+1.
+// ReLU decisions go to the stash in the layout of mask_index(): there, bit 4g+e of lane (col, h) is
+// feature 8g+4h+e; here bit q of lane (col, h) is feature 16(q>>3)+8h+(q&7), so half of every word
+// comes from the partner lane (col, 1-h).
+template <int NS, int DT, bool RELU, int NB, int KX>
+__device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin)[KX][NS], unsigned short* mrow, int lane) {
+    static_assert(2 * NB <= KX, "activation planes do not fit");
+#ifdef LUSH_ABL_NOCONV   // timing ablation only (wrong results): register moves instead of ReLU + plane split
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                f32x4 v = {acc[rb][8 * t], acc[rb][8 * t + 1 + p], acc[rb][8 * t + 2], acc[rb][8 * t + 3 + p]};
+                asm volatile("" : "+v"(v));
+                xin[2 * rb + t][p] = __builtin_bit_cast(bf16x8, v);
+            }
+    return;
+#endif
+    const int h = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        if (RELU && mrow != nullptr) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bits |= (acc[rb][q] > 0.f ? 1u : 0u) << q;
+            const unsigned other = (unsigned)__shfl_xor((int)bits, 32, 64);
+            const unsigned ev = h ? other : bits, od = h ? bits : other;
+            const int sh = 4 * h;
+            const unsigned old = ((ev >> sh) & 0xFu) | (((od >> sh) & 0xFu) << 4) | (((ev >> (8 + sh)) & 0xFu) << 8) |
+                                 (((od >> (8 + sh)) & 0xFu) << 12);
+            mrow[rb * 64] = (unsigned short)old;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __bf16 pl[8][NS];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = acc[rb][8 * t + j];
+                if (RELU) asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));
+                split_planes<NS, DT>(v, pl[j]);
+            }
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xin[2 * rb + t][p][j] = pl[j][p];
+        }
+    }
+}
+
+template <class N, int NS, bool HAS_ALPHA, int DT, int SPK>
+__global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A) {
+    using SC = ChSched<N, NS, HAS_ALPHA>;
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, NRB = N::NRB, NRBV = N::NRBV, KKH = N::KKH;
+    constexpr int PE_PLANE = CH_MT * PE_ROW * 2;
+    constexpr int NBIAS = N::f32_w_rgb;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                  // [CH_S][SLOT]
+    char* peimg = smem + CH_S * SC::SLOT;               // [NS][128 points][256 B], XOR-swizzled
+    float* biasl = reinterpret_cast<float*>(peimg + NS * PE_PLANE);
+    char* stage = reinterpret_cast<char*>(biasl + NBIAS);   // [4 waves][4 KiB] stash transposition tiles (SPK > 0)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const char* wbase = reinterpret_cast<const char*>(A.wpk);
+    {
+        const float* f32 = reinterpret_cast<const float*>(wbase + (long long)N::total_entries * NS * 1024);
+        for (int i = tid; i < NBIAS; i += CH_NT) biasl[i] = f32[i];
+    }
+    ChCtx cx;
+    cx.ring = ring;
+    cx.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    cx.gbase = wbase + (long long)N::fwd2_base * NS * 1024;
+    cx.cslot = 0;
+    cx.trunk_pos = 0;
+    cx.w = w;
+    cx.lane = lane;
+#pragma unroll
+    for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
+
+    constexpr bool stash_on = SPK > 0;
+    constexpr int sp = SPK;
+    const int row = w * 32 + n;
+    char* tile_w = stage + w * 4096;
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * CH_MT;
+        const long long gpt = pt0 + row;
+        const long long wpt = pt0 + w * 32;            // this wave's first point
+#ifndef LUSH_ABL_NOPE    // timing ablation only (wrong results)
+        pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
+#endif
+        wait_vm<0>();      // first tile: the prologue DMAs; later tiles: already published by the last mid-step
+        lds_barrier();
+        if (stash_on) {
+            for (int i = tid; i < sp * CH_MT * 12; i += CH_NT) {
+                const int c = i % 12, pt = (i / 12) % CH_MT, p = i / (12 * CH_MT);
+                const uint4 v = *reinterpret_cast<const uint4*>(peimg + p * PE_PLANE + swz(pt, c, PE_ROW * 2));
+                *reinterpret_cast<uint4*>(A.pe + p * A.plane_pe + (pt0 + pt) * PE_ROW + c * 8) = v;
+            }
+        }
+        cx.trunk_pos = 0;
+        {   // opaque per tile: otherwise the ~40 static stream addresses of the tail are hoisted out of the
+            // tile loop and live (spilled) across it
+            unsigned long long gb = (unsigned long long)cx.gbase;
+            asm volatile("" : "+s"(gb));
+            cx.gbase = (const char*)gb;
+        }
+        // mask record of (this wave's 32-point block, layer ml, row block 0), this lane's 16-bit word
+        const long long blk = pt0 / 32 + w;
+        auto mrow = [&](int ml) -> unsigned short* {
+            return stash_on ? reinterpret_cast<unsigned short*>(A.mask + ((blk * N::n_mask_layers + ml) * NRB) * 16) + lane : nullptr;
+        };
+        f32x16 acc[NRB];
+        bf16x8 xin[KKH][NS];
+        // ---- layer 0: gamma(x) from the PE image ----
+        ch_bias<NRB>(acc, biasl + N::f32_b_trunk, h);
+        ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, N::KKX, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
+        ch_convert<NS, DT, true, NRB, KKH>(acc, xin, mrow(0), lane);
+        // ---- layers 1 .. NL-1 ----
+#pragma unroll 1
+        for (int l = 1; l < NL; ++l) {
+            ch_bias<NRB>(acc, biasl + N::f32_b_trunk + l * HW, h);
+            if (l == N::SKIP)
+                ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, N::KKX, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
+            ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, KKH, B_REG, true, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
+                                                                                 A.h0 + (l - 1) * A.h_stride + wpt * HW, A.plane_h);
+            ch_convert<NS, DT, true, NRB, KKH>(acc, xin, mrow(l), lane);
+        }
+        // ---- feature head (no activation) and alpha head, both on h_{NL-1} ----
+        ch_bias<NRB>(acc, biasl + N::f32_b_feat, h);
+        ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, KKH, B_REG, false, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
+                                                                              A.h0 + (NL - 1) * A.h_stride + wpt * HW, A.plane_h);
+        float alpha = 0.f;
+        if constexpr (HAS_ALPHA) {
+            f32x16 aa[1];
+            ch_bias<1>(aa, biasl + N::f32_b_alpha, h);
+            ch_phase<N, NS, DT, HAS_ALPHA, 1, SC::G_A, SC::NP_A, B_REG, false, SC::T_A, KKH>(cx, aa, xin, peimg, row);
+            alpha = aa[0][0];
+        }
+        ch_convert<NS, DT, false, NRB, KKH>(acc, xin, nullptr, lane);
+        // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
+        f32x16 av[NRBV];
+        ch_bias<NRBV>(av, biasl + N::f32_b_views, h);
+        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_V, SC::NP_VA, B_REG, false, SC::T_VA, KKH, SPK, HW>(cx, av, xin, peimg, row, tile_w,
+                                                                                                A.feat + wpt * HW, A.plane_h);
+        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_V, SC::NP_VB, B_PED, false, SC::T_VB, KKH>(cx, av, xin, peimg, row);
+        ch_convert<NS, DT, true, NRBV, KKH>(av, xin, stash_on ? mrow(NL) : nullptr, lane);
+        // ---- rgb head ----
+        f32x16 ar[1];
+        ch_bias<1>(ar, biasl + N::f32_b_rgb, h);
+        ch_phase<N, NS, DT, HAS_ALPHA, 1, SC::G_R, SC::NP_R, B_REG, false, SC::T_R, KKH, SPK, HV>(cx, ar, xin, peimg, row, tile_w,
+                                                                                         A.hv + wpt * HV, A.plane_hv);
+        if (h == 0 && gpt < A.P) {
+            float4 o;
+            o.x = ar[0][0];
+            o.y = ar[0][1];
+            o.z = ar[0][2];
+            o.w = HAS_ALPHA ? alpha : 0.f;
+            *reinterpret_cast<float4*>(A.raw + gpt * 4) = o;
+        }
+    }
+    wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+template <class N, int NS, bool HAS_ALPHA>
+static size_t chain_lds_bytes() {
+    return (size_t)CH_S * ChSched<N, NS, HAS_ALPHA>::SLOT + (size_t)NS * CH_MT * PE_ROW * 2 + (size_t)N::f32_w_rgb * 4 +
+           (size_t)CH_NW * 4096;
+}
+
+template <class N, int NS, bool HAS_ALPHA, int DT, int SPK>
+static int launch_chain_sp(const MlpFwdArgs& a, hipStream_t s) {
+    auto k = mlp_chain_fwd_kernel<N, NS, HAS_ALPHA, DT, SPK>;
+    const size_t lds = chain_lds_bytes<N, NS, HAS_ALPHA>();
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        LUSH_HIP(hipGetDevice(&dev));
+        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+    }
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;     // one workgroup per CU, tiles strided
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+template <class N, int NS, bool HAS_ALPHA, int DT>
+static int launch_chain_k(const MlpFwdArgs& a, hipStream_t s) {
+    const int sp = a.write_stash ? a.stash_planes : 0;
+    if (sp == 0) return launch_chain_sp<N, NS, HAS_ALPHA, DT, 0>(a, s);
+    if (sp == 1) return launch_chain_sp<N, NS, HAS_ALPHA, DT, 1>(a, s);
+    if constexpr (NS == 2) {
+        if (sp == 2) return launch_chain_sp<N, NS, HAS_ALPHA, DT, 2>(a, s);
+    }
+    return set_error("launch_mlp_chain_fwd: bad stash plane count");
+}
+
+// planes 1, 2 and the fp16 code run on the chain kernel (128-point tiles); 3 planes keep mlp_fwd_kernel.
+// LUSH_FWD_OLD=1 forces the old kernel (A/B measurements).
+bool mlp_fwd_chain_enabled(int planes) {
+    static int old = -1;
+    if (old < 0) {
+        const char* e = getenv("LUSH_FWD_OLD");
+        old = (e && e[0] == '1') ? 1 : 0;
+    }
+    return !old && (planes == 1 || planes == 2 || planes == PLANES_F16);
+}
+
+int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, hipStream_t s) {
+    if (planes == PLANES_F16) {
+        if (net == 0) return launch_chain_k<NetNerf, 1, true, DT_F16>(a, s);
+        return launch_chain_k<NetNoise, 1, false, DT_F16>(a, s);
+    }
+    if (net == 0) {
+        if (planes == 1) return launch_chain_k<NetNerf, 1, true, DT_BF16>(a, s);
+        if (planes == 2) return launch_chain_k<NetNerf, 2, true, DT_BF16>(a, s);
+    } else {
+        if (planes == 1) return launch_chain_k<NetNoise, 1, false, DT_BF16>(a, s);
+        if (planes == 2) return launch_chain_k<NetNoise, 2, false, DT_BF16>(a, s);
+    }
+    return set_error("launch_mlp_chain_fwd: bad net/planes");
+}
+
+}  // namespace lush

@@ -1,0 +1,95 @@
+// lush-march: device helpers shared by the fused MLP kernels (lush_mlp.hip, lush_mlp_chain.hip).
+#pragma once
+#include "lush_common.h"
+#include "lush_mlp.h"
+
+namespace lush {
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), which
+// would stall every layer on the acknowledgement of the in-flight stash stores.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ReLU decisions: per (32-point column block, mask layer, row-block) one 128-byte record = a 16-bit
+// word per lane, bit q = "accumulator register q of this lane was > 0".  The backward (same lane <->
+// (point, rows) mapping) applies it with v_bfe_i32 + v_and per element.  The column block is global
+// (tile*CB + cb) so kernels with different tile sizes agree.  (Index is in 8-byte units.)
+__device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int nrb, int rb, int CB, int cb) {
+    return ((((long long)tile * CB + cb) * n_ml + ml) * nrb + rb) * 16;
+}
+
+// ----------------------------------------------------------------------------
+// positional encoding of one tile into the PE image
+// ----------------------------------------------------------------------------
+template <int NS, int DT>
+__device__ __forceinline__ void pe_put(char* img, int plane_bytes, int row_bytes, int pt, int col, float v) {
+    __bf16 p[NS];
+    split_planes<NS, DT>(v, p);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        *reinterpret_cast<__bf16*>(img + s * plane_bytes + swz(pt, col >> 3, row_bytes) + (col & 7) * 2) = p[s];
+}
+
+// Point position exactly as the reference forms it: o + d*z, two roundings,
+// no FMA (models/lushnerf.py:414, 525).
+__device__ __forceinline__ void point_of(const float* __restrict__ rays, const float* __restrict__ z,
+                                         int S, long long gpt, float (&x)[3], float (&d)[3]) {
+    const long long ray = gpt / S;
+    const float zz = z[gpt];
+    const float* rr = rays + ray * 11;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x[i] = __fadd_rn(rr[i], __fmul_rn(rr[3 + i], zz));
+        d[i] = rr[8 + i];
+    }
+}
+
+// (not inlined on purpose: the inlined sincosf bodies otherwise leave dozens of loop-invariant
+// values live across the MFMA loops of the whole tile)
+template <int NS, int MT, int NTHREADS, int DT>
+__device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
+                                        int S, int P, long long tile_pt0, int tid) {
+    constexpr int PARTS = NTHREADS / MT;
+    const int pt = tid % MT, part = tid / MT;
+    const long long gpt = tile_pt0 + pt;
+    float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (gpt < P) point_of(rays, z, S, gpt, x, d);
+    // units: 0..L_X-1 = frequency k of x; L_X..L_X+L_D-1 = frequency k of d; raw copies go with unit 0 / L_X
+    for (int u = part; u < L_X + L_D; u += PARTS) {
+        const bool isd = u >= L_X;
+        const int k = isd ? u - L_X : u;
+        const int base = isd ? PE_X : 0;
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float v = isd ? d[i] : x[i];
+            if (k == 0) pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + i, v);
+            float s, c;
+            sincosf(v * f, &s, &c);
+            pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + i, s);
+            pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, base + 3 + 6 * k + 3 + i, c);
+        }
+    }
+    if (part == PARTS - 1) {   // zero padding columns that the K loops do read
+        pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, PE_X_VALID, 0.f);
+#pragma unroll
+        for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) pe_put<NS, DT>(peimg, plane_bytes, row_bytes, pt, c, 0.f);
+    }
+}
+
+// One 1-KiB LDS-DMA: lane i moves 16 bytes from its own global address to LDS lds_base + 16*i.
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_base /* wave-uniform byte offset */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gptr), "s"(lds_base) : "memory");
+}
+
+// Same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: the address
+// arithmetic of a stream of DMAs stays on the scalar unit (per-lane 64-bit addresses of every
+// unrolled DMA are otherwise hoisted out of the tile loop and spilled).
+__device__ __forceinline__ void dma16s(const void* sbase /* uniform */, unsigned voff, unsigned lds_base /* uniform */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
+}  // namespace lush

@@ -13,9 +13,9 @@ from typing import Sequence
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO_PATH = os.path.join(HERE, "liblush_march.so")
-SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_abi.hip"]
-HEADERS = ["lush_common.h", "lush_mlp.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
+SO_PATH = os.environ.get("LUSH_SO") or os.path.join(HERE, "liblush_march.so")   # LUSH_SO: developer ablation builds
+SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_abi.hip"]
+HEADERS = ["lush_common.h", "lush_mlp.h", "lush_mlp_dev.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
 
 _lib = None
 
