@@ -185,6 +185,7 @@ __device__ __forceinline__ void store_block(const f32x16& acc, char* img, int pl
         unsigned bits = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) bits |= (acc[q] > 0.f ? 1u : 0u) << q;
+        bits = mask_relayout(bits, (unsigned)__shfl_xor((int)bits, 32, 64), h);
         reinterpret_cast<unsigned short*>(mask_words)[lane] = (unsigned short)bits;
     }
 #pragma unroll
@@ -264,7 +265,8 @@ __device__ __forceinline__ void store_block_masked(f32x16 acc, char* img, int pl
                                                    long long stash_plane, int stash_ld, long long gpt,
                                                    const unsigned long long* mask_words) {
     if (mask_words != nullptr) {
-        const int bits = reinterpret_cast<const unsigned short*>(mask_words)[lane];
+        const unsigned short* mw = reinterpret_cast<const unsigned short*>(mask_words);
+        const int bits = (int)mask_relayout(mw[lane], mw[lane ^ 32], lane >> 5);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (!((bits >> q) & 1)) acc[q] = 0.f;

@@ -82,6 +82,15 @@ struct ChSched {
     static constexpr int trunk_wait = (CH_S - 2) * TRUNK_PIECES / 4;
 };
 
+#ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back with hipMemcpyFromSymbol
+__device__ unsigned long long lush_prof[8];
+#define PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(slot, t0) prof[slot] += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0)
+#endif
+
 template <int N_>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
@@ -92,16 +101,17 @@ struct ChCtx {
     int cslot;             // slot of the position being consumed
     unsigned trunk_pos;    // index of the trunk position being consumed
     int w, lane;
+    unsigned voff[4];      // per-lane byte offset of this wave's d-th DMA piece of a position: 16*lane + 4096*d + 1024*w
 };
 
+// DMA piece d of this wave (d = 0 .. PIECES/4-1) of a position: global bytes [off + (w + 4d) KiB, +1 KiB)
+// of the stream -> the same offset inside ring slot `dst`.
 template <int PIECES, int SLOT>
 __device__ __forceinline__ void ch_issue(const ChCtx& cx, unsigned off, int slot) {
-    const unsigned dst = cx.ring_lds + (unsigned)slot * SLOT;
+    const unsigned dst = cx.ring_lds + (unsigned)slot * SLOT + (unsigned)cx.w * 1024u;
+    const char* src = cx.gbase + off;
 #pragma unroll
-    for (int i = 0; i < PIECES / 4; ++i) {
-        const int j = cx.w + 4 * i;
-        dma16s(cx.gbase + (off + (unsigned)j * 1024u), (unsigned)cx.lane * 16u, __builtin_amdgcn_readfirstlane(dst + (unsigned)j * 1024u));
-    }
+    for (int d = 0; d < PIECES / 4; ++d) dma16s(src, cx.voff[d], __builtin_amdgcn_readfirstlane(dst + (unsigned)d * 4096u));
 }
 
 template <int NS, int NU>
@@ -242,9 +252,14 @@ struct ChPhase {
                     const bool is_dma = (k < 2 * PAIRS) ? (k % 2 == 0) : (ND > NL);
                     const int d = (k < 2 * PAIRS) ? k / 2 : k - PAIRS;
                     if (is_dma) {
-                        const unsigned j = (unsigned)cx.w + 4u * (unsigned)d;
-                        dma16s(cx.gbase + (dma_off + j * 1024u), (unsigned)cx.lane * 16u,
-                               __builtin_amdgcn_readfirstlane(dma_dst + j * 1024u));
+                        // pieces go in pairs under one M0 save/restore (the odd one of a pair is a no-op filler)
+                        if (d % 2 == 0) {
+                            if (d + 1 < ND)
+                                dma16s_x2(cx.gbase + dma_off, cx.voff[d], __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)d * 4096u),
+                                          cx.voff[d + 1], __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)(d + 1) * 4096u));
+                            else
+                                dma16s(cx.gbase + dma_off, cx.voff[d], __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)d * 4096u));
+                        }
                     } else {
                         r.a0[d / NS][d % NS] = *reinterpret_cast<const bf16x8*>(rd_next + d * 1024 + cx.lane * 16);
                     }
@@ -285,9 +300,15 @@ struct ChPhase {
         h1<I>(acc, r, xin, cx.ring + cx.cslot * SC::SLOT, lane, st, std::make_integer_sequence<int, NM>{});
         // mid-step: my pieces of position +1 have landed; after the barrier everyone's have, and nobody
         // reads this position's slot any more (a1 is in registers: lgkmcnt(0) inside lds_barrier)
+#ifndef LUSH_ABL_NOVMWAIT   // timing ablations only (wrong results)
         wait_vm<TRUNK ? SC::trunk_wait : SC::tail_wait(T0 + I)>();
+#endif
+#ifndef LUSH_ABL_NOBAR
         lds_barrier();
-        const unsigned dma_dst = cx.ring_lds + (unsigned)cx.cslot * SC::SLOT;
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        const unsigned dma_dst = cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * 1024u;
         unsigned dma_off;
         if constexpr (TRUNK) {
             dma_off = (cx.trunk_pos + CH_S) * (unsigned)SC::SLOT;
@@ -343,10 +364,11 @@ __device__ __forceinline__ void ch_bias(f32x16 (&acc)[NB], const float* b, int h
 }
 
 // Accumulators -> (ReLU) -> NS planes, in place as the next B operand: block rb gives k-blocks 2rb, 2rb+1.
-// ReLU decisions go to the stash in the layout of mask_index(): there, bit 4g+e of lane (col, h) is
-// feature 8g+4h+e; here bit q of lane (col, h) is feature 16(q>>3)+8h+(q&7), so half of every word
-// comes from the partner lane (col, 1-h).
-template <int NS, int DT, bool RELU, int NB, int KX>
+// ReLU decisions (mask_index() records): bit q = "stored hi-plane value of accumulator q is non-zero",
+// read off the packed 16-bit planes with v_pk_min_u16 (1 instruction per 2 values instead of a
+// compare + select + or per value).  hi == 0 with acc > 0 needs acc below the smallest bf16 / half
+// of the smallest fp16 subnormal: such a unit contributes nothing either way.
+template <int NS, int DT, bool RELU, int NB, int KX, bool MASK>
 __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin)[KX][NS], unsigned short* mrow, int lane) {
     static_assert(2 * NB <= KX, "activation planes do not fit");
 #ifdef LUSH_ABL_NOCONV   // timing ablation only (wrong results): register moves instead of ReLU + plane split
@@ -362,20 +384,10 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
             }
     return;
 #endif
-    const int h = lane >> 5;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) {
-        if (RELU && mrow != nullptr) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) bits |= (acc[rb][q] > 0.f ? 1u : 0u) << q;
-            const unsigned other = (unsigned)__shfl_xor((int)bits, 32, 64);
-            const unsigned ev = h ? other : bits, od = h ? bits : other;
-            const int sh = 4 * h;
-            const unsigned old = ((ev >> sh) & 0xFu) | (((od >> sh) & 0xFu) << 4) | (((ev >> (8 + sh)) & 0xFu) << 8) |
-                                 (((od >> (8 + sh)) & 0xFu) << 12);
-            mrow[rb * 64] = (unsigned short)old;
-        }
+        unsigned word = 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             __bf16 pl[8][NS];
@@ -389,7 +401,19 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
             for (int p = 0; p < NS; ++p)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xin[2 * rb + t][p][j] = pl[j][p];
+            if constexpr (RELU && MASK) {
+                const u32x4 hv = __builtin_bit_cast(u32x4, xin[2 * rb + t][0]);
+                unsigned m = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned mi;   // 0/1 per halfword (as asm: LLVM rewrites umin(x, 1) into compare + select per halfword)
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(mi) : "v"(hv[i]), "s"(0x00010001u));
+                    m |= mi << (2 * i);
+                }
+                word |= ((m | (m >> 15)) & 0xFFu) << (8 * t);       // values 2i (low halves) and 2i+1 (high halves)
+            }
         }
+        if constexpr (RELU && MASK) mrow[rb * 64] = (unsigned short)word;
     }
 }
 
@@ -422,6 +446,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     cx.w = w;
     cx.lane = lane;
 #pragma unroll
+    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
+#pragma unroll
     for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
 
     constexpr bool stash_on = SPK > 0;
@@ -429,9 +455,14 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     const int row = w * 32 + n;
     char* tile_w = stage + w * 4096;
 
+#ifdef LUSH_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * CH_MT;
         const long long gpt = pt0 + row;
+        PROF_T(t_pe);
         const long long wpt = pt0 + w * 32;            // this wave's first point
 #ifndef LUSH_ABL_NOPE    // timing ablation only (wrong results)
         pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
@@ -445,6 +476,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
                 *reinterpret_cast<uint4*>(A.pe + p * A.plane_pe + (pt0 + pt) * PE_ROW + c * 8) = v;
             }
         }
+        PROF_ADD(1, t_pe);
         cx.trunk_pos = 0;
         {   // opaque per tile: otherwise the ~40 static stream addresses of the tail are hoisted out of the
             // tile loop and live (spilled) across it
@@ -462,17 +494,23 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         // ---- layer 0: gamma(x) from the PE image ----
         ch_bias<NRB>(acc, biasl + N::f32_b_trunk, h);
         ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, N::KKX, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
-        ch_convert<NS, DT, true, NRB, KKH>(acc, xin, mrow(0), lane);
+        ch_convert<NS, DT, true, NRB, KKH, stash_on>(acc, xin, mrow(0), lane);
+        PROF_T(t_trunk);
         // ---- layers 1 .. NL-1 ----
 #pragma unroll 1
         for (int l = 1; l < NL; ++l) {
             ch_bias<NRB>(acc, biasl + N::f32_b_trunk + l * HW, h);
             if (l == N::SKIP)
                 ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, N::KKX, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
+            PROF_T(t_ph);
             ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, KKH, B_REG, true, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
                                                                                  A.h0 + (l - 1) * A.h_stride + wpt * HW, A.plane_h);
-            ch_convert<NS, DT, true, NRB, KKH>(acc, xin, mrow(l), lane);
+            PROF_ADD(3, t_ph);
+            PROF_T(t_cv);
+            ch_convert<NS, DT, true, NRB, KKH, stash_on>(acc, xin, mrow(l), lane);
+            PROF_ADD(4, t_cv);
         }
+        PROF_ADD(2, t_trunk);
         // ---- feature head (no activation) and alpha head, both on h_{NL-1} ----
         ch_bias<NRB>(acc, biasl + N::f32_b_feat, h);
         ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, KKH, B_REG, false, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
@@ -484,14 +522,14 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
             ch_phase<N, NS, DT, HAS_ALPHA, 1, SC::G_A, SC::NP_A, B_REG, false, SC::T_A, KKH>(cx, aa, xin, peimg, row);
             alpha = aa[0][0];
         }
-        ch_convert<NS, DT, false, NRB, KKH>(acc, xin, nullptr, lane);
+        ch_convert<NS, DT, false, NRB, KKH, false>(acc, xin, nullptr, lane);
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
         f32x16 av[NRBV];
         ch_bias<NRBV>(av, biasl + N::f32_b_views, h);
         ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_V, SC::NP_VA, B_REG, false, SC::T_VA, KKH, SPK, HW>(cx, av, xin, peimg, row, tile_w,
                                                                                                 A.feat + wpt * HW, A.plane_h);
         ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_V, SC::NP_VB, B_PED, false, SC::T_VB, KKH>(cx, av, xin, peimg, row);
-        ch_convert<NS, DT, true, NRBV, KKH>(av, xin, stash_on ? mrow(NL) : nullptr, lane);
+        ch_convert<NS, DT, true, NRBV, KKH, stash_on>(av, xin, mrow(NL), lane);
         // ---- rgb head ----
         f32x16 ar[1];
         ch_bias<1>(ar, biasl + N::f32_b_rgb, h);
@@ -506,6 +544,12 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
             *reinterpret_cast<float4*>(A.raw + gpt * 4) = o;
         }
     }
+#ifdef LUSH_PROF
+    if (blockIdx.x == 0 && tid == 0) {
+        prof[0] = __builtin_amdgcn_s_memtime() - t_kernel;
+        for (int i = 0; i < 8; ++i) lush_prof[i] = prof[i];
+    }
+#endif
     wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
 }
 
@@ -546,6 +590,14 @@ static int launch_chain_k(const MlpFwdArgs& a, hipStream_t s) {
     }
     return set_error("launch_mlp_chain_fwd: bad stash plane count");
 }
+
+#ifdef LUSH_PROF
+extern "C" int lush_debug_prof(unsigned long long* out) {
+    LUSH_HIP(hipDeviceSynchronize());
+    LUSH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lush_prof), sizeof(unsigned long long) * 8));
+    return 0;
+}
+#endif
 
 // planes 1, 2 and the fp16 code run on the chain kernel (128-point tiles); 3 planes keep mlp_fwd_kernel.
 // LUSH_FWD_OLD=1 forces the old kernel (A/B measurements).

@@ -10,9 +10,17 @@ namespace lush {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ReLU decisions: per (32-point column block, mask layer, row-block) one 128-byte record = a 16-bit
-// word per lane, bit q = "accumulator register q of this lane was > 0".  The backward (same lane <->
-// (point, rows) mapping) applies it with v_bfe_i32 + v_and per element.  The column block is global
-// (tile*CB + cb) so kernels with different tile sizes agree.  (Index is in 8-byte units.)
+// word per lane.  Canonical layout = the chain kernels' register layout: bit q of lane (col, h) is
+// feature 16*(q>>3) + 8h + (q&7) of the 32-feature block ("activation > 0").  The column block is
+// global (tile*CB + cb) so kernels with different tile sizes agree.  (Index is in 8-byte units.)
+// Kernels whose accumulators hold the natural MFMA rows (bit 4g+e of lane (col, h) = feature
+// 8g+4h+e) convert with mask_relayout(): half of each word comes from the partner lane (col, 1-h);
+// the same formula maps either layout to the other.
+__device__ __forceinline__ unsigned mask_relayout(unsigned own, unsigned other, int h) {
+    const unsigned w0 = h ? other : own, w1 = h ? own : other;     // words of lanes (col, 0) and (col, 1)
+    const int sh = 4 * h;
+    return ((w0 >> sh) & 0xFu) | (((w1 >> sh) & 0xFu) << 4) | (((w0 >> (8 + sh)) & 0xFu) << 8) | (((w1 >> (8 + sh)) & 0xFu) << 12);
+}
 __device__ __forceinline__ long long mask_index(int tile, int n_ml, int ml, int nrb, int rb, int CB, int cb) {
     return ((((long long)tile * CB + cb) * n_ml + ml) * nrb + rb) * 16;
 }
@@ -90,6 +98,14 @@ __device__ __forceinline__ void dma16s(const void* sbase /* uniform */, unsigned
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
+// Two of them under one M0 save/restore.
+__device__ __forceinline__ void dma16s_x2(const void* sbase, unsigned voff0, unsigned lds0, unsigned voff1, unsigned lds1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff0), "s"(sbase), "s"(lds0), "v"(voff1), "s"(lds1) : "memory");
 }
 
 }  // namespace lush
