@@ -93,19 +93,23 @@ void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
         add(p->w_rgb, HV, 1, 3, HV, 1, N::KKV, N::fwd_RGB);
     }
     perm = 0; base = 0;
-    // transposed: element (row, k) = W[k][c0 + row]
-    add(p->w_views, 1, HW + DV, HW, HV, N::NRB, N::KKV, N::bwd_VAT);
-    add(p->w_views + HW, 1, HW + DV, DV, HV, 1, N::KKV, N::bwd_VBT);
-    add(p->w_feat, 1, HW, HW, HW, N::NRB, N::KKH, N::bwd_FEATT);
-    for (int l = NL - 1; l >= 1; --l) {
-        if (l == SK) {
-            add(p->w[l], 1, XV + HW, XV, HW, 2, N::KKH, N::bwd_LT(l, false));
-            add(p->w[l] + XV, 1, XV + HW, HW, HW, N::NRB, N::KKH, N::bwd_LT(l, true));
-        } else {
-            add(p->w[l], 1, HW, HW, HW, N::NRB, N::KKH, N::bwd_LT(l, true));
+    // transposed: element (row, k) = W[k][c0 + row]; natural rows for mlp_bwd_kernel, permuted copy for the chain kernel
+    for (int copy = 0; copy < 2; ++copy) {
+        perm = copy; base = copy ? N::bwd2_base - N::bwd_VAT : 0;
+        add(p->w_views, 1, HW + DV, HW, HV, N::NRB, N::KKV, N::bwd_VAT);
+        add(p->w_views + HW, 1, HW + DV, DV, HV, 1, N::KVB, N::bwd_VBT);
+        add(p->w_feat, 1, HW, HW, HW, N::NRB, N::KKH, N::bwd_FEATT);
+        for (int l = NL - 1; l >= 1; --l) {
+            if (l == SK) {
+                add(p->w[l], 1, XV + HW, XV, HW, 2, N::KKH, N::bwd_LT(l, false));
+                add(p->w[l] + XV, 1, XV + HW, HW, HW, N::NRB, N::KKH, N::bwd_LT(l, true));
+            } else {
+                add(p->w[l], 1, HW, HW, HW, N::NRB, N::KKH, N::bwd_LT(l, true));
+            }
         }
+        add(p->w[0], 1, XV, XV, HW, 2, N::KKH, N::bwd_LT(0, false));
     }
-    add(p->w[0], 1, XV, XV, HW, 2, N::KKH, N::bwd_LT(0, false));
+    perm = 0; base = 0;
 }
 
 int dw_splits(long long Ppad, int /*tiles*/) {
@@ -212,7 +216,8 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     const long long plane_h = L.Ppad * n.HW, plane_hv = L.Ppad * n.HV, plane_pe = L.Ppad * PE_ROW;
 
     MlpBwdArgs a{};
-    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / mlp_bwd_tile(planes_b));
+    const bool chain = mlp_bwd_chain_enabled(planes_b);
+    a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / (chain ? 128 : mlp_bwd_tile(planes_b)));
     a.wpk = (const uint4*)packed_b;
     (void)prm;
     a.draw = draw;
@@ -227,7 +232,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.dpts = dpts;
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
-    if (do_chain) rc = launch_mlp_bwd(net, planes_b, a, grid, st);
+    if (do_chain) rc = chain ? launch_mlp_chain_bwd(net, planes_b, a, st) : launch_mlp_bwd(net, planes_b, a, grid, st);
     if (rc || !do_weights) return rc;
 
     const __bf16* pe = (const __bf16*)(sb + L.pe);

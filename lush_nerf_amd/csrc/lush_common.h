@@ -57,6 +57,26 @@ __device__ __forceinline__ void split_planes(float x, __bf16 (&p)[NS]) {
         }
     }
 }
+// Two values at once, packed per plane (element 0 in the low half): lets the compiler use both operands
+// of v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 instead of converting singly and merging with v_perm.
+template <int NS, int DT = DT_BF16>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NS]) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    f32x2_t r = {a, b};
+    if constexpr (DT == DT_F16) {
+        static_assert(NS == 1, "fp16 is a single-plane format here");
+        o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const bf16x2_t p = __builtin_convertvector(r, bf16x2_t);
+            o[i] = __builtin_bit_cast(unsigned, p);
+            if (i + 1 < NS) r = r - __builtin_convertvector(p, f32x2_t);
+        }
+    }
+}
 // value of a stored 16-bit element
 template <int DT>
 __device__ __forceinline__ float elem_to_f32(__bf16 v) {

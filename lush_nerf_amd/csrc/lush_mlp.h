@@ -44,9 +44,11 @@ struct NetT {
     // ---- backward (transposed) segments ----
     // VAT (rows HW, K=HV) | VBT (rows 32, K=HV) | FEATT | L{NL-1}T .. L1T | L0T (rows 64)
     //   skip layer T = [a: rows 64 (gamma(x) part)][b: rows HW]
+    static constexpr int KVB = 2 * NRB;      // VBT is packed with its K zero-padded to this many k-blocks (whole chain-kernel positions)
+    static_assert(KVB >= KKV && KVB <= KKH, "VBT padding");
     static constexpr int bwd_VAT = fwd_END;
     static constexpr int bwd_VBT = bwd_VAT + KKV * NRB;
-    static constexpr int bwd_FEATT = bwd_VBT + KKV;
+    static constexpr int bwd_FEATT = bwd_VBT + KVB;
     static constexpr int bwd_LT(int l, bool part_b) {   // l in [0, NL-1]
         int off = bwd_FEATT + KKH * NRB;
         for (int i = NL - 1; i > l; --i) off += (i == SKIP ? (KKH * 2 + KKH * NRB) : KKH * NRB);
@@ -59,7 +61,9 @@ struct NetT {
     // (chain_row()) so that a lane's 16 accumulators are the 2 x 8 consecutive features it supplies
     // as the next layer's B operand ----
     static constexpr int fwd2_base = bwd_END;
-    static constexpr int total_entries = bwd_END + fwd_END;
+    // ... and of the backward (transposed) segments for mlp_chain_bwd_kernel: bwd2_X = bwd2_base + (bwd_X - bwd_VAT)
+    static constexpr int bwd2_base = fwd2_base + fwd_END;
+    static constexpr int total_entries = bwd2_base + (bwd_END - bwd_VAT);
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
 
@@ -99,7 +103,7 @@ struct PackJob {
 };
 
 struct PackTable {
-    PackJob j[48];
+    PackJob j[64];
     int n;
 };
 

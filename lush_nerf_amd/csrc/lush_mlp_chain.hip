@@ -45,15 +45,19 @@ template <class N, int NS, bool HAS_ALPHA>
 struct ChSched {
     static constexpr int grp(int nrb) { return nrb * NS >= 4 ? 1 : 4 / (nrb * NS); }
     static constexpr int ENTRY = NS * 1024;
-    static constexpr int TRUNK_PIECES = N::NRB * NS;
+    // trunk positions hold GT k-blocks: with one plane a single k-block is only 8 MFMAs per wave, too
+    // little to cover the LDS latency of the next half's fragments
+    static constexpr int GT = NS == 1 ? 2 : 1;
+    static constexpr int TRUNK_PIECES = N::NRB * NS * GT;
     static constexpr int SLOT = TRUNK_PIECES * 1024;
-    static constexpr int PT = N::KKX + (N::NL - 1) * N::KKH + (N::SKIP > 0 ? N::KKX : 0);
+    static constexpr int PT = (N::KKX + (N::NL - 1) * N::KKH + (N::SKIP > 0 ? N::KKX : 0)) / GT;
+    static_assert(N::KKX % GT == 0 && N::KKH % GT == 0, "trunk k-blocks must group evenly");
     static constexpr int G_A = grp(1), G_V = grp(N::NRBV), G_R = grp(1);
-    static constexpr int NP_F = N::KKH;
+    static constexpr int NP_F = N::KKH / GT;
     static constexpr int NP_A = HAS_ALPHA ? N::KKH / G_A : 0;
     static constexpr int NP_VA = N::KKH / G_V, NP_VB = N::KKD / G_V, NP_R = N::KKV / G_R;
     static constexpr int T_A = NP_F, T_VA = T_A + NP_A, T_VB = T_VA + NP_VA, T_R = T_VB + NP_VB, T_END = T_R + NP_R;
-    static_assert(N::fwd_FEAT == PT * N::NRB, "FEAT must follow the trunk in the stream");
+    static_assert(N::fwd_FEAT == PT * N::NRB * GT, "FEAT must follow the trunk in the stream");
     static_assert(TRUNK_PIECES % 4 == 0 && N::KKH % G_A == 0 && N::KKH % G_V == 0 && N::KKD % G_V == 0 && N::KKV % G_R == 0,
                   "stream positions must be whole multiples of 4 pieces");
     static constexpr int tail_pieces(int t) {
@@ -80,6 +84,7 @@ struct ChSched {
         return n;
     }
     static constexpr int trunk_wait = (CH_S - 2) * TRUNK_PIECES / 4;
+    static constexpr int WRAP = 0;          // trunk positions never wrap: the tail follows them
 };
 
 #ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back with hipMemcpyFromSymbol
@@ -143,9 +148,8 @@ __device__ __forceinline__ void ch_loadA(bf16x8 (&a)[NU][NS], const char* slot, 
 // ds_write_b128, 4 ds_read_b128 that return 8 rows x 128 B each, 4 global stores of full 128-byte
 // row segments.  Wave-private, so LDS ordering alone synchronises it.  Jobs are spread evenly over
 // the positions of the phase.
-template <class N, int NS, int DT, bool HAS_ALPHA, int NRBS, int G, int NPOS, int BSRC, bool TRUNK, int T0, int KX, int SP, int LD>
+template <class SC, int NS, int DT, int NRBS, int G, int NPOS, int BSRC, bool TRUNK, int T0, int KX, int SP, int LD>
 struct ChPhase {
-    using SC = ChSched<N, NS, HAS_ALPHA>;
     static constexpr int U = NRBS * G, H = U / 2;
     static_assert(U % 2 == 0, "a position needs an even number of units");
     static_assert(NS == 1 || NS == 2, "chain kernel: 1 or 2 planes");
@@ -311,7 +315,9 @@ struct ChPhase {
         const unsigned dma_dst = cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * 1024u;
         unsigned dma_off;
         if constexpr (TRUNK) {
-            dma_off = (cx.trunk_pos + CH_S) * (unsigned)SC::SLOT;
+            unsigned np = cx.trunk_pos + CH_S;
+            if constexpr (SC::WRAP > 0) np = np >= (unsigned)SC::WRAP ? np - (unsigned)SC::WRAP : np;   // next tile restarts the stream
+            dma_off = np * (unsigned)SC::SLOT;
             cx.trunk_pos += 1;
         } else {
             dma_off = SC::tail_off(T0 + I + CH_S);
@@ -343,7 +349,7 @@ struct ChPhase {
 template <class N, int NS, int DT, bool HAS_ALPHA, int NRBS, int G, int NPOS, int BSRC, bool TRUNK, int T0, int KX, int SP = 0, int LD = 1>
 __device__ __forceinline__ void ch_phase(ChCtx& cx, f32x16 (&acc)[NRBS], const bf16x8 (&xin)[KX][NS], const char* peimg,
                                          int row, char* tile = nullptr, __bf16* rows = nullptr, long long plane = 0) {
-    ChPhase<N, NS, DT, HAS_ALPHA, NRBS, G, NPOS, BSRC, TRUNK, T0, KX, SP, LD>::run(cx, acc, xin, peimg, row, tile, rows, plane);
+    ChPhase<ChSched<N, NS, HAS_ALPHA>, NS, DT, NRBS, G, NPOS, BSRC, TRUNK, T0, KX, SP, LD>::run(cx, acc, xin, peimg, row, tile, rows, plane);
 }
 
 // acc[rb][q] = bias[32 rb + 16 (q>>3) + 8 h + (q&7)]  (the permuted row order), from the LDS copy
@@ -390,17 +396,21 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
         unsigned word = 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            __bf16 pl[8][NS];
+            u32x4 pk[NS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = acc[rb][8 * t + j];
-                if (RELU) asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));
-                split_planes<NS, DT>(v, pl[j]);
+            for (int i = 0; i < 4; ++i) {
+                float v0 = acc[rb][8 * t + 2 * i], v1 = acc[rb][8 * t + 2 * i + 1];
+                if (RELU) {
+                    asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
+                    asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                }
+                unsigned o[NS];
+                split_pair<NS, DT>(v0, v1, o);
+#pragma unroll
+                for (int p = 0; p < NS; ++p) pk[p][i] = o[p];
             }
 #pragma unroll
-            for (int p = 0; p < NS; ++p)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xin[2 * rb + t][p][j] = pl[j][p];
+            for (int p = 0; p < NS; ++p) xin[2 * rb + t][p] = __builtin_bit_cast(bf16x8, pk[p]);
             if constexpr (RELU && MASK) {
                 const u32x4 hv = __builtin_bit_cast(u32x4, xin[2 * rb + t][0]);
                 unsigned m = 0;
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         bf16x8 xin[KKH][NS];
         // ---- layer 0: gamma(x) from the PE image ----
         ch_bias<NRB>(acc, biasl + N::f32_b_trunk, h);
-        ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, N::KKX, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
+        ch_phase<N, NS, DT, HAS_ALPHA, NRB, SC::GT, N::KKX / SC::GT, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
         ch_convert<NS, DT, true, NRB, KKH, stash_on>(acc, xin, mrow(0), lane);
         PROF_T(t_trunk);
         // ---- layers 1 .. NL-1 ----
@@ -501,9 +511,9 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         for (int l = 1; l < NL; ++l) {
             ch_bias<NRB>(acc, biasl + N::f32_b_trunk + l * HW, h);
             if (l == N::SKIP)
-                ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, N::KKX, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
+                ch_phase<N, NS, DT, HAS_ALPHA, NRB, SC::GT, N::KKX / SC::GT, B_PEX, true, 0, KKH>(cx, acc, xin, peimg, row);
             PROF_T(t_ph);
-            ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, KKH, B_REG, true, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
+            ch_phase<N, NS, DT, HAS_ALPHA, NRB, SC::GT, KKH / SC::GT, B_REG, true, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
                                                                                  A.h0 + (l - 1) * A.h_stride + wpt * HW, A.plane_h);
             PROF_ADD(3, t_ph);
             PROF_T(t_cv);
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         PROF_ADD(2, t_trunk);
         // ---- feature head (no activation) and alpha head, both on h_{NL-1} ----
         ch_bias<NRB>(acc, biasl + N::f32_b_feat, h);
-        ch_phase<N, NS, DT, HAS_ALPHA, NRB, 1, KKH, B_REG, false, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
+        ch_phase<N, NS, DT, HAS_ALPHA, NRB, SC::GT, KKH / SC::GT, B_REG, false, 0, KKH, SPK, HW>(cx, acc, xin, peimg, row, tile_w,
                                                                               A.h0 + (NL - 1) * A.h_stride + wpt * HW, A.plane_h);
         float alpha = 0.f;
         if constexpr (HAS_ALPHA) {
@@ -551,6 +561,289 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     }
 #endif
     wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
+}
+
+// ----------------------------------------------------------------------------
+// backward chain: dZ_{l-1} = relu'(h_{l-1}) * (W_l^T dZ_l), down to d/d(point), d/d(viewdir)
+// ----------------------------------------------------------------------------
+// Same organisation as the forward (autograd of utils/run_lushnerf_helpers.py:394-423, 483-512): a wave
+// keeps the gradient of its 32 points in registers from d_raw to d gamma; the transposed weights (bwd2
+// copy, rows permuted by chain_row()) stream through the LDS ring.  Every segment is cut into positions
+// of exactly NRB fragments (the 64-row d gamma(x) segments as 2 row blocks x NRB/2 k-blocks, the 32-row
+// d gamma(d) segment as 1 x NRB), so the stream is uniform: position p at p * SLOT, WRAP positions per tile.
+// Writes the dZ arrays the weight-gradient GEMMs read ([plane][point][cols] rows, through the same
+// per-wave LDS transposition as the forward stash).
+constexpr int BW_DPE_LD = 100;      // fp32 words per point in the d(gamma) scratch (96 used)
+
+template <class N, int NS>
+struct BwSched {
+    static constexpr int GT = NS == 1 ? 2 : 1;                           // k-blocks per full-width position (see ChSched)
+    static constexpr int TRUNK_PIECES = N::NRB * NS * GT;
+    static constexpr int SLOT = TRUNK_PIECES * 1024;
+    static constexpr int trunk_wait = (CH_S - 2) * TRUNK_PIECES / 4;
+    static constexpr int G_X = N::NRB * GT / 2, G_D = N::NRB * GT;       // k-blocks per position of the 2- and 1-row-block segments
+    static constexpr int NP_VA = N::KKV / GT, NP_VB = N::KVB / G_D, NP_H = N::KKH / GT, NP_X = N::KKH / G_X;
+    static constexpr int WRAP = NP_VA + NP_VB + NP_H * N::NL + (N::SKIP > 0 ? NP_X : 0) + NP_X;
+    static_assert(N::KKV % GT == 0 && N::KVB % G_D == 0 && N::KKH % G_X == 0 && TRUNK_PIECES % 4 == 0, "backward stream positions must be uniform");
+    static_assert((N::bwd_END - N::bwd_VAT) == WRAP * N::NRB * GT, "backward segments must tile into whole positions");
+    static constexpr int tail_pieces(int) { return TRUNK_PIECES; }     // (unused: every phase is TRUNK)
+    static constexpr unsigned tail_off(int) { return 0; }
+    static constexpr int tail_wait(int) { return trunk_wait; }
+};
+
+// acc (* stored ReLU decision) -> NS planes, the next B operand
+template <int NS, bool MASKED, int NB, int KX>
+__device__ __forceinline__ void bw_convert(const f32x16 (&acc)[NB], bf16x8 (&xin)[KX][NS], const unsigned (&mw)[NB]) {
+    static_assert(2 * NB <= KX, "gradient planes do not fit");
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // stored decisions of the 8 values as 0/1 halfword pairs: X bit 2i = value 2i, bit 2i+16 = value 2i+1
+            unsigned X = 0;
+            if (MASKED) {
+                const unsigned b = (mw[rb] >> (8 * t)) & 0xFFu;
+                X = b | (b << 15);
+            }
+            u32x4 pk[NS];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned o[NS];
+                split_pair<NS, DT_BF16>(acc[rb][8 * t + 2 * i], acc[rb][8 * t + 2 * i + 1], o);
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    if (MASKED) {   // x * {0,1} per halfword: zero where the ReLU was off (planes of a dropped value are both dropped)
+                        const unsigned y = (X >> (2 * i)) & 0x00010001u;
+                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o[p]) : "v"(o[p]), "v"(y));
+                    }
+                    pk[p][i] = o[p];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NS; ++p) xin[2 * rb + t][p] = __builtin_bit_cast(bf16x8, pk[p]);
+        }
+}
+
+template <int NB>
+__device__ __forceinline__ void bw_zero(f32x16 (&acc)[NB]) {
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
+}
+
+// all KB k-blocks x NS planes of xin to stash rows, outside any GEMM phase (4 k-blocks per pass through the wave's tile)
+template <int NS, int KB, int KX, int LD>
+__device__ __forceinline__ void bw_stash_all(const bf16x8 (&xin)[KX][NS], char* tile, __bf16* rows, long long plane, int lane) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < KB / 4; ++j)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+                *reinterpret_cast<u32x4*>(tile + n * 128 + (((2 * kq + hh) ^ (n & 7)) << 4)) = __builtin_bit_cast(u32x4, xin[4 * j + kq][p]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + (lane >> 3);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rows + p * plane + (long long)row * LD + j * 64 + (lane & 7) * 8));
+            }
+        }
+}
+
+template <class N, int NS, bool HAS_ALPHA>
+__global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A) {
+    using SC = BwSched<N, NS>;
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, NRB = N::NRB, NRBV = N::NRBV, KKH = N::KKH, KKV = N::KKV;
+    constexpr int PARTS = CH_NT / CH_MT;
+    constexpr int DT = DT_BF16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                              // [CH_S][SLOT]
+    char* stage = smem + CH_S * SC::SLOT;                           // [4 waves][4 KiB]
+    float* dpe = reinterpret_cast<float*>(stage + CH_NW * 4096);    // [128][BW_DPE_LD]
+    float* dxbuf = dpe + CH_MT * BW_DPE_LD;                         // [PARTS][128][6]
+    float* wtab = dxbuf + PARTS * CH_MT * 6;                        // w_rgb [3][HV] | w_alpha [HW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const char* wbase = reinterpret_cast<const char*>(A.wpk);
+    {
+        const float* f32 = reinterpret_cast<const float*>(wbase + (long long)N::total_entries * NS * 1024);
+        for (int i = tid; i < 3 * HV + HW; i += CH_NT) wtab[i] = f32[N::f32_w_rgb + i];   // w_rgb then w_alpha are adjacent
+    }
+    static_assert(N::f32_w_alpha == N::f32_w_rgb + 3 * N::HV, "head matrices must be adjacent in the fp32 block");
+    const float* w_rgb = wtab;
+    const float* w_alpha = wtab + 3 * HV;
+    ChCtx cx;
+    cx.ring = ring;
+    cx.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    cx.gbase = wbase + (long long)N::bwd2_base * NS * 1024;
+    cx.cslot = 0;
+    cx.trunk_pos = 0;
+    cx.w = w;
+    cx.lane = lane;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
+#pragma unroll
+    for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
+    char* tile_w = stage + w * 4096;
+    const int row = w * 32 + n;
+    // VBT's K is zero-padded to KVB k-blocks: the planes it multiplies by 0 must hold finite values from the start
+    bf16x8 xin[KKH][NS];
+#pragma unroll
+    for (int kb = 0; kb < KKH; ++kb)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xin[kb][p][j] = (__bf16)0.f;
+
+#ifdef LUSH_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * CH_MT;
+        const long long gpt = pt0 + row;
+        const long long wpt = pt0 + w * 32;
+        const long long blk = pt0 / 32 + w;
+        cx.trunk_pos = 0;
+        {
+            unsigned long long gb = (unsigned long long)cx.gbase;
+            asm volatile("" : "+s"(gb));
+            cx.gbase = (const char*)gb;
+        }
+        auto mask_words = [&](unsigned (&mw)[NRB], int ml, int nb) {
+            const unsigned short* m = reinterpret_cast<const unsigned short*>(A.mask + ((blk * N::n_mask_layers + ml) * NRB) * 16) + lane;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) mw[rb] = rb < nb ? (unsigned)m[rb * 64] : 0u;
+        };
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gpt < A.P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
+        wait_vm<0>();          // first tile: the prologue DMAs (later tiles: published by the last mid-step)
+        lds_barrier();         // also orders wtab and the previous tile's dpe/dxbuf traffic
+
+        f32x16 acc[NRB];
+        f32x16 apx[2], apd[1];
+        bw_zero<2>(apx);
+        bw_zero<1>(apd);
+        unsigned mw[NRB];
+        // ---- dZv = (Wrgb^T d_rgb) * relu'(hv)   (K = 3: rank-3 update on the VALU) ----
+        mask_words(mw, NL, NRBV);
+        {
+            f32x16 av[NRBV];
+#pragma unroll
+            for (int rb = 0; rb < NRBV; ++rb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int f = 32 * rb + 16 * (q >> 3) + 8 * h + (q & 7);
+                    av[rb][q] = w_rgb[f] * dr.x + w_rgb[HV + f] * dr.y + w_rgb[2 * HV + f] * dr.z;
+                }
+            unsigned mv[NRBV];
+#pragma unroll
+            for (int rb = 0; rb < NRBV; ++rb) mv[rb] = mw[rb];
+            bw_convert<NS, true, NRBV, KKH>(av, xin, mv);
+        }
+        // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
+        bw_zero<NRB>(acc);
+        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, HV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * HV, A.plane_hv);
+        ChPhase<SC, NS, DT, 1, SC::G_D, SC::NP_VB, B_REG, true, 0, KKH, 0, 1>::run(cx, apd, xin, nullptr, row, nullptr, nullptr, 0);
+        {
+            unsigned none[NRB];
+            bw_convert<NS, false, NRB, KKH>(acc, xin, none);
+        }
+        // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
+        mask_words(mw, NL - 1, NRB);
+        bw_zero<NRB>(acc);
+        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_H, B_REG, true, 0, KKH, NS, HW>::run(cx, acc, xin, nullptr, row, tile_w, A.dfeat + wpt * HW, A.plane_h);
+        if constexpr (HAS_ALPHA) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[rb][q] += w_alpha[32 * rb + 16 * (q >> 3) + 8 * h + (q & 7)] * dr.w;
+        }
+        bw_convert<NS, true, NRB, KKH>(acc, xin, mw);
+        // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
+#pragma unroll 1
+        for (int l = NL - 1; l >= 1; --l) {
+            mask_words(mw, l - 1, NRB);
+            if (l == N::SKIP)     // gamma(x) rows of the skip layer's input
+                ChPhase<SC, NS, DT, 2, SC::G_X, SC::NP_X, B_REG, true, 0, KKH, 0, 1>::run(cx, apx, xin, nullptr, row, nullptr, nullptr, 0);
+            bw_zero<NRB>(acc);
+            PROF_T(t_ph);
+            ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_H, B_REG, true, 0, KKH, NS, HW>::run(cx, acc, xin, nullptr, row, tile_w,
+                                                                                      A.dz0 + l * A.dz_stride + wpt * HW, A.plane_h);
+            PROF_ADD(3, t_ph);
+            PROF_T(t_cv);
+            bw_convert<NS, true, NRB, KKH>(acc, xin, mw);
+            asm volatile("" ::"v"(xin[0][0]), "v"(xin[KKH - 1][0]));
+            PROF_ADD(4, t_cv);
+        }
+        PROF_T(t_pe);
+        // ---- layer 0: d gamma(x) += W_0^T dZ_0 ----
+        ChPhase<SC, NS, DT, 2, SC::G_X, SC::NP_X, B_REG, true, 0, KKH, 0, 1>::run(cx, apx, xin, nullptr, row, nullptr, nullptr, 0);
+        bw_stash_all<NS, KKH, KKH, HW>(xin, tile_w, A.dz0 + wpt * HW, A.plane_h, lane);
+        // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos) ----
+        {
+            float* g = dpe + row * BW_DPE_LD + 8 * h;       // this lane's columns: 32b + 16t + 8h + (0..7)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x16& a = b < 2 ? apx[b] : apd[0];
+                    f32x4 v0 = {a[8 * t], a[8 * t + 1], a[8 * t + 2], a[8 * t + 3]};
+                    f32x4 v1 = {a[8 * t + 4], a[8 * t + 5], a[8 * t + 6], a[8 * t + 7]};
+                    *reinterpret_cast<f32x4*>(g + 32 * b + 16 * t) = v0;
+                    *reinterpret_cast<f32x4*>(g + 32 * b + 16 * t + 4) = v1;
+                }
+        }
+        lds_barrier();
+        {
+            const int pt = tid % CH_MT, part = tid / CH_MT;
+            const long long gp = pt0 + pt;
+            float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+            if (gp < A.P) point_of(A.rays, A.z, A.S, gp, x, d);
+            float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+            const float* g = dpe + pt * BW_DPE_LD;
+            for (int u = part; u < L_X + L_D; u += PARTS) {
+                const bool isd = u >= L_X;
+                const int k = isd ? u - L_X : u;
+                const int base = isd ? PE_X : 0;
+                const float f = (float)(1 << k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float v = isd ? d[i] : x[i];
+                    float sn, cs;
+                    sincosf(v * f, &sn, &cs);
+                    float t = f * (cs * g[base + 3 + 6 * k + i] - sn * g[base + 3 + 6 * k + 3 + i]);
+                    if (k == 0) t += g[base + i];
+                    if (isd) gd[i] += t; else gx[i] += t;
+                }
+            }
+            float* o = dxbuf + (part * CH_MT + pt) * 6;
+            o[0] = gx[0]; o[1] = gx[1]; o[2] = gx[2]; o[3] = gd[0]; o[4] = gd[1]; o[5] = gd[2];
+        }
+        lds_barrier();
+        for (int i = tid; i < CH_MT * 6; i += CH_NT) {
+            const int pt = i / 6, c = i % 6;
+            float sum = 0.f;
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) sum += dxbuf[(p * CH_MT + pt) * 6 + c];
+            const long long gp = pt0 + pt;
+            if (gp < A.P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum;
+        }
+        PROF_ADD(1, t_pe);
+    }
+#ifdef LUSH_PROF
+    if (blockIdx.x == 0 && tid == 0) {
+        prof[0] = __builtin_amdgcn_s_memtime() - t_kernel;
+        for (int i = 0; i < 8; ++i) lush_prof[i] = prof[i];
+    }
+#endif
+    wait_vm<0>();
 }
 
 // ----------------------------------------------------------------------------
@@ -623,6 +916,46 @@ int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, hipStream_t s
         if (planes == 2) return launch_chain_k<NetNoise, 2, false, DT_BF16>(a, s);
     }
     return set_error("launch_mlp_chain_fwd: bad net/planes");
+}
+
+template <class N, int NS, bool HAS_ALPHA>
+static int launch_chain_bwd_k(const MlpBwdArgs& a, hipStream_t s) {
+    auto k = mlp_chain_bwd_kernel<N, NS, HAS_ALPHA>;
+    const size_t lds = (size_t)CH_S * BwSched<N, NS>::SLOT + (size_t)CH_NW * 4096 + (size_t)CH_MT * BW_DPE_LD * 4 +
+                       (size_t)(CH_NT / CH_MT) * CH_MT * 6 * 4 + (size_t)(3 * N::HV + N::HW) * 4;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        LUSH_HIP(hipGetDevice(&dev));
+        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+    }
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+// 1 and 2 planes run on the chain kernel (128-point tiles); 3 planes keep mlp_bwd_kernel.  LUSH_BWD_OLD=1 forces the old kernel.
+bool mlp_bwd_chain_enabled(int planes) {
+    static int old = -1;
+    if (old < 0) {
+        const char* e = getenv("LUSH_BWD_OLD");
+        old = (e && e[0] == '1') ? 1 : 0;
+    }
+    return !old && (planes == 1 || planes == 2);
+}
+
+int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s) {
+    if (net == 0) {
+        if (planes == 1) return launch_chain_bwd_k<NetNerf, 1, true>(a, s);
+        if (planes == 2) return launch_chain_bwd_k<NetNerf, 2, true>(a, s);
+    } else {
+        if (planes == 1) return launch_chain_bwd_k<NetNoise, 1, false>(a, s);
+        if (planes == 2) return launch_chain_bwd_k<NetNoise, 2, false>(a, s);
+    }
+    return set_error("launch_mlp_chain_bwd: bad net/planes");
 }
 
 }  // namespace lush

@@ -27,3 +27,21 @@ for mode, stash in ((2, False), (2, True), (17, False)):
     ms = a.elapsed_time(e)
     v = list(out)
     print(f"mode={mode} stash={stash} ms={ms:.3f} kernel_cycles={v[0]} -> {v[0]/ms/1e3:.0f} MHz; pe={v[1]} trunk(l1..7)={v[2]} phases={v[3]} conv={v[4]}  per-tile: total={v[0]/80:.0f} phase/layer={v[3]/80/7:.0f} conv/layer={v[4]/80/7:.0f}")
+
+# backward chain kernel
+import ctypes as C
+for nf, nb in ((2, 1), (2, 2)):
+    pk = ops.mlp_pack(0, nf, tens); pkb = ops.mlp_pack(0, nb, tens)
+    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb))
+    draw = torch.randn(R * S, 4, device=dev) * 1e-3
+    dstash = torch.empty(L.lush_mlp_dstash_bytes(0, nb, R * S), dtype=torch.uint8, device=dev)
+    dpts = torch.empty(R * S, 8, device=dev)
+    st = lib.mlp_struct(tens, 8)
+    for _ in range(2):
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        lib.call("lush_mlp_bwd_chain", 0, ops.stash_code(nf, nb), nb, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pkb), C.byref(st),
+                 lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), ops._stream())
+        e.record(); torch.cuda.synchronize()
+    out = (C.c_ulonglong * 8)(); L.lush_debug_prof(out); v = list(out); ms = a.elapsed_time(e)
+    print(f"bwd planes={nb} ms={ms:.3f} kernel_cycles={v[0]} -> {v[0]/ms/1e3:.0f} MHz; per tile: total={v[0]/80:.0f} pe_bwd={v[1]/80:.0f} phase/layer={v[3]/80/7:.0f} conv/layer={v[4]/80/7:.0f}")
