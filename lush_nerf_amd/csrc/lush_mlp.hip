@@ -639,7 +639,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_kernel(const MlpBwdArgs A) {
                 for (int i = 0; i < 3; ++i) {
                     const float v = isd ? d[i] : x[i];
                     float s, c;
-                    sincosf(v * f, &s, &c);
+                    lush_sincos(v * f, &s, &c);
                     float t = f * (c * g[base + 3 + 6 * k + i] - s * g[base + 3 + 6 * k + 3 + i]);
                     if (k == 0) t += g[base + i];
                     if (isd) gd[i] += t; else gx[i] += t;

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
                 for (int i = 0; i < 3; ++i) {
                     const float v = isd ? d[i] : x[i];
                     float sn, cs;
-                    sincosf(v * f, &sn, &cs);
+                    lush_sincos(v * f, &sn, &cs);
                     float t = f * (cs * g[base + 3 + 6 * k + i] - sn * g[base + 3 + 6 * k + 3 + i]);
                     if (k == 0) t += g[base + i];
                     if (isd) gd[i] += t; else gx[i] += t;
