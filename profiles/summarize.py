@@ -18,6 +18,7 @@ planes = ("h" if _pf.startswith("fp16") else _pf.replace("bf16x", "")) + "," + _
 steps = bench.get("steps", 4) + bench.get("warmup", 2)
 
 GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
+         "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "dw_gemm_kernel": "mlp_bwd_weights", "dw_gemm_dma_kernel": "mlp_bwd_weights", "head_dw_kernel": "mlp_bwd_weights"}
 
 
