@@ -153,6 +153,8 @@ def main():
         sp = ops.nplanes(ops.stash_code(pf, pb))
         bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH + 16 + 44 / 64, "mlp_bwd_chain": pb * BYTES_DZ_STASH + 288 + 16 + 32,
                       "mlp_bwd_weights": pb * (BYTES_X_STASH + BYTES_DZ_STASH)}
+        per_prod = lambda c: {1: 1, 2: 3, 3: 6}[ops.nplanes(c)]
+        mfma_mult = {"mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
         kern = {}
         for g, d in groups.items():
             if g not in bytes_eval:
@@ -164,7 +166,9 @@ def main():
             kern[g] = {"launches_per_step": d["launches"] / steps, "avg_ms": round(avg_ms, 4),
                        "ms_per_step": round(d["ms"] / steps, 3), "tflops_algorithmic": round(tf, 1),
                        "hbm_gbs_algorithmic": round(gbs, 1), "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 4),
-                       "frac_hbm": round(gbs / PEAK_HBM_GBS, 4)}
+                       "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+                       # plane products: the matrix pipe executes 1 / 3 / 6 MFMAs per algorithmic product
+                       "frac_mfma_executed": round(tf * mfma_mult[g] / PEAK_BF16_TFLOPS, 4)}
         return kern
 
     pf, pb = ops.parse_planes(a.planes)
@@ -184,7 +188,7 @@ def main():
         roof = None
         if dom:
             k = kern[dom]
-            hbm_bound = k["frac_hbm"] >= k["frac_mfma"]      # the roof this kernel would hit first
+            hbm_bound = k["frac_hbm"] >= k["frac_mfma_executed"]      # the roof this kernel would hit first
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
@@ -193,8 +197,11 @@ def main():
                     "achieved": k["hbm_gbs_algorithmic"] if hbm_bound else k["tflops_algorithmic"],
                     "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": k["frac_hbm"] if hbm_bound else k["frac_mfma"], "traffic": traffic,
+                    "executed_mfma_frac": k["frac_mfma_executed"],
                     "note": "dominant kernel group by time; achieved = algorithmic bytes (or 2*593408 FLOP) per MLP "
-                            "evaluation x evaluations per launch / average launch time from HIP events on the launch stream"}
+                            "evaluation x evaluations per launch / average launch time from HIP events on the launch stream; "
+                            "the bound is the roof the kernel hits first counting the MFMAs it executes per product "
+                            "(3 with 2 bf16 planes), frac stays algorithmic"}
         dtype = {1: "bf16", 2: "bf16 MFMA, operands split in 2 bf16 planes (~2^-17, fp32-equivalent outputs), fp32 accumulate",
                  3: "bf16 MFMA, 3 planes (~fp32), fp32 accumulate",
                  ops.PLANES_F16: "fp16 MFMA forward (one plane, outputs within 3e-5 of fp32), fp32 accumulate"}[pf]
