@@ -117,7 +117,11 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
     R, S = z.shape
     dev = rays.device
     dstash = torch.empty(lib.load().lush_mlp_dstash_bytes(net, planes_b, R * S), dtype=torch.uint8, device=dev)
-    grads = [torch.zeros_like(t) for t in tensors]
+    flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=dev)   # one zero-fill for all of them
+    grads, o = [], 0
+    for t in tensors:
+        grads.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
     dpts = torch.empty(R * S, 8, dtype=torch.float32, device=dev)
     st, gs = lib.mlp_struct(tensors, _NL[net]), lib.mlp_struct(grads, _NL[net])
     timed = TIMER is not None and net == NET_NERF
@@ -307,7 +311,7 @@ class March(torch.autograd.Function):
             grads_c = run(ctx.coarse, sv["zc"], sv["raw_c"], sv["noise_c"], sv["stash_c"], g_c)
         ctx.saved = None
         if fine_on and ctx.fine is ctx.coarse and grads_f:
-            grads_c = [a + b if a is not None else b for a, b in zip(grads_c, grads_f)]
+            grads_c = [(a + b if b is not None else a) if a is not None else b for a, b in zip(grads_c, grads_f)]
             grads_f = []
         n_fine = ctx.n_params - ctx.n_coarse
         out_f = list(grads_f) if grads_f else [None] * n_fine
