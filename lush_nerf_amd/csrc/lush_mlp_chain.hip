@@ -400,9 +400,10 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v0 = acc[rb][8 * t + 2 * i], v1 = acc[rb][8 * t + 2 * i + 1];
-                if (RELU) {
-                    asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
-                    asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                if (RELU) {   // on the bit patterns: max_i32(bits, 0) is +0 for every negative float and -0, identity otherwise
+                              // (a float max would add a canonicalising second v_max; inline asm draws hazard nops)
+                    v0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v0), 0));
+                    v1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v1), 0));
                 }
                 unsigned o[NS];
                 split_pair<NS, DT>(v0, v1, o);
