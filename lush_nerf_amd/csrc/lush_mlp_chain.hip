@@ -43,7 +43,6 @@ enum { B_REG = 0, B_PEX = 1, B_PED = 2 };     // where a phase takes its B opera
 // the "tail" list is FEAT | ALPHA | VA | VB | RGB | first CH_S positions of the next tile.
 template <class N, int NS, bool HAS_ALPHA>
 struct ChSched {
-    static constexpr int grp(int nrb) { return nrb * NS >= 4 ? 1 : 4 / (nrb * NS); }
     static constexpr int ENTRY = NS * 1024;
     // trunk positions hold GT k-blocks: with one plane a single k-block is only 8 MFMAs per wave, too
     // little to cover the LDS latency of the next half's fragments
@@ -52,26 +51,35 @@ struct ChSched {
     static constexpr int SLOT = TRUNK_PIECES * 1024;
     static constexpr int PT = (N::KKX + (N::NL - 1) * N::KKH + (N::SKIP > 0 ? N::KKX : 0)) / GT;
     static_assert(N::KKX % GT == 0 && N::KKH % GT == 0, "trunk k-blocks must group evenly");
-    static constexpr int G_A = grp(1), G_V = grp(N::NRBV), G_R = grp(1);
+    // narrow segments: as many k-blocks per position as fit a slot (fewer positions = fewer barriers), dividing K
+    static constexpr int grp(int nrb, int kk) {
+        int g = 1;
+        for (int c = 1; c <= kk; ++c)
+            if (kk % c == 0 && nrb * NS * c <= TRUNK_PIECES) g = c;
+        return g;
+    }
+    static constexpr int G_A = grp(1, N::KKH), G_VA = grp(N::NRBV, N::KKH), G_VB = grp(N::NRBV, N::KKD), G_R = grp(1, N::KKV);
     static constexpr int NP_F = N::KKH / GT;
     static constexpr int NP_A = HAS_ALPHA ? N::KKH / G_A : 0;
-    static constexpr int NP_VA = N::KKH / G_V, NP_VB = N::KKD / G_V, NP_R = N::KKV / G_R;
+    static constexpr int NP_VA = N::KKH / G_VA, NP_VB = N::KKD / G_VB, NP_R = N::KKV / G_R;
     static constexpr int T_A = NP_F, T_VA = T_A + NP_A, T_VB = T_VA + NP_VA, T_R = T_VB + NP_VB, T_END = T_R + NP_R;
     static_assert(N::fwd_FEAT == PT * N::NRB * GT, "FEAT must follow the trunk in the stream");
-    static_assert(TRUNK_PIECES % 4 == 0 && N::KKH % G_A == 0 && N::KKH % G_V == 0 && N::KKD % G_V == 0 && N::KKV % G_R == 0,
-                  "stream positions must be whole multiples of 4 pieces");
+    static_assert(TRUNK_PIECES % 4 == 0 && (NS * G_A) % 4 == 0 && (N::NRBV * NS * G_VA) % 4 == 0 && (N::NRBV * NS * G_VB) % 4 == 0 &&
+                      (NS * G_R) % 4 == 0, "stream positions must be whole multiples of 4 pieces");
+    static_assert(G_A % 2 == 0 && (N::NRBV * G_VA) % 2 == 0 && (N::NRBV * G_VB) % 2 == 0 && G_R % 2 == 0, "a position needs an even number of units");
     static constexpr int tail_pieces(int t) {
         if (t < T_A) return TRUNK_PIECES;
         if (t < T_VA) return NS * G_A;
-        if (t < T_R) return N::NRBV * NS * G_V;
+        if (t < T_VB) return N::NRBV * NS * G_VA;
+        if (t < T_R) return N::NRBV * NS * G_VB;
         if (t < T_END) return NS * G_R;
         return TRUNK_PIECES;
     }
     static constexpr unsigned tail_off(int t) {        // bytes from the start of the stream
         if (t < T_A) return (unsigned)(PT + t) * SLOT;
         if (t < T_VA) return (unsigned)N::fwd_ALPHA * ENTRY + (unsigned)(t - T_A) * G_A * ENTRY;
-        if (t < T_VB) return (unsigned)N::fwd_VA * ENTRY + (unsigned)(t - T_VA) * (N::NRBV * G_V) * ENTRY;
-        if (t < T_R) return (unsigned)N::fwd_VB * ENTRY + (unsigned)(t - T_VB) * (N::NRBV * G_V) * ENTRY;
+        if (t < T_VB) return (unsigned)N::fwd_VA * ENTRY + (unsigned)(t - T_VA) * (N::NRBV * G_VA) * ENTRY;
+        if (t < T_R) return (unsigned)N::fwd_VB * ENTRY + (unsigned)(t - T_VB) * (N::NRBV * G_VB) * ENTRY;
         if (t < T_END) return (unsigned)N::fwd_RGB * ENTRY + (unsigned)(t - T_R) * G_R * ENTRY;
         return (unsigned)(t - T_END) * SLOT;
     }
@@ -428,6 +436,27 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
     }
 }
 
+// The first SP planes of KB k-blocks of xin to stash rows, outside any GEMM phase (4 k-blocks per pass through the wave's tile).
+template <int NS, int SP, int KB, int KX, int LD>
+__device__ __forceinline__ void ch_stash_all(const bf16x8 (&xin)[KX][NS], char* tile, __bf16* rows, long long plane, int lane) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < KB / 4; ++j)
+#pragma unroll
+        for (int p = 0; p < SP; ++p) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+                *reinterpret_cast<u32x4*>(tile + n * 128 + (((2 * kq + hh) ^ (n & 7)) << 4)) = __builtin_bit_cast(u32x4, xin[4 * j + kq][p]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + (lane >> 3);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rows + p * plane + (long long)row * LD + j * 64 + (lane & 7) * 8));
+            }
+        }
+}
+
 template <class N, int NS, bool HAS_ALPHA, int DT, int SPK>
 __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A) {
     using SC = ChSched<N, NS, HAS_ALPHA>;
@@ -537,15 +566,15 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
         f32x16 av[NRBV];
         ch_bias<NRBV>(av, biasl + N::f32_b_views, h);
-        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_V, SC::NP_VA, B_REG, false, SC::T_VA, KKH, SPK, HW>(cx, av, xin, peimg, row, tile_w,
+        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VA, SC::NP_VA, B_REG, false, SC::T_VA, KKH, SPK, HW>(cx, av, xin, peimg, row, tile_w,
                                                                                                 A.feat + wpt * HW, A.plane_h);
-        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_V, SC::NP_VB, B_PED, false, SC::T_VB, KKH>(cx, av, xin, peimg, row);
+        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VB, SC::NP_VB, B_PED, false, SC::T_VB, KKH>(cx, av, xin, peimg, row);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(av, xin, mrow(NL), lane);
         // ---- rgb head ----
         f32x16 ar[1];
         ch_bias<1>(ar, biasl + N::f32_b_rgb, h);
-        ch_phase<N, NS, DT, HAS_ALPHA, 1, SC::G_R, SC::NP_R, B_REG, false, SC::T_R, KKH, SPK, HV>(cx, ar, xin, peimg, row, tile_w,
-                                                                                         A.hv + wpt * HV, A.plane_hv);
+        if constexpr (SPK > 0) ch_stash_all<NS, SPK, N::KKV, KKH, HV>(xin, tile_w, A.hv + wpt * HV, A.plane_hv, lane);
+        ch_phase<N, NS, DT, HAS_ALPHA, 1, SC::G_R, SC::NP_R, B_REG, false, SC::T_R, KKH>(cx, ar, xin, peimg, row);
         if (h == 0 && gpt < A.P) {
             float4 o;
             o.x = ar[0][0];
@@ -637,22 +666,7 @@ __device__ __forceinline__ void bw_zero(f32x16 (&acc)[NB]) {
 // all KB k-blocks x NS planes of xin to stash rows, outside any GEMM phase (4 k-blocks per pass through the wave's tile)
 template <int NS, int KB, int KX, int LD>
 __device__ __forceinline__ void bw_stash_all(const bf16x8 (&xin)[KX][NS], char* tile, __bf16* rows, long long plane, int lane) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const int n = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < KB / 4; ++j)
-#pragma unroll
-        for (int p = 0; p < NS; ++p) {
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq)
-                *reinterpret_cast<u32x4*>(tile + n * 128 + (((2 * kq + hh) ^ (n & 7)) << 4)) = __builtin_bit_cast(u32x4, xin[4 * j + kq][p]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 8 * i + (lane >> 3);
-                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rows + p * plane + (long long)row * LD + j * 64 + (lane & 7) * 8));
-            }
-        }
+    ch_stash_all<NS, NS, KB, KX, LD>(xin, tile, rows, plane, lane);
 }
 
 template <class N, int NS, bool HAS_ALPHA>
