@@ -522,7 +522,7 @@ __device__ void rbk_dense(const float* W, const float* b, const float* x, int xs
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
+__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
                                                           float* __restrict__ acts) {
     const int ST = LUSH_RBK_ACT_STRIDE;
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) acts[(t / 64) * ST + RA_E + (t % 64)] = p.embed[t];
@@ -588,7 +588,7 @@ __device__ void rbk_dense_bwd_w(const float* dz, int zs, const float* x, int xs,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
+__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
                                                           float* __restrict__ sc) {
@@ -824,14 +824,14 @@ int lush_gen_rays(const float* c2w, const int64_t* view, const int64_t* px, cons
 
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
-    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(1), dim3(256), 0, S_(st), *p, num_img, M, window, acts);
+    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts);
     CHECK_LAUNCH();
     return 0;
 }
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
                      const float* d_rvw, const lush_rbk_grads* g, float* scratch, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
-    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(256), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
     CHECK_LAUNCH();
     return 0;
 }
