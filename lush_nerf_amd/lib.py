@@ -40,14 +40,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return SO_PATH
     # -ffp-contract=off: fp32 VALU expressions round op by op like the reference's torch ops
     # (o + d*z must not become one FMA: a 1-ulp point error is amplified x512 by the encoding).
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           *os.environ.get("LUSH_HIPCC_FLAGS", "").split(),
-           *[os.path.join(CSRC, f) for f in SOURCES], "-o", SO_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    # one hipcc -c per source, in parallel (the chain kernels alone take ~1 min), then one link
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *os.environ.get("LUSH_HIPCC_FLAGS", "").split()]
+    with tempfile.TemporaryDirectory(prefix="lush_build_") as tmp:
+        def compile_one(f):
+            obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
+            cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, f), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+            objs = list(ex.map(compile_one, SOURCES))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", SO_PATH + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     os.replace(SO_PATH + ".tmp", SO_PATH)
     return SO_PATH
 
