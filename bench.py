@@ -2,7 +2,10 @@
 """Training rays/s of the LuSh-NeRF ray-march hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  or plainly: with WORLD_SIZE unset, bench.py starts the N ranks itself as a child torch.distributed.run
+  BEFORE anything touches the GPU, and exits with the child's code.  It refuses to run when the RCCL world
+  size differs from --gpus or when fewer than N devices are present.
 
 One "step" = one optimisation step of BASELINE config 2 per GPU: poster_lushnerf,
 N_rand = 4096 input rays, N_samples 64 + N_importance 64, blur kernel (RBK/"DSK") on
@@ -46,35 +49,96 @@ def model_args(n_importance):
                               render_rmnearplane=80)
 
 
-def cpu_baseline(n_rand, n_samples, n_importance, steps=2):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores:
-    forward + loss + backward of the same kernel-on step on a bounded sample of rays."""
-    from lush_nerf_amd import synth
-    from oracle import lush_oracle as O
+def _host_cpu():
     cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))          # the cores this process may actually run on
     except Exception:
         pass
-    cores = min(cores, 16)          # a 1-GPU box owns a 16-core share of the host (gpurun contract)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, model
+
+
+def cpu_baseline(n_rand, n_samples, n_importance, steps=5, warmup=2, c1_steps=5):
+    """The oracle (CPU restatement of the reference path, parity-pinned against the reference's own outputs)
+    timed on this box's host cores, as SURVEY 8d / BASELINE.md section 3 plan it: all cores the process may use,
+    >= 2 warm-up and >= 5 timed steps, median; (a) the poster 64+64 kernel-on training step at N_rand 512
+    (forward + loss + backward) and (b) BASELINE config 1 (N_rand 256, 32+0, naive, entry render_infer)."""
+    from lush_nerf_amd import synth
+    from oracle import lush_oracle as O
+    cores, model = _host_cpu()
     torch.set_num_threads(cores)
     w = synth.all_weights(30, 0)
     p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in w.items()}
-    times = []
-    for s in range(steps + 1):
+
+    def timed(fn, n_warm, n_timed):
+        ts = []
+        for s in range(n_warm + n_timed):
+            t = time.perf_counter()
+            fn(s)
+            ts.append(time.perf_counter() - t)
+            for v in p.values():
+                v.grad = None
+        ts = sorted(ts[n_warm:])
+        return ts[len(ts) // 2]
+
+    def kernel_on(s):
         b = {k: torch.from_numpy(v) for k, v in synth.ray_batch(n_rand, 0, 30, step=s).items()}
         d = {k: torch.from_numpy(v) for k, v in synth.draws(n_rand * 5, n_samples, n_importance, 0, step=s).items()}
-        t = time.perf_counter()
         out = O.forward_train(p, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, b["rays"], b["images_idx"], n_samples,
                               n_importance, force_naive=False, allkernel=True, kernel_pixel=b["fq_mask"], draws=d)
         O.train_loss(out[0], out[1], b["target"]).backward()
-        times.append(time.perf_counter() - t)
-        for v in p.values():
-            v.grad = None
-    best = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": n_rand / best, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"N_rand={n_rand} (x5 marched), {n_samples}+{n_importance}, kernel on, fwd+bwd, "
-                      f"median of {steps} steps after 1 warm-up, torch CPU fp32"}
+
+    def config1(s):
+        b = {k: torch.from_numpy(v) for k, v in synth.ray_batch(256, 0, 30, step=s).items()}
+        d = {k: torch.from_numpy(v) for k, v in synth.draws(256, 32, 0, 0, step=s).items()}
+        batch = O.pack_rays(synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, b["rays"])
+        ret, _ = O.render_rays(p, batch, 32, retraw=True, perturb=1., N_importance=0, raw_noise_std=1., draws=d)
+        rgb = O.tonemap(ret["rgb_map"])
+        (0.5 * torch.mean((rgb - b["target"]) ** 2) + 0.5 * torch.mean(torch.abs(rgb - b["target"]))).backward()
+
+    t_k = timed(kernel_on, warmup, steps)
+    t_1 = timed(config1, warmup, c1_steps)
+    return {"value": n_rand / t_k, "unit": "rays/s", "cores": cores, "cpu_model": model, "kind": "port",
+            "sample": f"N_rand={n_rand} (x5 marched), {n_samples}+{n_importance}, blur kernel on, forward+loss+backward, "
+                      f"median of {steps} steps after {warmup} warm-up, torch CPU fp32, {cores} threads",
+            "s_per_step": round(t_k, 3),
+            "config1": {"value": 256 / t_1, "unit": "rays/s", "s_per_step": round(t_1, 4),
+                        "sample": f"BASELINE config 1: N_rand=256, 32+0, naive, entry render_rays/render_infer, forward+loss+"
+                                  f"backward, median of {c1_steps} after {warmup} warm-up"}}
+
+
+CONFIGS = {   # BASELINE.json configs (SURVEY 8d): input rays per GPU, N_samples, N_importance, blur kernel on, micro-batch
+    "C1": dict(n_rand=256, ns=32, ni=0, kernel=False, micro=0),
+    "C2": dict(n_rand=4096, ns=64, ni=64, kernel=True, micro=0),
+    "C3": dict(n_rand=8192, ns=64, ni=64, kernel=True, micro=0),
+    "C5": dict(n_rand=16384, ns=128, ni=128, kernel=True, micro=4096),
+}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher: start N fresh ranks as a CHILD torch.distributed.run.  Nothing in
+    this process has touched the GPU yet (torch.cuda.device_count() does not initialise it on this image), and the
+    process is never replaced: it waits for the child and exits with its code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -90,45 +154,72 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=0, help="input rays per forward+backward slice (0 = whole batch); "
                     "bounds the activation stash for the larger BASELINE configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n-rand", type=int, default=64)
+    ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
+    ap.add_argument("--config", type=str, default="C2", choices=["C2", "C3", "C5"],
+                    help="BASELINE config timed as the headline workload (C2 = the one the metric is quoted on)")
+    ap.add_argument("--extra", type=str, default=None, help="other BASELINE configs reported under extra_configs "
+                    "(default at 1 GPU: C1,C3,C5,eval; none on multi-GPU runs); empty to skip")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.config != "C2":
+        c = CONFIGS[a.config]
+        a.n_rand, a.n_samples, a.n_importance = c["n_rand"], c["ns"], c["ni"]
+        a.micro_batch = a.micro_batch or c["micro"]
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)                                   # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback of the product path)")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the reported n_gpus must be the RCCL world size")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py needs an MI355X per rank (no CPU fallback of the product path): rank {rank} has no device")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # the RCCL group exists at every N (at N = 1 the all-reduce is a one-rank collective): the timed path is the same code
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if dist.get_world_size() != a.gpus:
+        raise SystemExit(f"RCCL world size {dist.get_world_size()} != --gpus {a.gpus}")
 
     from lush_nerf_amd import lib, ops, synth
     from lush_nerf_amd.trainer import Trainer
     lib.load()
 
     n_batches = 4
-    batches = []
-    for s in range(n_batches):     # disjoint ray draws per rank; all resident before timing
-        b = synth.ray_batch(a.n_rand, seed=1000 + rank, step=s)
-        batches.append({k: torch.from_numpy(v).to(dev) for k, v in b.items()})
+    poses = torch.from_numpy(synth.poses(30, 1000 + rank)).to(dev)
+
+    def make_batches(n_rand):
+        """(view, pixel) draws + targets, disjoint per rank, resident in HBM before timing; the rays
+        themselves are generated on the device every step (lush_gen_rays)."""
+        out = []
+        for s in range(n_batches):
+            b = synth.pixel_batch(n_rand, seed=1000 + rank, step=s)
+            b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+            b["c2w"] = poses
+            out.append(b)
+        return out
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
     M = 5
-    evals_step = a.n_rand * M * (a.n_samples + (a.n_samples + a.n_importance if a.n_importance else 0))
 
-    def run_mode(pf, pb, steps, warmup):
-        net = make_model(model_args(a.n_importance), dev, ops.Precision(pf, pb))
-        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, a.n_samples, a.n_importance, kernel_start_iter=0,
-                     allkernel_start_iter=1 << 30, distributed=world > 1, micro_batch=a.micro_batch)
+    def evals_per_step(n_rand, ns, ni, kernel=True):
+        return n_rand * (M if kernel else 1) * (ns + (ns + ni if ni else 0))
+
+    def run_mode(pf, pb, steps, warmup, cfg=None):
+        """Time `steps` optimisation steps of one BASELINE config in one precision mode (max over ranks)."""
+        cfg = cfg or dict(n_rand=a.n_rand, ns=a.n_samples, ni=a.n_importance, kernel=True, micro=a.micro_batch)
+        batches = make_batches(cfg["n_rand"])
+        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb))
+        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, cfg["ns"], cfg["ni"], kernel_start_iter=0,
+                     allkernel_start_iter=1 << 30, distributed=True, micro_batch=cfg["micro"])
         for i in range(warmup):
             tr.step(batches[i % n_batches], i)
         ops.TIMER = ops.KernelTimer()
@@ -139,13 +230,68 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         timer, ops.TIMER = ops.TIMER, None
-        if world > 1:
-            tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-            dt = float(tdt.item())
-        del tr, net
+        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)       # the slowest rank's clock
+        dt = float(tdt.item())
+        fault = tr.faults()
+        if fault:
+            raise SystemExit(f"numerical fault during the timed steps: {net.fault_names(fault)}")
+        del tr, net, batches
         torch.cuda.empty_cache()
         return dt, timer.summary()
+
+    def run_c1(pf, pb, steps, warmup):
+        """BASELINE config 1 (N_rand 256, 32+0, naive): NeRFAll.forward cannot take N_importance = 0 (it indexes
+        extras['rgb0']), so the entry is render_infer, as in the reference's own CPU-runnable case."""
+        c = CONFIGS["C1"]
+        batches = make_batches(c["n_rand"])
+        net = make_model(model_args(0), dev, ops.Precision(pf, pb)).train()
+        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, c["ns"], 0, kernel_start_iter=1 << 30, distributed=True)
+        K = tr.K
+
+        def one(i):
+            b = batches[i % n_batches]
+            tr.flat.grad.zero_()
+            rays = ops.gen_rays(b["c2w"], b["view"], b["px"], b["py"], K)
+            (rgb, depth, acc, extras), noise = net.render_infer(
+                synth.H_DEF, synth.W_DEF, K, 1 << 15, rays=rays, perturb=1., N_importance=0, N_samples=c["ns"],
+                use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., retraw=True)
+            tm = net.tonemapping(rgb)
+            ops.TrainLoss.apply(tm, tm, b["target"]).backward()
+            a0, a1 = tr.flat.segments[0]
+            tr.steps[0] += 1
+            ops.adam_step(tr.flat.param[a0:a1], tr.flat.grad[a0:a1], tr.m[a0:a1], tr.v[a0:a1], tr.lr(), tr.steps[0])
+
+        ops.ACCUMULATE_INTO_PARAM_GRAD = True
+        try:
+            for i in range(warmup):
+                one(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one(warmup + i)
+            sync()
+        finally:
+            ops.ACCUMULATE_INTO_PARAM_GRAD = False
+        dt = time.perf_counter() - t0
+        del tr, net
+        return dt
+
+    def run_eval(pf, steps):
+        """NeRFAll.forward(poses=...) -> render_path, one 640x1120 pose per step, forward only."""
+        net = make_model(model_args(64), dev, ops.Precision(pf, 1)).eval()
+        K = [[synth.FOCAL_DEF, 0, synth.W_DEF / 2], [0, synth.FOCAL_DEF, synth.H_DEF / 2], [0, 0, 1]]
+        rk = dict(perturb=False, N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
+                  inference=True, near=0., far=1.)
+        net(synth.H_DEF, synth.W_DEF, K, chunk=1 << 15, poses=poses[:1], render_kwargs=dict(rk))
+        sync()
+        t0 = time.perf_counter()
+        net(synth.H_DEF, synth.W_DEF, K, chunk=1 << 15, poses=poses[1:1 + steps], render_kwargs=dict(rk))
+        sync()
+        dt = time.perf_counter() - t0
+        del net
+        torch.cuda.empty_cache()
+        return dt
 
     def kernel_table(groups, pf, pb, steps):
         """Per kernel group: average launch time (HIP events on the launch stream), algorithmic
@@ -172,6 +318,7 @@ def main():
         return kern
 
     pf, pb = ops.parse_planes(a.planes)
+    evals_step = evals_per_step(a.n_rand, a.n_samples, a.n_importance)
     dt, groups = run_mode(pf, pb, a.steps, a.warmup)
     others = []
     for m in [x for x in a.also.split(";") if x and x != a.planes]:
@@ -179,6 +326,29 @@ def main():
         osteps = max(2, a.steps // 2)
         odt, ogroups = run_mode(qf, qb, osteps, 1)
         others.append((m, qf, qb, odt, ogroups, osteps))
+    extra_names = [x for x in (a.extra if a.extra is not None else ("C1,C3,C5,eval" if world == 1 else "")).split(",") if x]
+    extras = {}
+    for name in extra_names:       # the other BASELINE configs with the SAME kernels and precision mode as the headline
+        if name == "eval":
+            n_pose = 2
+            edt = run_eval(pf, n_pose)
+            extras["eval"] = {"value": round(n_pose * synth.H_DEF * synth.W_DEF * world / edt, 1), "unit": "rays/s (forward only)",
+                              "s_per_pose": round(edt / n_pose, 4),
+                              "workload": "NeRFAll.forward(poses) -> render_path, 640x1120 rays per pose, 64+64, chunk 32768"}
+        elif name == "C1":
+            st = 20
+            cdt = run_c1(pf, pb, st, 3)
+            extras["C1"] = {"value": round(256 * world * st / cdt, 1), "unit": "rays/s", "ms_per_step": round(cdt / st * 1e3, 3),
+                            "workload": "N_rand=256, 32+0, naive, entry render_infer, fwd+bwd+Adam (launch-bound: 8 192 MLP evaluations)"}
+        elif name in CONFIGS and name != a.config:
+            c = CONFIGS[name]
+            st = 3 if name == "C3" else 2
+            cdt, cgroups = run_mode(pf, pb, st, 1, c)
+            extras[name] = {"value": round(c["n_rand"] * world * st / cdt, 1), "unit": "rays/s",
+                            "ms_per_step": round(cdt / st * 1e3, 3), "micro_batch": c["micro"] or c["n_rand"],
+                            "mlp_evals_per_step": evals_per_step(c["n_rand"], c["ns"], c["ni"]),
+                            "workload": f"N_rand={c['n_rand']} per GPU, {c['ns']}+{c['ni']}, blur kernel on, fwd+bwd+Adam",
+                            "kernels": kernel_table(cgroups, pf, pb, st)}
 
     if rank == 0:
         rays_per_s = a.n_rand * world * a.steps / dt
@@ -191,12 +361,13 @@ def main():
             hbm_bound = k["frac_hbm"] >= k["frac_mfma_executed"]      # the roof this kernel would hit first
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath):     # per-launch HBM bytes from the separate rocprofv3 --pmc passes of THIS command
                 traffic = json.load(open(tpath)).get(f"{dom}:{a.planes}")
             roof = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": k["hbm_gbs_algorithmic"] if hbm_bound else k["tflops_algorithmic"],
                     "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": k["frac_hbm"] if hbm_bound else k["frac_mfma"], "traffic": traffic,
+                    "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; not re-measured in this run)",
                     "executed_mfma_frac": k["frac_mfma_executed"],
                     "note": "dominant kernel group by time; achieved = algorithmic bytes (or 2*593408 FLOP) per MLP "
                             "evaluation x evaluations per launch / average launch time from HIP events on the launch stream; "
@@ -211,8 +382,9 @@ def main():
             "metric": "training rays/sec (fwd+bwd), N_samples=64+64", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"poster_lushnerf 1xMI355X N_rand={a.n_rand} N_samples={a.n_samples} "
-                                   f"N_importance={a.n_importance} blur kernel (DSK/RBK) on, fwd+bwd+Adam",
+            "config": {"workload": f"poster_lushnerf {world}xMI355X N_rand={a.n_rand}/GPU N_samples={a.n_samples} "
+                                   f"N_importance={a.n_importance} blur kernel (DSK/RBK) on, fwd+bwd+Adam, "
+                                   f"one RCCL all-reduce of the flat gradient (BASELINE config {a.config if world == 1 else '4' if a.config == 'C2' else a.config})",
                        "rays_per_gpu": a.n_rand, "marched_rays_per_gpu": a.n_rand * M, "mlp_evals_per_step": evals_step,
                        "planes_fwd": ("fp16x1" if pf == ops.PLANES_F16 else f"bf16x{pf}"), "planes_bwd": f"bf16x{pb}", "parallelism": f"dp{world}"},
             "step_tflops_algorithmic": round(flop_step * world * a.steps / dt / 1e12, 2),
@@ -228,12 +400,16 @@ def main():
                                 "ms_per_step": round(odt / osteps * 1e3, 3),
                                 "kernels": kernel_table(ogroups, qf, qb, osteps), "note": notes.get(m, "")}
                             for m, qf, qb, odt, ogroups, osteps in others}
+            if "2,2" in out["modes"]:     # the strict figure sits next to `value`, not only under modes
+                out["value_strict_2_2"] = out["modes"]["2,2"]["value"]
+                out["ms_per_step_strict_2_2"] = out["modes"]["2,2"]["ms_per_step"]
+        if extras:
+            out["extra_configs"] = extras
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, a.n_samples, a.n_importance)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, 64, 64)
             out["gpu_over_cpu"] = round(rays_per_s / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -40,6 +40,21 @@ int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand
  * models/lushnerf.py:271, 396, 612): z [R]. */
 int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* z, lush_stream_t stream);
 
+/* ------------------------------------------------------- numerical-fault word
+ * The reference tests every entry of render_rays' result dict for NaN/Inf after every chunk and
+ * prints (models/lushnerf.py:474-478, 578-582): one device sync per key per chunk.  Here the
+ * kernels that produce those entries OR bits into ONE caller-owned int32 word (`flags`, may be
+ * NULL = no checking), which the caller reads whenever it likes.  lush_composite_fwd shifts
+ * its five bits left by `flag_shift` (0 for the final pass: rgb_map, depth_map, acc_map,
+ * density_map, raw; LUSH_FAULT_COARSE_SHIFT for the coarse pass: rgb0, depth0, acc0, density0). */
+#define LUSH_FAULT_RGB 1
+#define LUSH_FAULT_DEPTH 2
+#define LUSH_FAULT_ACC 4
+#define LUSH_FAULT_DENSITY 8
+#define LUSH_FAULT_RAW 16
+#define LUSH_FAULT_COARSE_SHIFT 5
+#define LUSH_FAULT_ZSTD 1024
+
 /* ---------------------------------------------------------------- compositing
  * NeRFAll.raw2outputs, models/lushnerf.py:296-352.  raw [R][S][4]; noise [R][S-1]
  * N(0,1) draws or NULL; near_mask < 0 disables the eval-only near-plane mask
@@ -48,7 +63,7 @@ int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* 
 int lush_composite_fwd(const float* raw, const float* z, const float* rays, int R, int S,
                        const float* noise, float noise_std, float near_mask, int white_bkgd,
                        float* rgb, float* depth, float* acc, float* weights, float* density,
-                       lush_stream_t stream);
+                       int* flags, int flag_shift, lush_stream_t stream);
 /* Backward of the above w.r.t. raw and rays_d.  g_* may be NULL (= 0).
  * draw [R][S][4] overwritten; drays [R][11] accumulate (columns 3..5). */
 int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S,
@@ -63,7 +78,7 @@ int lush_composite_bwd(const float* raw, const float* z, const float* rays, int 
  * z_out [R][S+Ni] sorted; z_samples [R][Ni] (may be NULL); z_std [R] =
  * std(z_samples, unbiased=False) (:465). */
 int lush_sample_merge(const float* z, const float* weights, int R, int S, int Ni, const float* u,
-                      float* z_out, float* z_samples, float* z_std, lush_stream_t stream);
+                      float* z_out, float* z_samples, float* z_std, int* flags, lush_stream_t stream);
 
 /* ------------------------------------------------------------- ray prologue
  * The shared head of render_infer / render_train_scene / render_train_noise
@@ -82,6 +97,28 @@ int lush_pack_rays_bwd(const float* rays, int N, int ndc, float cx, float cy, co
  * c2w [V][3][4]; view, px, py [N] int64; rays [N][3][2]. */
 int lush_gen_rays(const float* c2w, const int64_t* view, const int64_t* px, const int64_t* py, int N,
                   float fx, float fy, float cx, float cy, float* rays, lush_stream_t stream);
+
+/* The same for all H*W pixels of one pose, row-major pixel order: the eval path's get_rays call
+ * (models/lushnerf.py:868-896 -> helpers:517-528).  c2w [3][4]; rays [H*W][3][2]. */
+int lush_gen_rays_image(const float* c2w, int H, int W, float fx, float fy, float cx, float cy,
+                        float* rays, lush_stream_t stream);
+
+/* ------------------------------------------------ consistency branch
+ * Ray gather of NeRFAll.Render_Aligned_Pixel (models/lushnerf.py:949-985): for pose v and sample s
+ * the matched pixel (x, y) = align[v][samples[s]][2:4].long() clamped to the image, its ray taken
+ * from get_rays(H, W, K, c2w[v]).  c2w [V][3][4]; align [V][HW][4] = Align_matrix[anchor];
+ * cert [V][HW] = Align_mask[anchor] as fp32 (cert_is_u8 = 0) or bool/uint8 (1; the reference
+ * allocates it as torch.bool, run_lushnerf.py:292); samples [ns] int64.
+ * rays [V*ns][3][2]; cert_out [V][ns] fp32. */
+int lush_align_rays(const float* c2w, const float* align, const void* cert, int cert_is_u8,
+                    const int64_t* samples, int V, int ns, long long HW, int H, int W, float fx, float fy,
+                    float cx, float cy, float* rays, float* cert_out, lush_stream_t stream);
+/* compute_mean_with_confidence (utils/run_lushnerf_helpers.py:665-688) and the masked L1 of
+ * run_lushnerf.py:644-650: loss[0] = sum |rgb - mean| * (cert >= threshold) / #(cert >= threshold)
+ * (overwritten; NaN when nothing passes the threshold, as in the reference), grad [V][ns][3] =
+ * d loss / d rgb including the path through the mean.  rgb [V][ns][3], cert [V][ns]. */
+int lush_consist_loss_fwd_bwd(const float* rgb, const float* cert, int V, int ns, float threshold,
+                              float* loss, float* grad, lush_stream_t stream);
 
 /* ----------------------------------------------------------- blur kernel (RBK)
  * View_Embedding + Rigid_Blurring_Kernel.forward trunk/heads,

@@ -144,6 +144,8 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
 size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P) {
     NetInfo n;
     if (!net_info(net, n) || !code_ok(planes_fwd) || stash_planes < 0 || nplanes(stash_planes) > nplanes(planes_fwd)) return 0;
+    // inference on the chain kernel keeps the encoding image in LDS and touches no workspace at all
+    if (stash_planes == 0 && mlp_fwd_chain_enabled(planes_fwd)) return 256;
     return stash_layout(n, nplanes(planes_fwd), nplanes(stash_planes), P).total;
 }
 size_t lush_mlp_dstash_bytes(int net, int planes, long long P) {

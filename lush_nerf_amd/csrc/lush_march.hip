@@ -70,7 +70,7 @@ struct CompIn {
 template <int SPL>
 __device__ __forceinline__ void comp_load(const CompIn& c, int ray, int lane, float (&alpha)[SPL], float (&dist)[SPL],
                                           float (&dens)[SPL], float (&gate)[SPL], float (&zz)[SPL],
-                                          float (&rgbv)[SPL][3], float& norm) {
+                                          float (&rgbv)[SPL][3], float& norm, bool* bad_raw = nullptr) {
     const float* rr = c.rays + (long long)ray * 11;
     norm = sqrtf(rr[3] * rr[3] + rr[4] * rr[4] + rr[5] * rr[5]);
 #pragma unroll
@@ -81,6 +81,9 @@ __device__ __forceinline__ void comp_load(const CompIn& c, int ray, int lane, fl
         if (j < c.S) {
             const long long p = (long long)ray * c.S + j;
             const float4 rw = *reinterpret_cast<const float4*>(c.raw + p * 4);
+            if (bad_raw)     // NaN or Inf in the network output (models/lushnerf.py:474-478 checks ret['raw'])
+                *bad_raw |= !(fabsf(rw.x) <= 3.402823466e38f) || !(fabsf(rw.y) <= 3.402823466e38f) ||
+                            !(fabsf(rw.z) <= 3.402823466e38f) || !(fabsf(rw.w) <= 3.402823466e38f);
             zz[e] = c.z[p];
             rgbv[e][0] = 1.f / (1.f + expf(-rw.x));
             rgbv[e][1] = 1.f / (1.f + expf(-rw.y));
@@ -118,12 +121,14 @@ __device__ __forceinline__ void comp_trans(const float (&alpha)[SPL], int lane, 
 
 template <int SPL>
 __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_fwd_kernel(CompIn c, float* __restrict__ rgb,
-        float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ density) {
+        float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ density,
+        int* __restrict__ flags, int flag_shift) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= c.R) return;
     float alpha[SPL], dist[SPL], dens[SPL], gate[SPL], zz[SPL], col[SPL][3], T[SPL], norm;
-    comp_load<SPL>(c, ray, lane, alpha, dist, dens, gate, zz, col, norm);
+    bool bad_dens = false, bad_raw = false;
+    comp_load<SPL>(c, ray, lane, alpha, dist, dens, gate, zz, col, norm, flags != nullptr ? &bad_raw : nullptr);
     comp_trans<SPL>(alpha, lane, T);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, sd = 0.f, sa = 0.f;
 #pragma unroll
@@ -133,11 +138,25 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_fwd_kernel(Comp
         if (j < c.S) {
             if (weights) weights[(long long)ray * c.S + j] = wgt;
             if (density && j < c.S - 1) density[(long long)ray * (c.S - 1) + j] = dens[e];
+            if (j < c.S - 1) bad_dens |= !(fabsf(dens[e]) <= 3.402823466e38f);
         }
         s0 += wgt * col[e][0]; s1 += wgt * col[e][1]; s2 += wgt * col[e][2];
         sd += wgt * zz[e]; sa += wgt;
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); sd = wave_sum(sd); sa = wave_sum(sa);
+    if (flags != nullptr) {   // wave-uniform branch; the ballots run with all lanes active
+        const bool any_dens = __ballot(bad_dens) != 0ull, any_raw = __ballot(bad_raw) != 0ull;
+        if (lane == 0) {
+            if (c.white_bkgd) { s0 += 1.f - sa; s1 += 1.f - sa; s2 += 1.f - sa; }
+            auto bad = [](float v) { return !(fabsf(v) <= 3.402823466e38f); };      // NaN or Inf
+            const int w = (bad(s0) || bad(s1) || bad(s2) ? LUSH_FAULT_RGB : 0) | (bad(sd) ? LUSH_FAULT_DEPTH : 0) |
+                          (bad(sa) ? LUSH_FAULT_ACC : 0) | (any_dens ? LUSH_FAULT_DENSITY : 0) | (any_raw ? LUSH_FAULT_RAW : 0);
+            if (w) atomicOr(flags, w << flag_shift);
+            rgb[ray * 3 + 0] = s0; rgb[ray * 3 + 1] = s1; rgb[ray * 3 + 2] = s2;
+            depth[ray] = sd; acc[ray] = sa;
+        }
+        return;
+    }
     if (lane == 0) {
         if (c.white_bkgd) { s0 += 1.f - sa; s1 += 1.f - sa; s2 += 1.f - sa; }
         rgb[ray * 3 + 0] = s0; rgb[ray * 3 + 1] = s1; rgb[ray * 3 + 2] = s2;
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(Comp
 constexpr int SM_MAXN = 512;   // S + Ni rounded up to a power of two
 __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const float* __restrict__ z,
         const float* __restrict__ weights, int R, int S, int Ni, const float* __restrict__ u,
-        float* __restrict__ z_out, float* __restrict__ z_samples, float* __restrict__ z_std) {
+        float* __restrict__ z_out, float* __restrict__ z_samples, float* __restrict__ z_std, int* __restrict__ flags) {
     __shared__ float s_cdf[RAYS_PER_BLOCK][256];
     __shared__ float s_bins[RAYS_PER_BLOCK][256];
     __shared__ float s_sort[RAYS_PER_BLOCK][SM_MAXN];
@@ -268,7 +287,11 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const
     float var = 0.f;
     for (int i = lane; i < Ni; i += 64) { const float d = srt[S + i] - mean; var += d * d; }
     var = wave_sum(var);
-    if (lane == 0 && z_std) z_std[ray] = sqrtf(var / (float)Ni);
+    if (lane == 0) {
+        const float sd = sqrtf(var / (float)Ni);
+        if (z_std) z_std[ray] = sd;
+        if (flags != nullptr && !(fabsf(sd) <= 3.402823466e38f)) atomicOr(flags, LUSH_FAULT_ZSTD);
+    }
     // sort(cat(z, samples)): bitonic network over N2 >= N values padded with +inf
     int N2 = 64;
     while (N2 < N) N2 <<= 1;
@@ -378,6 +401,100 @@ __global__ void gen_rays_kernel(const float* __restrict__ c2w, const int64_t* __
         o[2 * i] = M[i * 4 + 3];
         o[2 * i + 1] = (d0 * M[i * 4 + 0] + d1 * M[i * 4 + 1]) + d2 * M[i * 4 + 2];
     }
+}
+
+// All H*W pixels of ONE pose in row-major pixel order (the eval path's get_rays, helpers:517-528).
+__global__ void gen_rays_image_kernel(const float* __restrict__ c2w, int H, int W, float fx, float fy, float cx,
+                                      float cy, float* __restrict__ rays) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= H * W) return;
+    const int px = n % W, py = n / W;
+    const float d0 = ((float)px + (0.5f - cx)) / fx;
+    const float d1 = -((float)py + (0.5f - cy)) / fy;
+    const float d2 = -1.f;
+    float* o = rays + (long long)n * 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o[2 * i] = c2w[i * 4 + 3];
+        o[2 * i + 1] = (d0 * c2w[i * 4 + 0] + d1 * c2w[i * 4 + 1]) + d2 * c2w[i * 4 + 2];
+    }
+}
+
+// ------------------------------------------------- consistency branch
+// Render_Aligned_Pixel's gather (models/lushnerf.py:958-985): for pose v and sample s the matched
+// pixel is (x, y) = align[v][samples[s]][2:4].long(), clamped to the image; its ray is row
+// [y][x] of get_rays(H, W, K, c2w[v]).  One thread per (v, s).
+__global__ void align_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ align,
+                                  const void* __restrict__ cert, int cert_is_u8, const int64_t* __restrict__ samples,
+                                  int V, int ns, long long HW, int H, int W, float fx, float fy, float cx, float cy,
+                                  float* __restrict__ rays, float* __restrict__ cert_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= V * ns) return;
+    const int v = t / ns, s = t % ns;
+    long long pix = samples[s];
+    pix = pix < 0 ? 0 : (pix >= HW ? HW - 1 : pix);     // memory safety only: the reference would raise an IndexError
+    const float* a = align + ((long long)v * HW + pix) * 4;
+    long long x = (long long)a[2], y = (long long)a[3];          // .long(): truncation toward zero
+    x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+    const float* M = c2w + (long long)v * 12;
+    const float d0 = ((float)x + (0.5f - cx)) / fx;
+    const float d1 = -((float)y + (0.5f - cy)) / fy;
+    const float d2 = -1.f;
+    float* o = rays + (long long)t * 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o[2 * i] = M[i * 4 + 3];
+        o[2 * i + 1] = (d0 * M[i * 4 + 0] + d1 * M[i * 4 + 1]) + d2 * M[i * 4 + 2];
+    }
+    const long long ci = (long long)v * HW + pix;
+    cert_out[t] = cert_is_u8 ? (float)(reinterpret_cast<const uint8_t*>(cert)[ci] != 0) : reinterpret_cast<const float*>(cert)[ci];
+}
+
+// compute_mean_with_confidence (helpers:665-688) + the masked L1 of run_lushnerf.py:644-650, forward and
+// backward (the mean is built with differentiable in-place adds, so gradients flow through it):
+//   m[v][p] = cert[v][p] >= thr ; mean[p][c] = sum_v m rgb / max(1, sum_v m)
+//   loss = sum_{v,p,c} |rgb - mean| m / #{m}
+// One workgroup; thread t owns (p, c) = (t / 3, t % 3).
+__global__ __launch_bounds__(256) void consist_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ cert,
+                                                          int V, int ns, float thr, float* __restrict__ loss,
+                                                          float* __restrict__ grad) {
+    __shared__ float s_cnt, s_sum;
+    if (threadIdx.x == 0) { s_cnt = 0.f; s_sum = 0.f; }
+    __syncthreads();
+    float cnt = 0.f;
+    for (int i = threadIdx.x; i < V * ns; i += blockDim.x) cnt += cert[i] >= thr ? 1.f : 0.f;
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt != 0.f) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    const float n_mask = s_cnt;                      // 0 -> loss = 0/0 = NaN, as in the reference
+    float part = 0.f;
+    for (int t = threadIdx.x; t < ns * 3; t += blockDim.x) {
+        const int p = t / 3, c = t % 3;
+        float sum = 0.f, k = 0.f;
+        for (int v = 0; v < V; ++v)
+            if (cert[v * ns + p] >= thr) { sum += rgb[(v * ns + p) * 3 + c]; k += 1.f; }
+        const float mean = k > 0.f ? sum / k : 0.f;
+        float ssum = 0.f;
+        for (int v = 0; v < V; ++v)
+            if (cert[v * ns + p] >= thr) {
+                const float d = rgb[(v * ns + p) * 3 + c] - mean;
+                part += fabsf(d);
+                ssum += d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            }
+        for (int v = 0; v < V; ++v) {
+            float g = 0.f;
+            if (cert[v * ns + p] >= thr) {
+                const float d = rgb[(v * ns + p) * 3 + c] - mean;
+                g = ((d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) - ssum / k) / n_mask;
+            }
+            grad[(v * ns + p) * 3 + c] = g;
+        }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0 && part != 0.f) atomicAdd(&s_sum, part);
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = s_sum / n_mask;
 }
 
 // ---------------------------------------------------------------- SE(3) warp
@@ -752,7 +869,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 1; }
+int lush_abi_version(void) { return 2; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
@@ -769,13 +886,14 @@ int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* 
 
 int lush_composite_fwd(const float* raw, const float* z, const float* rays, int R, int S, const float* noise,
                        float noise_std, float near_mask, int white_bkgd, float* rgb, float* depth, float* acc,
-                       float* weights, float* density, lush_stream_t st) {
+                       float* weights, float* density, int* flags, int flag_shift, lush_stream_t st) {
     if (S < 2 || S > 256) return set_error("lush_composite_fwd: S must be in [2,256]");
+    if (flag_shift < 0 || flag_shift > 16) return set_error("lush_composite_fwd: flag_shift must be in [0,16]");
     CompIn c{raw, z, rays, noise, R, S, noise_std, near_mask, white_bkgd};
     dim3 g(cdiv(R, RAYS_PER_BLOCK)), b(RAYS_PER_BLOCK * 64);
-    if (S <= 64) hipLaunchKernelGGL(composite_fwd_kernel<1>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density);
-    else if (S <= 128) hipLaunchKernelGGL(composite_fwd_kernel<2>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density);
-    else hipLaunchKernelGGL(composite_fwd_kernel<4>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density);
+    if (S <= 64) hipLaunchKernelGGL(composite_fwd_kernel<1>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density, flags, flag_shift);
+    else if (S <= 128) hipLaunchKernelGGL(composite_fwd_kernel<2>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density, flags, flag_shift);
+    else hipLaunchKernelGGL(composite_fwd_kernel<4>, g, b, 0, S_(st), c, rgb, depth, acc, weights, density, flags, flag_shift);
     CHECK_LAUNCH();
     return 0;
 }
@@ -793,10 +911,10 @@ int lush_composite_bwd(const float* raw, const float* z, const float* rays, int 
 }
 
 int lush_sample_merge(const float* z, const float* weights, int R, int S, int Ni, const float* u, float* z_out,
-                      float* z_samples, float* z_std, lush_stream_t st) {
+                      float* z_samples, float* z_std, int* flags, lush_stream_t st) {
     if (S < 3 || S > 256 || Ni < 1 || S + Ni > SM_MAXN) return set_error("lush_sample_merge: need 3<=S<=256, S+Ni<=512");
     hipLaunchKernelGGL(sample_merge_kernel, dim3(cdiv(R, RAYS_PER_BLOCK)), dim3(RAYS_PER_BLOCK * 64), 0, S_(st), z,
-                       weights, R, S, Ni, u, z_out, z_samples, z_std);
+                       weights, R, S, Ni, u, z_out, z_samples, z_std, flags);
     CHECK_LAUNCH();
     return 0;
 }
@@ -818,6 +936,33 @@ int lush_gen_rays(const float* c2w, const int64_t* view, const int64_t* px, cons
                   float fy, float cx, float cy, float* rays, lush_stream_t st) {
     if (N <= 0) return 0;
     hipLaunchKernelGGL(gen_rays_kernel, dim3(cdiv(N, 256)), dim3(256), 0, S_(st), c2w, view, px, py, N, fx, fy, cx, cy, rays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_gen_rays_image(const float* c2w, int H, int W, float fx, float fy, float cx, float cy, float* rays,
+                        lush_stream_t st) {
+    if (H <= 0 || W <= 0) return set_error("lush_gen_rays_image: empty image");
+    hipLaunchKernelGGL(gen_rays_image_kernel, dim3(cdiv((long long)H * W, 256)), dim3(256), 0, S_(st), c2w, H, W, fx, fy, cx, cy, rays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_align_rays(const float* c2w, const float* align, const void* cert, int cert_is_u8, const int64_t* samples,
+                    int V, int ns, long long HW, int H, int W, float fx, float fy, float cx, float cy, float* rays,
+                    float* cert_out, lush_stream_t st) {
+    if (V <= 0 || ns <= 0) return set_error("lush_align_rays: empty");
+    if (HW <= 0) return set_error("lush_align_rays: empty match table");
+    hipLaunchKernelGGL(align_rays_kernel, dim3(cdiv((long long)V * ns, 128)), dim3(128), 0, S_(st), c2w, align, cert, cert_is_u8,
+                       samples, V, ns, HW, H, W, fx, fy, cx, cy, rays, cert_out);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_consist_loss_fwd_bwd(const float* rgb, const float* cert, int V, int ns, float threshold, float* loss,
+                              float* grad, lush_stream_t st) {
+    if (V <= 0 || ns <= 0) return set_error("lush_consist_loss_fwd_bwd: empty");
+    hipLaunchKernelGGL(consist_loss_kernel, dim3(1), dim3(256), 0, S_(st), rgb, cert, V, ns, threshold, loss, grad);
     CHECK_LAUNCH();
     return 0;
 }

@@ -83,12 +83,15 @@ _SIGS = {
     "lush_abi_version": ([], _i),
     "lush_zgrid": ([_p, _i, _i, _i, _p, _p, _p], _i),
     "lush_zfixed": ([_p, _i, _i, _i, _i, _p, _p], _i),
-    "lush_composite_fwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_composite_fwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _p], _i),
     "lush_composite_bwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p], _i),
-    "lush_sample_merge": ([_p, _p, _i, _i, _i, _p, _p, _p, _p, _p], _i),
+    "lush_sample_merge": ([_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
     "lush_pack_rays_fwd": ([_p, _i, _i, _f, _f, _f, _f, _p, _p], _i),
     "lush_pack_rays_bwd": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),
     "lush_gen_rays": ([_p, _p, _p, _p, _i, _f, _f, _f, _f, _p, _p], _i),
+    "lush_gen_rays_image": ([_p, _i, _i, _f, _f, _f, _f, _p, _p], _i),
+    "lush_align_rays": ([_p, _p, _p, _i, _p, _i, _i, _ll, _i, _i, _f, _f, _f, _f, _p, _p, _p], _i),
+    "lush_consist_loss_fwd_bwd": ([_p, _p, _i, _i, _f, _p, _p, _p], _i),
     "lush_rbk_mlp_fwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p], _i),
     "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, C.POINTER(RbkParams), _p, _p], _i),
     "lush_rbk_warp_fwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
@@ -114,6 +117,16 @@ _SIGS = {
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
+ABI_VERSION = 2
+# include/lush_march.h: LUSH_FAULT_*
+FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
+               128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}
+FAULT_BITS = {n: b for b, n in FAULT_NAMES.items()}
+FAULT_COARSE_SHIFT = 5
+
+
+def fault_names(word: int):
+    return [n for b, n in FAULT_NAMES.items() if word & b]
 
 
 def load():

@@ -144,10 +144,27 @@ class NeRFAll(nn.Module):
             self.dbk_view_embedding = blur_kernel_net.view_embed_layer
             self.mlp_rbk = blur_kernel_net.RBK
         self.gamma = args.tone_mapping_type == 'gamma'
+        # numerical-fault word (include/lush_march.h LUSH_FAULT_*): the kernels OR bits into it, read_faults()
+        # fetches and clears it.  Not persistent: the reference state_dict has exactly 108 keys.
+        self.register_buffer("_faults", torch.zeros(1, dtype=torch.int32), persistent=False)
 
     # ------------------------------------------------------------------ helpers
     def tonemapping(self, x, noise_raw=None):
         return ops.ToneMap.apply(x, noise_raw, self.gamma)
+
+    def read_faults(self, clear: bool = True) -> int:
+        """NaN/Inf report of every render call since the last read (one device sync).  The reference tests each
+        result key after every chunk and prints (models/lushnerf.py:474-478, 578-582); here the kernels set bits
+        of one device word and the caller decides when to look.  Returns the LUSH_FAULT_* bit mask."""
+        v = int(self._faults.item())
+        if v and clear:
+            self._faults.zero_()
+        return v
+
+    @staticmethod
+    def fault_names(word: int):
+        from . import lib
+        return [n for b, n in lib.FAULT_NAMES.items() if word & b]
 
     def _draws(self, R, N_samples, N_importance, perturb, raw_noise_std, device, draws):
         """Random draws in the reference's order and shapes (models/lushnerf.py:515, :322;
@@ -174,7 +191,8 @@ class NeRFAll(nn.Module):
         cfg = MarchCfg(N_samples=N_samples, N_importance=N_importance, perturb=float(perturb),
                        raw_noise_std=float(raw_noise_std), white_bkgd=bool(white_bkgd), lindisp=bool(lindisp),
                        near_mask=near_mask, precision=self.precision, has_fine=self.mlp_fine is not None,
-                       want_grad=torch.is_grad_enabled())
+                       want_grad=torch.is_grad_enabled(),
+                       flags=self._faults if self._faults.is_cuda else None)
         R = ray_batch.shape[0]
         d = self._draws(R, N_samples, N_importance, perturb, raw_noise_std, ray_batch.device, draws)
         coarse = self.mlp_coarse.tensors()
@@ -276,7 +294,8 @@ class NeRFAll(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, H, W, K, chunk=1024 * 32, rays=None, rays_info=None, poses=None, allkernel=False,
-                kernel_pixel=None, consist_loss=False, Align_matrix=None, Align_mask=None, **kwargs):
+                kernel_pixel=None, consist_loss=False, Align_matrix=None, Align_mask=None, anchor_pose=None,
+                samples=None, **kwargs):
         """models/lushnerf.py:619-677.  Training branch returns the reference 7-tuple."""
         if self.training and not consist_loss:
             assert rays is not None, "Please specify rays when in the training mode"
@@ -296,8 +315,10 @@ class NeRFAll(nn.Module):
             (rgb, depth, acc, extras), noise_raw = self.render_infer(H, W, K, chunk, rays, **kwargs)
             rgb_noise = ops.NoiseAct.apply(noise_raw)
             return self.tonemapping(rgb), self.tonemapping(extras['rgb0']), {}, rgb_noise, rgb_noise, {}, {}
-        if self.training and consist_loss:
-            raise NotImplementedError("consistency branch (Render_Aligned_Pixel) is SURVEY section 8(f) row 3: next")
+        if self.training and consist_loss:      # models/lushnerf.py:664-668
+            kwargs['render_kwargs'].pop('save_warped_ray_img', False)
+            return self.Render_Aligned_Pixel(H, W, K, chunk, poses, images_idx=rays_info, align_matrix=Align_matrix,
+                                             align_mask=Align_mask, anchor_pose=anchor_pose, samples=samples, **kwargs)
         assert poses is not None, "Please specify poses when in the eval model"
         kwargs['render_kwargs'].pop('save_warped_ray_img', False)
         rgbs, rgbs_noise, depths = self.render_path(H, W, K, chunk, poses, **kwargs)
@@ -310,16 +331,43 @@ class NeRFAll(nn.Module):
             H, W = H // render_factor, W // render_factor
         rgbs, depths, noises = [], [], []
         for c2w in render_poses:
-            rays = torch.stack(get_rays(H, W, K, c2w), dim=-1)
+            rays = ops.gen_rays_image(c2w, H, W, K)       # get_rays (helpers:517-528) on the device, [H,W,3,2]
             with torch.no_grad():
                 (rgb, depth, acc, extras), noise = self.render_infer(H, W, K, chunk=chunk, rays=rays,
                                                                      c2w=c2w[:3, :4], **render_kwargs)
             rgbs.append(rgb); depths.append(depth); noises.append(noise)
         return torch.stack(rgbs, 0), torch.stack(noises, 0), torch.stack(depths, 0)
 
+    def Render_Aligned_Pixel(self, H, W, K, chunk, render_poses, images_idx, render_kwargs, render_factor=0,
+                             align_matrix=None, align_mask=None, anchor_pose=None, samples=None):
+        """models/lushnerf.py:949-989 -> (rgb_align [V,32,3], align_certainty [V,32]).
+
+        The reference draws `anchor_pose = random.randint(0, V-1)` and `samples = np.random.randint(0, 640*1120,
+        32)` on the host (:960, :964); pass them explicitly to pin a run (parity tests), otherwise they are
+        drawn the same way here.  The reference then loops over the poses, builds each pose's full H*W ray
+        table and renders 32 rays at a time; rays are independent and this branch draws nothing (perturb
+        False, raw_noise_std 0), so one gather kernel + ONE render_train_scene call over V*32 rays gives the
+        same values."""
+        if render_factor != 0:
+            H, W = H // render_factor, W // render_factor
+        V = len(render_poses)
+        if anchor_pose is None:
+            import random
+            anchor_pose = random.randint(0, V - 1)
+        if samples is None:
+            import numpy as np
+            samples = torch.from_numpy(np.random.randint(0, 640 * 1120, size=32))
+        samples = torch.as_tensor(samples).long()
+        c2w = render_poses if torch.is_tensor(render_poses) else torch.stack(list(render_poses), 0)
+        rays, certainty = ops.align_rays(c2w, align_matrix[anchor_pose], align_mask[anchor_pose], samples, H, W, K)
+        rgb, _, _, _ = self.render_train_scene(H, W, K, chunk=chunk, rays=rays.detach(), render_noise=False,
+                                               **render_kwargs)
+        return rgb.reshape(V, samples.numel(), 3), certainty
+
 
 def get_rays(H, W, K, c2w):
-    """utils/run_lushnerf_helpers.py:517-528 (host-side ray table for the eval path; plumbing)."""
+    """utils/run_lushnerf_helpers.py:517-528 in torch ops (kept for callers that want the host formula; the
+    product paths use ops.gen_rays / ops.gen_rays_image)."""
     dev = c2w.device
     i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=dev), torch.linspace(0, H - 1, H, device=dev),
                           indexing='ij')

@@ -92,6 +92,9 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+# Test hook (tests/ only): when set to a dict, March / NoiseMlp forward leave their activation stashes in it
+# ("stash_c", "stash_f", "stash_noise" + the point counts) so a test can read the ReLU decisions the GPU took.
+DEBUG_KEEP: Optional[dict] = None
 
 
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0):
@@ -112,16 +115,37 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
     return raw, (stash if want_stash else None)
 
 
-def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash):
-    """Returns (list of parameter grads in `tensors` order, dpts [P][8])."""
+# When True (set by Trainer.step), parameter gradients are accumulated by the weight-gradient kernels' own
+# atomics straight into each parameter's existing .grad buffer (the trainer's flat gradient) and autograd
+# receives None for them: no per-tensor temporaries, zero-fills or `grad += tmp` kernels on the step.
+ACCUMULATE_INTO_PARAM_GRAD = False
+
+
+def grad_sink(tensors):
+    """The .grad buffers of `tensors` if accumulation into them is enabled and every one is usable, else None."""
+    if not ACCUMULATE_INTO_PARAM_GRAD:
+        return None
+    gs = [getattr(t, "grad", None) for t in tensors]
+    for g, t in zip(gs, tensors):
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != t.shape or g.device != t.device:
+            return None
+    return gs
+
+
+def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash, sink=None):
+    """Returns (list of parameter grads in `tensors` order, dpts [P][8]).  With `sink` (a list of fp32
+    buffers, one per tensor) the gradients are ADDED to those buffers and the returned list holds None."""
     R, S = z.shape
     dev = rays.device
     dstash = torch.empty(lib.load().lush_mlp_dstash_bytes(net, planes_b, R * S), dtype=torch.uint8, device=dev)
-    flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=dev)   # one zero-fill for all of them
-    grads, o = [], 0
-    for t in tensors:
-        grads.append(flat[o:o + t.numel()].view(t.shape))
-        o += t.numel()
+    if sink is not None:
+        grads = list(sink)
+    else:
+        flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=dev)   # one zero-fill for all of them
+        grads, o = [], 0
+        for t in tensors:
+            grads.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
     dpts = torch.empty(R * S, 8, dtype=torch.float32, device=dev)
     st, gs = lib.mlp_struct(tensors, _NL[net]), lib.mlp_struct(grads, _NL[net])
     timed = TIMER is not None and net == NET_NERF
@@ -139,7 +163,7 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
              C.byref(gs), _stream())
     if ev:
         ev[1].record()
-    return grads, dpts
+    return ([None] * len(tensors) if sink is not None else grads), dpts
 
 
 # ----------------------------------------------------------------------------- ray prologue
@@ -184,6 +208,7 @@ class MarchCfg:
     precision: Precision = None
     has_fine: bool = True
     want_grad: bool = True           # set by the caller from torch.is_grad_enabled() (it is off inside forward)
+    flags: Optional[torch.Tensor] = None   # int32 [1] numerical-fault word (include/lush_march.h LUSH_FAULT_*), or None
 
     def __post_init__(self):
         if self.precision is None:
@@ -197,7 +222,7 @@ def zgrid(batch, S, lindisp, t_rand):
     return z
 
 
-def composite_fwd(raw, z, batch, noise, cfg: MarchCfg):
+def composite_fwd(raw, z, batch, noise, cfg: MarchCfg, flag_shift: int = 0):
     R, S = z.shape
     dev = z.device
     rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
@@ -207,7 +232,7 @@ def composite_fwd(raw, z, batch, noise, cfg: MarchCfg):
     density = torch.empty(R, S - 1, dtype=torch.float32, device=dev)
     lib.call("lush_composite_fwd", lib.ptr(raw), lib.ptr(z), lib.ptr(batch), R, S, lib.ptr(noise),
              float(cfg.raw_noise_std), float(cfg.near_mask), int(cfg.white_bkgd), lib.ptr(rgb), lib.ptr(depth),
-             lib.ptr(acc), lib.ptr(weights), lib.ptr(density), _stream())
+             lib.ptr(acc), lib.ptr(weights), lib.ptr(density), lib.ptr(cfg.flags), int(flag_shift), _stream())
     return rgb, depth, acc, weights, density
 
 
@@ -220,14 +245,14 @@ def composite_bwd(raw, z, batch, noise, cfg: MarchCfg, g_rgb, g_depth, g_acc, dr
     return draw
 
 
-def sample_merge(z, weights, Ni, u):
+def sample_merge(z, weights, Ni, u, flags=None):
     R, S = z.shape
     dev = z.device
     z_out = torch.empty(R, S + Ni, dtype=torch.float32, device=dev)
     z_samples = torch.empty(R, Ni, dtype=torch.float32, device=dev)
     z_std = torch.empty(R, dtype=torch.float32, device=dev)
     lib.call("lush_sample_merge", lib.ptr(z), lib.ptr(weights), R, S, Ni, lib.ptr(u), lib.ptr(z_out),
-             lib.ptr(z_samples), lib.ptr(z_std), _stream())
+             lib.ptr(z_samples), lib.ptr(z_std), lib.ptr(flags), _stream())
     return z_out, z_samples, z_std
 
 
@@ -259,14 +284,15 @@ class March(torch.autograd.Function):
         zc = zgrid(batch, cfg.N_samples, cfg.lindisp, t_rand)
         pk_c = mlp_pack(NET_NERF, pf, coarse)
         raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb))
-        rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, noise_c, cfg)
+        rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, noise_c, cfg,
+                                                          lib.FAULT_COARSE_SHIFT if cfg.N_importance > 0 else 0)
         outs = [rgb, depth, acc, density]
         saved = dict(zc=zc, raw_c=raw_c, noise_c=noise_c, stash_c=stash_c)
         z_last, raw_last = zc, raw_c
         if cfg.N_importance > 0:
             u = _opt(draws.get("u")) if cfg.perturb > 0 else None
             noise_f = _opt(draws.get("noise_f")) if cfg.raw_noise_std > 0 else None
-            zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, u)
+            zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, u, cfg.flags)
             same = fine is coarse
             pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
             raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb))
@@ -280,6 +306,9 @@ class March(torch.autograd.Function):
         outs += [raw_last.view(R, -1, 4), w_last, z_last]
         if cfg.N_importance > 0:
             outs += [rgb, depth, acc, density, z_std]
+        if DEBUG_KEEP is not None:
+            DEBUG_KEEP.update(stash_c=saved.get("stash_c"), stash_f=saved.get("stash_f"), P_c=zc.numel(),
+                              P_f=saved["zf"].numel() if "zf" in saved else 0, batch=batch)
         ctx.cfg, ctx.n_coarse, ctx.n_params = cfg, n_coarse, len(params)
         ctx.batch, ctx.coarse, ctx.fine, ctx.saved = batch, coarse, fine, saved
         nd = [outs[3], outs[4], outs[5], outs[6]] + ([outs[10], outs[11]] if cfg.N_importance > 0 else [])
@@ -300,7 +329,8 @@ class March(torch.autograd.Function):
         def run(tensors, z, raw, noise, stash, gg):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
             pk = mlp_pack(NET_NERF, pb, tensors)
-            gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash)
+            gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash,
+                                    sink=grad_sink(tensors))
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays),
                      _stream())
             return gr
@@ -333,6 +363,8 @@ class NoiseMlp(torch.autograd.Function):
         pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
         need = bool(want_grad) and any(ctx.needs_input_grad)
         raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, stash_code(precision.fwd, precision.bwd))
+        if DEBUG_KEEP is not None:
+            DEBUG_KEEP.update(stash_noise=stash, P_noise=R)
         ctx.batch, ctx.z, ctx.tensors, ctx.stash, ctx.precision = batch, z, tensors, stash, precision
         return raw[:, :3].contiguous()
 
@@ -342,7 +374,8 @@ class NoiseMlp(torch.autograd.Function):
         draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
         draw[:, :3] = g
         pk = mlp_pack(NET_NOISE, pr.bwd, ctx.tensors)
-        grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash)
+        grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash,
+                                sink=grad_sink(ctx.tensors))
         ctx.stash = None
         o = 2 * _NL[NET_NOISE] + 4   # alpha_linear is dead in NeRF_Noise (helpers:496,505,512): grad None
         grads[o] = None
@@ -500,3 +533,57 @@ def gen_rays(c2w, view, px, py, K):
     lib.call("lush_gen_rays", lib.ptr(c2w), lib.ptr(view), lib.ptr(px), lib.ptr(py), N, float(K[0][0]), float(K[1][1]),
              float(K[0][2]), float(K[1][2]), lib.ptr(rays), _stream())
     return rays
+
+
+def gen_rays_image(c2w, H, W, K):
+    """get_rays(H, W, K, c2w) of the eval path (utils/run_lushnerf_helpers.py:517-528; models/lushnerf.py:881) for
+    every pixel of one pose: c2w [3(+),4] -> rays [H, W, 3, 2]."""
+    c2w = _f32(c2w[:3, :4])
+    rays = torch.empty(H, W, 3, 2, dtype=torch.float32, device=c2w.device)
+    lib.call("lush_gen_rays_image", lib.ptr(c2w), int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]),
+             float(K[1][2]), lib.ptr(rays), _stream())
+    return rays
+
+
+def align_rays(c2w, align, cert, samples, H, W, K):
+    """Ray gather of Render_Aligned_Pixel (models/lushnerf.py:958-985): c2w [V,3(+),4], align [V,HW,4] =
+    Align_matrix[anchor], cert [V,HW] = Align_mask[anchor] (bool / uint8 / float), samples [ns] int64
+    -> rays [V*ns,3,2], certainty [V,ns] fp32."""
+    c2w = _f32(c2w[:, :3, :4])
+    align = _f32(align)
+    V, HW = align.shape[0], align.shape[1]
+    if align.shape[2] != 4 or c2w.shape[0] != V or tuple(cert.shape) != (V, HW):
+        raise ValueError("align_rays: need align [V,HW,4], cert [V,HW], c2w [V,3,4]")
+    is_u8 = cert.dtype in (torch.bool, torch.uint8)
+    cert = cert.contiguous() if is_u8 else _f32(cert)
+    if not cert.is_cuda:
+        raise RuntimeError("lush_nerf_amd ops need CUDA/HIP tensors (no CPU path)")
+    samples = samples.reshape(-1).to(device=c2w.device, dtype=torch.int64).contiguous()
+    ns = samples.numel()
+    rays = torch.empty(V * ns, 3, 2, dtype=torch.float32, device=c2w.device)
+    cert_out = torch.empty(V, ns, dtype=torch.float32, device=c2w.device)
+    lib.call("lush_align_rays", lib.ptr(c2w), lib.ptr(align), lib.ptr(cert), int(is_u8), lib.ptr(samples), V, ns, HW,
+             int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), lib.ptr(rays),
+             lib.ptr(cert_out), _stream())
+    return rays, cert_out
+
+
+class ConsistLoss(torch.autograd.Function):
+    """loss_rgb of the consistency branch (run_lushnerf.py:644-650) with compute_mean_with_confidence
+    (utils/run_lushnerf_helpers.py:665-688): rgb_align [V,ns,3], align_certainty [V,ns], threshold -> scalar."""
+
+    @staticmethod
+    def forward(ctx, rgb, cert, threshold):
+        rgb, cert = _f32(rgb), _f32(cert)
+        V, ns = cert.shape
+        loss = torch.empty(1, dtype=torch.float32, device=rgb.device)
+        grad = torch.empty_like(rgb)
+        lib.call("lush_consist_loss_fwd_bwd", lib.ptr(rgb), lib.ptr(cert), V, ns, float(threshold), lib.ptr(loss),
+                 lib.ptr(grad), _stream())
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None

@@ -136,6 +136,19 @@ def poses(num_img: int = 30, seed: int = 0) -> np.ndarray:
     return out.astype(np.float32)
 
 
+def pixel_batch(n_rand: int, seed: int = 0, num_img: int = 30, H: int = H_DEF, W: int = W_DEF, step: int = 0):
+    """The (view, pixel) draws of one training batch + targets, without the rays: what a trainer that generates its
+    rays on the device (lush_gen_rays) keeps resident instead of the [N_img*H*W, 2, 3] ray table.
+    view, px, py [N] int64; target [N,3]; fq_mask [N] uint8."""
+    st = _stream("batch") + 7919 * step
+    views = np.minimum((uniform01(n_rand, seed, st) * num_img).astype(np.int64), num_img - 1)
+    px = np.floor(uniform01(n_rand, seed, st + 1) * W).astype(np.int64)
+    py = np.floor(uniform01(n_rand, seed, st + 2) * H).astype(np.int64)
+    target = uniform((n_rand, 3), 0.0, 1.0, seed, st + 3)
+    fq = (uniform01(n_rand, seed, st + 4) < 0.5).astype(np.uint8)
+    return {"view": views, "px": px, "py": py, "target": target, "fq_mask": fq}
+
+
 def ray_batch(n_rand: int, seed: int = 0, num_img: int = 30, H: int = H_DEF, W: int = W_DEF,
               focal: float = FOCAL_DEF, step: int = 0):
     """One training batch in the reference's iter_data layout
@@ -143,19 +156,15 @@ def ray_batch(n_rand: int, seed: int = 0, num_img: int = 30, H: int = H_DEF, W: 
     [N,1] int64, target rgb [N,3], fq_mask [N] uint8.  Rays follow the get_rays_np
     formula (helpers:531-539) at pixel centres."""
     c2w = poses(num_img, seed)
-    st = _stream("batch") + 7919 * step
-    views = np.minimum((uniform01(n_rand, seed, st) * num_img).astype(np.int64), num_img - 1)
-    px = np.floor(uniform01(n_rand, seed, st + 1) * W)
-    py = np.floor(uniform01(n_rand, seed, st + 2) * H)
+    pb = pixel_batch(n_rand, seed, num_img, H, W, step)
+    views, px, py = pb["view"], pb["px"].astype(np.float64), pb["py"].astype(np.float64)
     dirs = np.stack([(px + (0.5 - W / 2)) / focal, -(py + (0.5 - H / 2)) / focal,
                      -np.ones_like(px)], -1)
     R = c2w[views][:, :3, :3].astype(np.float64)
     rays_d = np.einsum("nij,nj->ni", R, dirs)
     rays_o = c2w[views][:, :3, 3].astype(np.float64)
     rays = np.stack([rays_o, rays_d], -1).astype(np.float32)          # [N,3,2]
-    target = uniform((n_rand, 3), 0.0, 1.0, seed, st + 3)
-    fq = (uniform01(n_rand, seed, st + 4) < 0.5).astype(np.uint8)
-    return {"rays": rays, "images_idx": views.reshape(-1, 1), "target": target, "fq_mask": fq}
+    return {"rays": rays, "images_idx": views.reshape(-1, 1), "target": pb["target"], "fq_mask": pb["fq_mask"]}
 
 
 def draws(R: int, Ns: int, Ni: int, seed: int = 0, step: int = 0):

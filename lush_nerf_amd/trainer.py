@@ -1,11 +1,15 @@
 """Training step around the HIP ray march: the build's counterpart of the reference's
 train() inner loop (run_lushnerf.py:603-685) and of its nn.DataParallel wrapper (:348).
 
-* loss = 0.5*MSE + 0.5*L1 on rgb_blur and rgb0_blur (:652-661)
-* Adam(lr 5e-4), lr = lrate * 0.1**(global_step / (lrate_decay*1000)) (:368-371, :681-685)
+* loss = 0.5*MSE + 0.5*L1 on rgb_blur and rgb0_blur (:652-661), plus 1e-2 * the consistency term of
+  the aligned-pixel branch for i > noisenerf_start_iter (:629-661)
+* Adam(lr 5e-4), lr = lrate * 0.1**(global_step / (lrate_decay*1000)) computed AFTER the step it
+  follows, i.e. step g runs with the rate of global_step g-1 (:368-371, :675-685, :788)
 * data parallel: one process per GPU, each draws its own N_rand rays; ONE all-reduce
   (RCCL over xGMI) of a single flat fp32 gradient buffer per step, then Adam runs
-  redundantly on every rank.  No other collective.
+  redundantly on every rank.  No other collective on the data path;
+  parameters and Adam moments are broadcast from rank 0 once at construction / checkpoint load
+  (nn.DataParallel replicates module 0 every step, run_lushnerf.py:348).
 
 All parameters live in one flat fp32 buffer (the nn.Parameters are views), ordered in three
 Adam segments that mirror which parameters the reference leaves with grad=None
@@ -53,69 +57,145 @@ class FlatParams:
         self.numel = total
 
 
+def adam_segments(model: NeRFAll) -> List[List[torch.nn.Parameter]]:
+    """[always stepped], [stepped once the blur kernel is on], [never stepped]."""
+    base = list(model.mlp_coarse.parameters()) + (list(model.mlp_fine.parameters()) if model.mlp_fine else [])
+    dead = list(model.mlp_noise_coarse.alpha_linear.parameters())
+    dead_ids = {id(p) for p in dead}
+    late = [p for p in model.mlp_noise_coarse.parameters() if id(p) not in dead_ids]
+    if model.blur_kernel_net is not None:
+        late = list(model.blur_kernel_net.parameters()) + late
+    return [base, late, dead]
+
+
 class Trainer:
     def __init__(self, model: NeRFAll, H: int, W: int, focal: float, N_samples: int = 64, N_importance: int = 64,
                  lrate: float = 5e-4, lrate_decay: int = 250, perturb: float = 1., raw_noise_std: float = 1.,
-                 kernel_start_iter: int = 0, allkernel_start_iter: int = 0, chunk: int = 1024 * 32,
-                 distributed: bool = False, micro_batch: int = 0):
+                 kernel_start_iter: int = 0, allkernel_start_iter: int = 0, noisenerf_start_iter: int = 1 << 30,
+                 chunk: int = 1024 * 32, distributed: bool = False, micro_batch: int = 0, white_bkgd: bool = False,
+                 step_fn=None):
         self.model = model
         self.H, self.W = H, W
         self.K = [[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]]
         self.kw = dict(perturb=perturb, N_importance=N_importance, N_samples=N_samples, use_viewdirs=True,
-                       white_bkgd=False, raw_noise_std=raw_noise_std, inference=False, near=0., far=1.)
+                       white_bkgd=white_bkgd, raw_noise_std=raw_noise_std, inference=False, near=0., far=1.)
+        # render_kwargs_test of the reference (run_lushnerf.py:406-410): what the consistency branch renders with
+        self.kw_test = dict(self.kw, perturb=False, raw_noise_std=0., inference=True)
         self.lrate, self.lrate_decay = lrate, lrate_decay
         self.kernel_start_iter, self.allkernel_start_iter = kernel_start_iter, allkernel_start_iter
+        self.noisenerf_start_iter = noisenerf_start_iter
         self.chunk = chunk
         # micro_batch > 0: forward+backward run per slice of that many INPUT rays and gradients accumulate in
         # the flat buffer (the loss is a mean over rays, so this is exact up to summation order).  It bounds the
         # activation stash: BASELINE config 5 (16 384 rays, 128+128) would otherwise hold ~260 GB between
         # forward and backward.
         self.micro_batch = micro_batch
-        self.distributed = distributed and dist.is_initialized() and dist.get_world_size() > 1
+        self.distributed = distributed and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
-        base = list(model.mlp_coarse.parameters()) + (list(model.mlp_fine.parameters()) if model.mlp_fine else [])
-        dead = list(model.mlp_noise_coarse.alpha_linear.parameters())
-        dead_ids = {id(p) for p in dead}
-        late = [p for p in model.mlp_noise_coarse.parameters() if id(p) not in dead_ids]
-        if model.blur_kernel_net is not None:
-            late = list(model.blur_kernel_net.parameters()) + late
-        self.flat = FlatParams([base, late, dead])
+        self.flat = FlatParams(adam_segments(model))
         n = self.flat.numel
         self.m = torch.zeros(n, dtype=torch.float32, device=self.flat.param.device)
         self.v = torch.zeros_like(self.m)
         self.steps = [0, 0, 0]            # per-segment Adam step counters (torch keeps one per parameter)
         self.global_step = 0
+        self._lr_next = None              # rate restored from a checkpoint's optimizer state, used for ONE step
+        # test seam: the CPU (gloo) tests replace the HIP forward+backward of one slice by injected gradients
+        self._fwd_bwd = step_fn or self._hip_forward_backward
+        self._adam = ops.adam_step
+        self.sync_replicas()
+
+    # ------------------------------------------------------------------ data parallel plumbing
+    def sync_replicas(self):
+        """Every rank continues from rank 0's parameters and Adam state (what nn.DataParallel's per-step
+        replicate gives the reference for free).  Called at construction and after a checkpoint load."""
+        if not self.distributed:
+            return
+        for t in (self.flat.param, self.m, self.v):
+            dist.broadcast(t, 0)
+        meta = torch.tensor(self.steps + [self.global_step], dtype=torch.int64, device=self.flat.param.device)
+        dist.broadcast(meta, 0)
+        meta = [int(x) for x in meta.tolist()]
+        self.steps, self.global_step = meta[:3], meta[3]
+
+    def replica_checksum(self) -> float:
+        """max over ranks of |sum(param) - rank 0's sum(param)| (debug aid; 0.0 when replicas agree)."""
+        s = self.flat.param.double().sum().reshape(1)
+        if not self.distributed:
+            return 0.0
+        ref = s.clone()
+        dist.broadcast(ref, 0)
+        d = (s - ref).abs()
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        return float(d.item())
 
     def lr(self) -> float:
-        return self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 1000)))
+        """Rate the NEXT optimizer step runs with.  The reference sets new_lrate from global_step after
+        optimizer.step() and before global_step += 1 (run_lushnerf.py:675-685, 788): step g (0-based) uses
+        lrate * 0.1**((g-1)/decay), and the very first step the constructor's lrate."""
+        g = max(self.global_step - 1, 0)
+        return self.lrate * (0.1 ** (g / (self.lrate_decay * 1000)))
 
-    def step(self, batch: Dict[str, torch.Tensor], i: int, draws=None):
-        """One optimisation step on a batch {rays [N,3,2], images_idx [N,1], target [N,3], fq_mask [N]}."""
+    # ------------------------------------------------------------------ one slice on the GPU
+    def _hip_forward_backward(self, batch, a, b, i, draws, frac, force_naive):
+        M = 1 if force_naive else self.model.mlp_rbk.num_motion + 1
+        d = None if draws is None else {k: v[a * M:b * M] for k, v in draws.items()}
+        rays = batch["rays"][a:b] if "rays" in batch else \
+            ops.gen_rays(batch["c2w"], batch["view"][a:b], batch["px"][a:b], batch["py"][a:b], self.K)
+        idx = batch["images_idx"][a:b] if "images_idx" in batch else batch["view"][a:b].reshape(-1, 1)
+        out = self.model(self.H, self.W, self.K, chunk=self.chunk, rays=rays, rays_info={"images_idx": idx},
+                         retraw=True, force_naive=force_naive, allkernel=i < self.allkernel_start_iter,
+                         kernel_pixel=batch["fq_mask"][a:b], draws=d, **self.kw)
+        part = ops.TrainLoss.apply(out[0], out[1], batch["target"][a:b]) * frac
+        part.backward()
+        return part.detach()
+
+    def _consistency(self, consist, weight):
+        """The aligned-pixel branch (run_lushnerf.py:629-650): loss_rgb and its backward; returns loss_rgb."""
+        rgb_align, cert = self.model(self.H, self.W, self.K, self.chunk, poses=consist["poses"],
+                                     render_kwargs=dict(self.kw_test), render_factor=0,
+                                     rays_info=consist.get("images_idx"), consist_loss=True,
+                                     Align_matrix=consist["Align_matrix"], Align_mask=consist["Align_mask"],
+                                     anchor_pose=consist.get("anchor_pose"), samples=consist.get("samples"))
+        loss_rgb = ops.ConsistLoss.apply(rgb_align, cert, 0.8)
+        if weight != 0.0:
+            (loss_rgb * weight).backward()
+        return loss_rgb.detach()
+
+    def step(self, batch: Dict[str, torch.Tensor], i: int, draws=None, consist: Optional[dict] = None):
+        """One optimisation step on a batch {rays [N,3,2] (or c2w/view/px/py for device-side ray generation),
+        images_idx [N,1], target [N,3], fq_mask [N]}."""
         self.model.train()
         self.flat.grad.zero_()
         force_naive = i < self.kernel_start_iter
-        N = batch["rays"].shape[0]
+        N = batch["target"].shape[0]
         mb = self.micro_batch if 0 < self.micro_batch < N else N
-        M = 1 if force_naive else self.model.mlp_rbk.num_motion + 1
         loss = None
-        for a in range(0, N, mb):
-            b = min(a + mb, N)
-            d = None if draws is None else {k: v[a * M:b * M] for k, v in draws.items()}
-            out = self.model(self.H, self.W, self.K, chunk=self.chunk, rays=batch["rays"][a:b],
-                             rays_info={"images_idx": batch["images_idx"][a:b]}, retraw=True,
-                             force_naive=force_naive, allkernel=i < self.allkernel_start_iter,
-                             kernel_pixel=batch["fq_mask"][a:b], draws=d, **self.kw)
-            part = ops.TrainLoss.apply(out[0], out[1], batch["target"][a:b]) * ((b - a) / N)
-            part.backward()
-            loss = part.detach() if loss is None else loss + part.detach()
+        sink_before, ops.ACCUMULATE_INTO_PARAM_GRAD = ops.ACCUMULATE_INTO_PARAM_GRAD, True
+        try:      # dW kernels add straight into the flat gradient (p.grad are views of it)
+            for a in range(0, N, mb):
+                b = min(a + mb, N)
+                part = self._fwd_bwd(batch, a, b, i, draws, (b - a) / N, force_naive)
+                loss = part if loss is None else loss + part
+            if consist is not None and i >= self.noisenerf_start_iter:
+                # computed from i >= noisenerf_start_iter, added to the loss only for i > (run_lushnerf.py:629, 658-659)
+                w = 1e-2 if i > self.noisenerf_start_iter else 0.0
+                loss = loss + w * self._consistency(consist, w)
+        finally:
+            ops.ACCUMULATE_INTO_PARAM_GRAD = sink_before
         if self.distributed:
             dist.all_reduce(self.flat.grad)          # RCCL sum over xGMI; the 1/world mean is folded into Adam
-        lr = self.lr()
+        lr = self.lr() if self._lr_next is None else self._lr_next
+        self._lr_next = None
         active = [True, not force_naive, False]
         for s, (a, b) in enumerate(self.flat.segments):
             if active[s] and b > a:
                 self.steps[s] += 1
-                ops.adam_step(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
-                              grad_scale=1.0 / self.world)
+                self._adam(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
+                           grad_scale=1.0 / self.world)
         self.global_step += 1
         return loss
+
+    def faults(self) -> int:
+        """Numerical-fault word of the model's render calls since the last read (one device sync; the reference
+        prints after every chunk, models/lushnerf.py:474-478, 578-582)."""
+        return self.model.read_faults()

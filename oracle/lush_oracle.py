@@ -395,3 +395,67 @@ def get_rays_np_formula(H: int, W: int, focal: float, c2w, px, py):
     rays_d = np.sum(dirs[..., None, :] * c2w[..., :3, :3], -1)
     rays_o = np.broadcast_to(c2w[..., :3, 3], rays_d.shape)
     return rays_o.astype(np.float32), rays_d.astype(np.float32)
+
+
+def lr_schedule(n_steps: int, lrate: float = 5e-4, lrate_decay: int = 250, start: int = 0):
+    """Learning rate each optimizer.step() of the reference loop actually runs with: the rate is recomputed from
+    global_step AFTER the step and BEFORE global_step += 1 (run_lushnerf.py:675-685, 788), so step g uses the
+    rate of global_step g-1 and the first step the constructor's lrate (:368-371)."""
+    used, lr, global_step = [], lrate, start
+    for _ in range(n_steps):
+        used.append(lr)                                   # optimizer.step()
+        lr = lr_at(global_step, lrate, lrate_decay)       # new_lrate -> param_group['lr']
+        global_step += 1
+    return used
+
+
+# --------------------------------------------------------------------------- f3: consistency branch
+def get_rays(H: int, W: int, K, c2w: Tensor):
+    """utils/run_lushnerf_helpers.py:517-528 (pixel centres: HALF_PIX = 0.5)."""
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i + (0.5 - K[0][2])) / K[0][0], -(j + (0.5 - K[1][2])) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def render_aligned_pixel(p: Params, H: int, W: int, focal: float, poses: Tensor, align_anchor: Tensor,
+                         cert_anchor: Tensor, samples: Tensor, N_samples: int, N_importance: int):
+    """NeRFAll.Render_Aligned_Pixel, models/lushnerf.py:949-989, after the two host draws (:960, :964):
+    ``align_anchor`` = Align_matrix[anchor] [V, HW, 4], ``cert_anchor`` = Align_mask[anchor] [V, HW].
+    Module in train mode, render_kwargs_test (perturb False, raw_noise_std 0): no draws, no near-plane mask.
+    Returns (rgb_align [V, ns, 3], certainty [V, ns])."""
+    K = [[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]]
+    anchor_pose = align_anchor[:, samples]
+    anchor_certain = cert_anchor[:, samples]
+    V, ns = poses.shape[0], samples.numel()
+    rgb_align = torch.zeros(V, ns, 3)
+    cert = torch.zeros(V, ns)
+    outs = []
+    for i in range(V):
+        ro, rd = get_rays(H, W, K, poses[i])
+        rays_org = torch.stack([ro, rd], -1)                      # [H, W, 3, 2]
+        px = anchor_pose[i, :, 2:].long()
+        rays = rays_org[torch.clamp(px[:, 1], 0, H - 1), torch.clamp(px[:, 0], 0, W - 1)]
+        batch = pack_rays(H, W, focal, rays.detach())
+        ret = render_rays(p, batch, N_samples, perturb=0., N_importance=N_importance, raw_noise_std=0.,
+                          with_noise_branch=False, training=True)
+        outs.append(ret["rgb_map"])
+        cert[i] = anchor_certain[i].float()
+    return torch.stack(outs, 0), cert
+
+
+def compute_mean_with_confidence(rgb_align: Tensor, confidence: Tensor, threshold: float = 0.2) -> Tensor:
+    """utils/run_lushnerf_helpers.py:665-688 (vectorised; the per-sample in-place adds are differentiable)."""
+    m = (confidence >= threshold).to(rgb_align.dtype)                 # [V, ns]
+    cnt = m.sum(0)
+    mean = (rgb_align * m[..., None]).sum(0)
+    return mean / torch.where(cnt == 0, torch.ones_like(cnt), cnt)[:, None]
+
+
+def consist_loss(rgb_align: Tensor, certainty: Tensor, threshold: float = 0.8) -> Tensor:
+    """run_lushnerf.py:644-650: masked L1 around the confidence-weighted mean."""
+    mask = certainty >= threshold
+    mean = compute_mean_with_confidence(rgb_align, certainty, threshold)
+    return torch.sum(torch.abs(rgb_align - mean[None]) * mask[..., None]) / mask.sum()

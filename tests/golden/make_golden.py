@@ -13,6 +13,11 @@ torch.rand / torch.randn_like calls are served from those draws in call order
 Only DATA is written: inputs are regenerated from (seed, shape) recorded in the
 fixture; outputs are the reference's tensors.  Gradients of tensors > 4096
 elements are stored as 8 fixed projections + the L2 norm.
+
+Render_Aligned_Pixel (the consistency branch) calls ``.cuda()`` on three tensors it creates and
+draws its anchor / pixel samples from ``random`` / ``np.random``; for that one case
+``torch.Tensor.cuda`` is an identity stand-in (there is no GPU in the build container) and the two
+host draws are served from values recorded in the fixture.  The arithmetic is the reference's.
 """
 import os
 import sys
@@ -230,11 +235,187 @@ def case_checkpoint_layout():
          group0_numel=np.array([p.numel() for p in base]), group1_numel=np.array([p.numel() for p in noise]))
 
 
+def case_sample_pdf_z(seed=8):
+    """sample_pdf on bins that ARE the mid-points of a stored z (what render_rays feeds it,
+    models/lushnerf.py:435-437): lets the GPU kernel, which takes z and weights, run the reference's vectors."""
+    R, S, Ni = 40, 64, 64
+    z = np.sort(synth.uniform((R, S), 0, 1, seed, 1), -1)
+    w = synth.uniform((R, S), 0, 1, seed, 2) ** 8
+    w[:3] = 0.0
+    w[3:6, 12:] = 0.0
+    u = np.minimum(synth.uniform((R, Ni), 0, 1, seed, 3), np.float32(1 - 2 ** -24))
+    zt = torch.from_numpy(z)
+    bins = .5 * (zt[..., 1:] + zt[..., :-1])
+    wt = torch.from_numpy(w)[..., 1:-1]
+    with ServeDraws([u]):
+        s_rand = ref_helpers.sample_pdf(bins, wt, Ni, det=False)
+    s_det = ref_helpers.sample_pdf(bins, wt, Ni, det=True)
+    save("sample_pdf_z", z=z, weights=w, u=u, s_rand=s_rand.numpy(), s_det=s_det.numpy(),
+         merged_rand=torch.sort(torch.cat([zt, s_rand], -1), -1)[0].numpy(),
+         merged_det=torch.sort(torch.cat([zt, s_det], -1), -1)[0].numpy())
+
+
+def nondc_batch(n, seed):
+    """[n,11] ray batch for the no_ndc configuration (run_lushnerf.py:397-399): world-space o, d, near 2, far 6."""
+    b = synth.ray_batch(n, seed, NUM_IMG)
+    o, d = b["rays"][..., 0], b["rays"][..., 1]
+    vd = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    ones = np.ones((n, 1), np.float32)
+    return np.concatenate([o, d, 2.0 * ones, 6.0 * ones, vd], -1).astype(np.float32)
+
+
+def case_lindisp_white(seed=14):
+    """render_rays with lindisp=True and white_bkgd=True (models/lushnerf.py:393-396, 349-350): only reachable
+    with --no_ndc (near > 0), so the ray batch is fed to render_rays directly."""
+    n, Ns, Ni = 40, 64, 64
+    wts = synth.all_weights(NUM_IMG, seed, sharp=True)
+    net = build_ref(Ni, wts)
+    net.train()
+    d = synth.draws(n, Ns, Ni, seed)
+    batch = torch.from_numpy(nondc_batch(n, seed))
+    with torch.no_grad(), ServeDraws([d["t_rand"], d["noise_c"], d["u"], d["noise_f"]]):
+        ret, ret_noise = net.render_rays(batch, N_samples=Ns, retraw=True, lindisp=True, perturb=1.,
+                                         N_importance=Ni, white_bkgd=True, raw_noise_std=1.)
+    arrs = dict(meta=np.array([n, Ns, Ni, seed]), noise_rgb=ret_noise["rgb_map"].numpy())
+    for k, v in ret.items():
+        arrs[k] = v.numpy()
+    save("rays_lindisp_white", **arrs)
+
+
+def case_eval_forward(seed=15):
+    """NeRFAll.forward(poses=...) in eval mode (models/lushnerf.py:671-677 -> render_path :868-896) on a tiny
+    image: tone-mapped rgbs, 0.1*sigmoid noise image, depths."""
+    H_, W_, F_ = 12, 20, 17.5
+    K_ = [[F_, 0, W_ / 2], [0, F_, H_ / 2], [0, 0, 1]]
+    wts = synth.all_weights(NUM_IMG, seed, sharp=True)
+    net = build_ref(64, wts)
+    net.eval()
+    poses = torch.from_numpy(synth.poses(2, seed))
+    rk = dict(perturb=False, N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
+              inference=True, near=0., far=1.)
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        rgbs, noise, depths = net(H_, W_, K_, chunk=128, poses=poses, render_kwargs=rk)
+    save("eval_forward", meta=np.array([H_, W_, seed]), focal=np.array(F_), rgbs=rgbs.numpy(), noise=noise.numpy(),
+         depths=depths.numpy())
+
+
+def case_consistency(seed=31):
+    """The consistency branch (run_lushnerf.py:629-650; models/lushnerf.py:664-668, 949-989):
+    forward(consist_loss=True) in train mode + compute_mean_with_confidence + the masked L1, with gradients."""
+    import random as pyrandom
+    V, ns = 5, 32
+    wts = synth.all_weights(NUM_IMG, seed, sharp=True)
+    net = build_ref(64, wts)
+    net.train()
+    poses = torch.from_numpy(synth.poses(V, seed))
+    HW = H * W
+    anchor = 3
+    samples = (synth.uniform01(ns, seed, 11) * HW).astype(np.int64)
+    # matched pixels of the anchor view in every view: in-image, plus a few that must be clamped
+    ax = synth.uniform((V, ns), -40, W + 40, seed, 12)
+    ay = synth.uniform((V, ns), -30, H + 30, seed, 13)
+    cert_f = synth.uniform((V, ns), 0, 1, seed, 14)
+    cert_f[cert_f < 0.35] = 0.0                       # Align_Mask is torch.bool (run_lushnerf.py:292): nonzero -> True
+    cert_f[:, 5] = 0.0                                # one pixel no view is certain about (count 0 -> mean 0)
+    Align_Matrix = torch.zeros(V, V, HW, 4)
+    Align_Mask = torch.zeros(V, V, HW, dtype=torch.bool)
+    st = torch.from_numpy(samples)
+    Align_Matrix[anchor][:, st, 2] = torch.from_numpy(ax)
+    Align_Matrix[anchor][:, st, 3] = torch.from_numpy(ay)
+    Align_Mask[anchor][:, st] = torch.from_numpy(cert_f) != 0   # what copy_ of a float certainty into the bool table stores
+    rk = dict(perturb=False, N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
+              inference=True, save_warped_ray_img=False, near=0., far=1.)
+    keep = (torch.Tensor.cuda, pyrandom.randint, np.random.randint)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    pyrandom.randint = lambda a, b: anchor
+    np.random.randint = lambda lo, hi=None, size=None: samples.copy()
+    import contextlib, io
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            rgb_align, cert = net(H, W, K, 1 << 20, poses=poses, render_kwargs=rk, render_factor=0,
+                                  rays_info=torch.arange(V), consist_loss=True, Align_matrix=Align_Matrix,
+                                  Align_mask=Align_Mask)
+    finally:
+        torch.Tensor.cuda, pyrandom.randint, np.random.randint = keep
+    mask = cert >= 0.8
+    mean = ref_helpers.compute_mean_with_confidence(rgb_align, cert, 0.8)
+    loss_rgb = torch.sum(torch.abs(rgb_align - mean.unsqueeze(0)) * mask.unsqueeze(2)) / len(mask[mask == 1])
+    loss_rgb.backward()
+    grads, seen = {}, set()
+    for k, p in net.named_parameters():
+        ck = canon_name(k)
+        if ck in seen:
+            continue
+        seen.add(ck)
+        if p.grad is not None:
+            grads[ck] = p.grad
+    arrs = dict(meta=np.array([V, ns, seed, anchor]), samples=samples, ax=ax, ay=ay, cert_in=cert_f,
+                rgb_align=rgb_align.detach().numpy(), certainty=cert.numpy(), mean=mean.detach().numpy(),
+                loss_rgb=np.array(loss_rgb.item()))
+    arrs.update(pack_grads(grads))
+    arrs["grad_none"] = np.array(sorted(set(canon_name(k) for k, p in net.named_parameters() if p.grad is None)))
+    save("consistency", **arrs)
+
+
+def case_trajectory(seed=41, n_rand=32, steps=40):
+    """A short training run of the reference itself: the model of case_train stepped by the reference's optimizer
+    set-up (run_lushnerf.py:359-371: Adam, two parameter groups) and learning-rate rule (:681-685), fresh rays and
+    draws every step.  Stores the loss curve; the GPU modes are compared with it inside a stated band."""
+    Ns = Ni = 64
+    wts = synth.all_weights(NUM_IMG, seed, sharp=True, rbk_scale=2.0e4)
+    net = build_ref(Ni, wts)
+    net.train()
+    noise = list(net.mlp_noise_coarse.parameters())
+    ids = set(map(id, noise))
+    base = [p for p in net.parameters() if id(p) not in ids]
+    lrate, decay = 5e-4, 250
+    opt = torch.optim.Adam([{"params": base}, {"params": noise, "lr": lrate}], lr=lrate)
+    kw = dict(perturb=1., N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
+              inference=False, near=0., far=1.)
+    losses, global_step = [], 0
+    for s in range(steps):
+        b = synth.ray_batch(n_rand, seed, NUM_IMG, step=s)
+        d = synth.draws(n_rand * 5, Ns, Ni, seed, step=s)
+        with ServeDraws([d["t_rand"], d["noise_c"], d["u"], d["noise_f"]]):
+            out = net(H, W, K, chunk=1 << 20, rays=torch.from_numpy(b["rays"]),
+                      rays_info={"images_idx": torch.from_numpy(b["images_idx"])}, retraw=True, force_naive=False,
+                      allkernel=False, kernel_pixel=torch.from_numpy(b["fq_mask"]).bool(), **kw)
+        target = torch.from_numpy(b["target"])
+        loss = ref_helpers.img2mse(out[0], target) * 0.5 + ref_helpers.img2l1(out[0], target) * 0.5 \
+            + ref_helpers.img2mse(out[1], target) * 0.5 + ref_helpers.img2l1(out[1], target) * 0.5
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        new_lrate = lrate * (0.1 ** (global_step / (decay * 1000)))
+        for g in opt.param_groups:
+            g["lr"] = new_lrate
+        global_step += 1
+        losses.append(loss.item())
+        print("traj step", s, loss.item(), flush=True)
+    sd = {canon_name(k): v for k, v in net.state_dict().items()}
+    save("train_trajectory", meta=np.array([n_rand, Ns, Ni, seed, steps]), losses=np.array(losses),
+         final_norms=np.array([float(sd[k].double().norm()) for k in sorted(sd)]),
+         final_keys=np.array(sorted(sd)),
+         final_fine_l3=sd["mlp_fine.pts_linears.3.weight"].numpy()[:8, :8].copy(),
+         final_rgb_w=sd["mlp_fine.rgb_linear.weight"].numpy().copy())
+
+
+NEW_CASES = {"sample_pdf_z": case_sample_pdf_z, "lindisp_white": case_lindisp_white, "eval_forward": case_eval_forward,
+             "consistency": case_consistency, "trajectory": case_trajectory}
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
         case_checkpoint_layout()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in NEW_CASES:      # regenerate one of the round-2 fixtures only
+        for name in sys.argv[1:]:
+            NEW_CASES[name]()
+        for sub in ("", "models", "utils"):
+            assert not os.path.isdir(os.path.join(REF, sub, "__pycache__")), sub
         sys.exit(0)
     case_checkpoint_layout()
     case_sample_pdf()
@@ -245,6 +426,8 @@ if __name__ == "__main__":
     case_train("train_naive_sharp", 32, 64, 64, True, True, 21)
     case_train("train_kernel_sharp", 12, 64, 64, False, True, 22)
     case_train("train_kernel_default", 12, 64, 64, False, False, 23, allkernel=False)
+    for fn in NEW_CASES.values():
+        fn()
     # the imported reference packages must be left untouched (gim/ ships its own
     # upstream __pycache__ dirs; we never import it)
     for sub in ("", "models", "utils"):

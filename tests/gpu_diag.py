@@ -138,9 +138,18 @@ def t_composite():
 
 
 def t_sample():
+    # (a) the reference's own vectors: bins of this fixture ARE the mid-points of its z (make_golden.case_sample_pdf_z)
+    gz = util.golden("sample_pdf_z")
+    zt, wt, ut = (torch.from_numpy(gz[k]) for k in ("z", "weights", "u"))
+    for det in (False, True):
+        zo, zs, zstd = ops.sample_merge(gpu(zt), gpu(wt), 64, None if det else gpu(ut))
+        tag = "det" if det else "rand"
+        rep(f"sample_pdf reference vectors {tag}", zs, gz["s_" + tag], 2e-5)
+        rep(f"merged sort reference vectors {tag}", zo, gz["merged_" + tag], 2e-5)
+        rep(f"z_std reference vectors {tag}", zstd, torch.std(torch.from_numpy(gz["s_" + tag]), -1, unbiased=False), 2e-5)
+    # (b) fresh data against the oracle (which the CPU suite pins to both reference fixtures)
     g = util.golden("sample_pdf")
     R, S = g["bins"].shape[0], g["bins"].shape[1] + 1
-    # build z whose mid-points are the fixture bins is not possible in general: test on fresh data instead
     z = torch.sort(torch.from_numpy(synth.uniform((R, S), 0, 1, 21)), -1)[0]
     w = torch.from_numpy(synth.uniform((R, S), 0, 1, 22)) ** 6
     w[:3] = 0
@@ -363,8 +372,248 @@ def t_march_e2e():
             rep(f"e2e {name} z_std (worst ray)", extras["z_std"], g["z_std"], 5e-2)
             nbad, allowed = int((dz > 2e-3).sum()), max(1, int(5e-3 * dz.size))
             ok = nbad <= allowed
+            if nbad and not train:
+                # the claim behind this gate, checked: every ray that moved has a deterministic u (a linspace value)
+                # sitting on a step of the coarse CDF within a few ulp, where searchsorted's answer is ill-conditioned
+                p_or = util.params(seed, sharp=bool(sharp))
+                with torch.no_grad():
+                    bo = O.pack_rays(H, W, F, b["rays"])
+                    ro = O.render_rays(p_or, bo, Ns, perturb=0., N_importance=0, raw_noise_std=0., training=False,
+                                       render_rmnearplane=80, with_noise_branch=False)
+                wts = ro["_weights"][:, 1:-1] + 1e-5
+                cdf = torch.cumsum(wts / wts.sum(-1, keepdim=True), -1)
+                cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1).double()
+                u = torch.linspace(0., 1., Ni).double()
+                for r in np.nonzero(dz > 2e-3)[0]:
+                    gap = float((cdf[r][:, None] - u[None, :]).abs().min())
+                    on_step = gap < 4e-7
+                    RESULTS.append((f"e2e {name} ray {int(r)}: moved sample sits on a CDF step", gap, 4e-7, on_step))
+                    print(f"{'ok  ' if on_step else 'FAIL'} e2e {name} ray {int(r)} z_std moved {dz[r]:.2e}: min |cdf_k - u_i| = {gap:.2e}", flush=True)
             RESULTS.append((f"e2e {name} z_std (rays beyond 2e-3)", float(nbad), float(allowed), ok))
             print(f"{'ok  ' if ok else 'FAIL'} {'e2e ' + name + ' z_std (rays beyond 2e-3, of ' + str(dz.size) + ')':58s} n={nbad} allowed={allowed}", flush=True)
+
+
+def _nerf_all(Ni=64, seed=0, sharp=True, precision=None, rbk_scale=1.0, train=True):
+    from lush_nerf_amd import model as M
+    import argparse
+    args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+                              N_importance=Ni, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                              rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
+                              render_rmnearplane=80)
+    net = M.NeRFAll(args, M.RBK(util.NUM_IMG, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
+                    precision=precision or ops.Precision(*E2E_PLANES))
+    M.load_reference_weights(net, synth.all_weights(util.NUM_IMG, seed, sharp=sharp, rbk_scale=rbk_scale))
+    return net.to(dev).train(train)
+
+
+def nondc_batch(n, seed):
+    b = synth.ray_batch(n, seed, util.NUM_IMG)
+    o, d = b["rays"][..., 0], b["rays"][..., 1]
+    vd = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    ones = np.ones((n, 1), np.float32)
+    return torch.from_numpy(np.concatenate([o, d, 2.0 * ones, 6.0 * ones, vd], -1).astype(np.float32))
+
+
+def t_lindisp_white():
+    """lindisp=True + white_bkgd=True (models/lushnerf.py:393-396, 349-350) against the reference fixture, forward and
+    (masked oracle) backward."""
+    g = util.golden("rays_lindisp_white")
+    n, Ns, Ni, seed = (int(x) for x in g["meta"])
+    net = _nerf_all(Ni, seed)
+    batch = nondc_batch(n, seed)
+    cpu_draws = util.tdraws(n, Ns, Ni, seed)
+    bg = gpu(batch).requires_grad_(True)
+    ops.DEBUG_KEEP = {}
+    try:
+        ret, ret_noise = net.render_rays(bg, N_samples=Ns, retraw=True, lindisp=True, perturb=1., N_importance=Ni,
+                                         white_bkgd=True, raw_noise_std=1., draws={k: v.to(dev) for k, v in cpu_draws.items()})
+        keep = ops.DEBUG_KEEP
+    finally:
+        ops.DEBUG_KEEP = None
+    for k, tol in (("rgb_map", 1e-4), ("rgb0", 1e-4), ("acc_map", 1e-4), ("acc0", 1e-4), ("depth_map", 1e-3), ("depth0", 1e-3),
+                   ("z_std", 2e-3)):
+        rep(f"lindisp+white {k}", ret[k], g[k], tol)
+    rep("lindisp+white noise rgb", ret_noise["rgb_map"], g["noise_rgb"], 1e-4)
+    G = [gpu(synth.normal((n, 3), 91, i)) for i in range(2)]
+    ((ret["rgb_map"] * G[0]).sum() + (ret["rgb0"] * G[1]).sum() + ret["depth_map"].sum() + ret["acc_map"].sum()).backward()
+    p = util.params(seed, sharp=True, requires_grad=True)
+    bc = batch.clone().requires_grad_(True)
+    masks = _gpu_masks(keep, net.precision)
+    with util.masked_oracle(masks):
+        ro, _ = O.render_rays(p, bc, Ns, retraw=True, lindisp=True, perturb=1., N_importance=Ni, white_bkgd=True,
+                              raw_noise_std=1., draws=cpu_draws)
+        ((ro["rgb_map"] * G[0].cpu()).sum() + (ro["rgb0"] * G[1].cpu()).sum() + ro["depth_map"].sum() + ro["acc_map"].sum()).backward()
+    gate = MASKED_GATE.get(tuple(E2E_PLANES), 3e-2)
+    worst, wk = 0.0, ""
+    for k, v in _canon_grads(net).items():
+        if v is None or p[k].grad is None:
+            continue
+        e = util.relerr(v, p[k].grad)
+        if not e <= worst:
+            worst, wk = e, k
+    RESULTS.append((f"lindisp+white MASKED worst grad [{wk}]", worst, gate, bool(worst <= gate)))
+    print(f"{'ok  ' if worst <= gate else 'FAIL'} lindisp+white masked-oracle worst param grad {wk}: {worst:.3e}")
+    # columns 6, 7 (near, far) take no gradient in the reference either: z_vals come from detached bounds only in value
+    rep("lindisp+white MASKED d ray batch (o, d, viewdir)", bg.grad[:, [0, 1, 2, 3, 4, 5, 8, 9, 10]],
+        bc.grad[:, [0, 1, 2, 3, 4, 5, 8, 9, 10]], gate)
+
+
+def _canon_grads(net):
+    grads = {}
+    for k, v in net.named_parameters():
+        ck = k
+        if k.startswith("blur_kernel_net.RBK."):
+            ck = "mlp_rbk." + k[len("blur_kernel_net.RBK."):]
+        elif k.startswith("blur_kernel_net.view_embed_layer."):
+            ck = "mlp_rbk.view_embedding_layer.view_embed_layer.weight"
+        grads[ck] = v.grad
+    return grads
+
+
+def t_eval_forward():
+    """NeRFAll.forward(poses=...) in eval mode against the reference fixture (render_path over every
+    pixel through lush_gen_rays_image, near-plane mask, 0.1*sigmoid noise image, tone map)."""
+    g = util.golden("eval_forward")
+    Hh, Ww, seed = (int(x) for x in g["meta"])
+    Ff = float(g["focal"])
+    K = [[Ff, 0, Ww / 2], [0, Ff, Hh / 2], [0, 0, 1]]
+    net = _nerf_all(64, seed, train=False)
+    rk = dict(perturb=False, N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
+              inference=True, near=0., far=1.)
+    rgbs, noise, depths = net(Hh, Ww, K, chunk=128, poses=gpu(synth.poses(2, seed)), render_kwargs=rk)
+    rep("eval forward rgbs", rgbs, g["rgbs"], 1e-4)
+    rep("eval forward noise image", noise, g["noise"], 1e-4)
+    rep("eval forward depths", depths, g["depths"], 1e-3)
+    # device-side image rays against the host formula of the reference
+    c2w = torch.from_numpy(synth.poses(2, seed))[1]
+    ro, rd = O.get_rays(Hh, Ww, K, c2w)
+    img = ops.gen_rays_image(gpu(c2w), Hh, Ww, K)
+    rep("gen_rays_image origins", img[..., 0], ro, 0.0)
+    rep("gen_rays_image directions", img[..., 1], rd, 2e-7)
+
+
+def consistency_inputs(g):
+    V, ns, seed, anchor = (int(x) for x in g["meta"])
+    HW = H * W
+    st = torch.from_numpy(g["samples"])
+    am = torch.zeros(V, HW, 4)
+    am[:, st, 2] = torch.from_numpy(g["ax"])
+    am[:, st, 3] = torch.from_numpy(g["ay"])
+    cm = torch.zeros(V, HW, dtype=torch.bool)
+    cm[:, st] = torch.from_numpy(g["cert_in"]) != 0
+    return V, ns, seed, anchor, st, am, cm
+
+
+def t_consistency():
+    """NeRFAll.forward(consist_loss=True) -> Render_Aligned_Pixel (lush_align_rays + one march) and the
+    masked-L1 consistency term (lush_consist_loss_fwd_bwd), against the reference fixture and the masked oracle."""
+    g = util.golden("consistency")
+    V, ns, seed, anchor, st, am, cm = consistency_inputs(g)
+    net = _nerf_all(64, seed)
+    K = [[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]]
+    rk = dict(perturb=False, N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
+              inference=True, save_warped_ray_img=False, near=0., far=1.)
+    poses = torch.from_numpy(synth.poses(V, seed))
+    ops.DEBUG_KEEP = {}
+    try:     # the tables are indexed by the anchor only: {anchor: [V, HW, ...]} stands in for the [V, V, HW, ...] tensors
+        rgb_align, cert = net(H, W, K, 1 << 20, poses=gpu(poses), render_kwargs=rk, render_factor=0,
+                              rays_info=torch.arange(V), consist_loss=True, Align_matrix={anchor: gpu(am)},
+                              Align_mask={anchor: gpu(cm)}, anchor_pose=anchor, samples=st)
+        keep = ops.DEBUG_KEEP
+    finally:
+        ops.DEBUG_KEEP = None
+    rep("consistency rgb_align", rgb_align, g["rgb_align"], 1e-4)
+    rep("consistency align_certainty", cert, g["certainty"], 0.0)
+    loss = ops.ConsistLoss.apply(rgb_align, cert, 0.8)
+    loss.backward()
+    rep("consistency loss_rgb", loss.reshape(1), g["loss_rgb"].reshape(1), 1e-5)
+    # float certainty table takes the same path
+    rg2, cert2 = ops.align_rays(gpu(poses), gpu(am), gpu(cm.float() * 0.9), st, H, W, K)
+    rep("consistency certainty from a float table", cert2, g["certainty"] * 0.9, 1e-7)
+    grads = _canon_grads(net)
+    none_ref = set(str(x) for x in g["grad_none"])
+    none_got = set(k for k, v in grads.items() if v is None)
+    ok = none_ref == none_got
+    RESULTS.append(("consistency grad-None set", 0. if ok else 1., 0, ok))
+    print("ok  " if ok else "FAIL", "consistency grad None set", sorted(none_ref ^ none_got)[:6])
+    p = util.params(seed, sharp=True, requires_grad=True)
+    with util.masked_oracle(_gpu_masks(keep, net.precision)):
+        ra, ca = O.render_aligned_pixel(p, H, W, F, poses, am, cm, st, 64, 64)
+        O.consist_loss(ra, ca, 0.8).backward()
+    gate = MASKED_GATE.get(tuple(E2E_PLANES), 3e-2)
+    worst, wk = 0.0, ""
+    for k, v in grads.items():
+        if v is None:
+            continue
+        e = util.relerr(v, p[k].grad)
+        if not e <= worst:
+            worst, wk = e, k
+    RESULTS.append((f"consistency MASKED worst grad [{wk}]", worst, gate, bool(worst <= gate)))
+    print(f"{'ok  ' if worst <= gate else 'FAIL'} consistency masked-oracle worst param grad {wk}: {worst:.3e}")
+    w2 = util.check_grads({k: v for k, v in grads.items() if v is not None}, g, 1e9)
+    wk = max(w2, key=w2.get)
+    sec = 3e-2 if E2E_PLANES[0] in (2, 3) else 1e-1
+    RESULTS.append((f"consistency worst grad vs fixture [{wk}]", w2[wk], sec, bool(w2[wk] <= sec)))
+    print(f"{'ok  ' if w2[wk] <= sec else 'FAIL'} consistency worst grad vs reference fixture {wk}: {w2[wk]:.3e}")
+    # the loss kernel alone, against torch autograd through compute_mean_with_confidence
+    rr = torch.from_numpy(synth.uniform((7, 32, 3), 0, 1, 77)).requires_grad_(True)
+    cc = torch.from_numpy(synth.uniform((7, 32), 0.5, 1, 78))
+    cc[:, 3] = 0.1
+    lo = O.consist_loss(rr, cc, 0.8)
+    lo.backward()
+    rg = gpu(rr.detach()).requires_grad_(True)
+    lg = ops.ConsistLoss.apply(rg, gpu(cc), 0.8)
+    lg.backward()
+    rep("consist loss kernel fwd", lg.reshape(1), lo.reshape(1), 2e-6)
+    rep("consist loss kernel bwd", rg.grad, rr.grad, 2e-6)
+
+
+def t_faults():
+    """The numerical-fault word (models/lushnerf.py:474-478, 578-582 print per key; here one device word)."""
+    from lush_nerf_amd import lib as L
+    n, Ns, Ni, seed = 16, 64, 64, 5
+    b = batch_of(n, seed)
+    K = [[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]]
+    kw = dict(perturb=1., N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
+              inference=False, near=0., far=1., retraw=True)
+
+    def word(mutate):
+        net = _nerf_all(Ni, seed)
+        with torch.no_grad():
+            mutate(net)
+            net.render_infer(H, W, K, 1 << 20, rays=gpu(b["rays"]), **kw)
+        return net.read_faults()
+    clean = word(lambda net: None)
+    RESULTS.append(("fault word of a clean run", float(clean), 0, clean == 0))
+    w1 = word(lambda net: net.mlp_fine.rgb_linear.bias.fill_(float("nan")))
+    ok1 = (w1 & (L.FAULT_BITS["rgb_map"] | L.FAULT_BITS["raw"])) == (L.FAULT_BITS["rgb_map"] | L.FAULT_BITS["raw"]) and not (w1 & L.FAULT_BITS["rgb0"])
+    RESULTS.append((f"NaN in the fine rgb head -> rgb_map + raw bits ({L.fault_names(w1)})", float(w1), 0, ok1))
+    w2 = word(lambda net: net.mlp_coarse.alpha_linear.bias.fill_(float("inf")))
+    ok2 = bool(w2 & L.FAULT_BITS["density0"]) and bool(w2 & L.FAULT_BITS["raw0"])
+    RESULTS.append((f"Inf in the coarse sigma head -> density0 + raw0 bits ({L.fault_names(w2)})", float(w2), 0, ok2))
+    for r in RESULTS[-3:]:
+        print("ok  " if r[3] else "FAIL", r[0], flush=True)
+
+
+# Gate of the masked end-to-end gradient check per precision mode (normalised max error per parameter tensor
+# against torch autograd on the oracle evaluated with the GPU's own ReLU decisions): what is left is arithmetic.
+# (2,2)/(3,3): split-bf16 products are fp32-equivalent; (x,1): one bf16 plane in the backward, measured bound.
+MASKED_GATE = {(3, 3): 1e-4, (2, 2): 2e-4, (2, 1): 2.5e-2, (ops.PLANES_F16, 1): 2.5e-2, (1, 1): 5e-2}
+
+
+def _gpu_masks(keep, precision):
+    """ReLU decisions of the coarse / fine / noise MLP evaluations of the last forward (ops.DEBUG_KEEP)."""
+    pf, pb = precision.fwd, precision.bwd
+    f16 = pf == ops.PLANES_F16
+    sp = ops.nplanes(ops.stash_code(pf, pb))
+    out = {"mlp_coarse": util.stash_masks(ops.NET_NERF, sp, keep["P_c"], keep["stash_c"], f16=f16)}
+    if keep.get("stash_f") is not None:
+        out["mlp_fine"] = util.stash_masks(ops.NET_NERF, sp, keep["P_f"], keep["stash_f"], f16=f16)
+    if keep.get("stash_noise") is not None:
+        pn = precision.noise()
+        out["mlp_noise_coarse"] = util.stash_masks(ops.NET_NOISE, ops.nplanes(ops.stash_code(pn.fwd, pn.bwd)), keep["P_noise"],
+                                                   keep["stash_noise"], f16=False)
+    return out
 
 
 def t_train_e2e():
@@ -378,24 +627,33 @@ def t_train_e2e():
                                   rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
                                   render_rmnearplane=80)
         rbk = M.RBK(util.NUM_IMG, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4)
-        net = M.NeRFAll(args, rbk, precision=ops.Precision(*E2E_PLANES))
-        M.load_reference_weights(net, synth.all_weights(util.NUM_IMG, seed, sharp=bool(sharp),
-                                                        rbk_scale=1.0 if naive else 2.0e4))
+        prec = ops.Precision(*E2E_PLANES)
+        net = M.NeRFAll(args, rbk, precision=prec)
+        rbk_scale = 1.0 if naive else 2.0e4
+        M.load_reference_weights(net, synth.all_weights(util.NUM_IMG, seed, sharp=bool(sharp), rbk_scale=rbk_scale))
         net = net.to(dev).train()
         b = batch_of(n, seed)
         K = [[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]]
-        draws = {k: v.to(dev) for k, v in util.tdraws(n * (1 if naive else 5), Ns, Ni, seed).items()}
+        cpu_draws = util.tdraws(n * (1 if naive else 5), Ns, Ni, seed)
+        draws = {k: v.to(dev) for k, v in cpu_draws.items()}
         rays = gpu(b["rays"]).requires_grad_(True)
-        out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": gpu(b["images_idx"])}, retraw=True,
-                  force_naive=bool(naive), allkernel=bool(allk), kernel_pixel=gpu(b["fq_mask"]), perturb=1.,
-                  N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
-                  inference=False, near=0., far=1., draws=draws)
+        ops.DEBUG_KEEP = {}
+        try:
+            out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": gpu(b["images_idx"])}, retraw=True,
+                      force_naive=bool(naive), allkernel=bool(allk), kernel_pixel=gpu(b["fq_mask"]), perturb=1.,
+                      N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
+                      inference=False, near=0., far=1., draws=draws)
+            keep = ops.DEBUG_KEEP
+        finally:
+            ops.DEBUG_KEEP = None
         loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
         loss.backward()
         rep(f"train {name} rgb_blur", out[0], g["rgb_blur"], 1e-4)
         rep(f"train {name} rgb0_blur", out[1], g["rgb0_blur"], 1e-4)
         rep(f"train {name} noise", out[3], g["noise"], 1e-4)
         rep(f"train {name} loss", loss.reshape(1), g["loss"].reshape(1), 1e-4)
+        fw = net.read_faults()
+        RESULTS.append((f"train {name} fault word", float(fw), 0, fw == 0))
         sd = dict(net.named_parameters())
         grads = {}
         for k, v in sd.items():
@@ -410,24 +668,49 @@ def t_train_e2e():
         ok = none_ref == none_got
         RESULTS.append((f"train {name} grad-None set", 0. if ok else 1., 0, ok))
         print("ok  " if ok else "FAIL", f"train {name} grad None set", sorted(none_ref ^ none_got)[:6])
-        try:
-            worst = util.check_grads({k: v for k, v in grads.items() if v is not None}, g, 1e9)
-            wk = max(worst, key=worst.get)
-            RESULTS.append((f"train {name} worst grad [{wk}]", worst[wk], 3e-2, worst[wk] <= 3e-2))
-            print(f"{'ok  ' if worst[wk] <= 3e-2 else 'FAIL'} train {name} worst grad {wk}: {worst[wk]:.3e}")
-            for k in sorted(worst, key=worst.get, reverse=True)[:5]:
-                print(f"       {k}: {worst[k]:.3e}")
-        except Exception:
-            traceback.print_exc()
+        # (1) PRIMARY gradient gate: torch autograd on the oracle with every MLP ReLU replaced by the decision the
+        # GPU took (read from its stash), so only arithmetic separates the two.  Any exception or NaN fails.
+        p = util.params(seed, sharp=bool(sharp), rbk_scale=rbk_scale, requires_grad=True)
+        rays_c = b["rays"].clone().requires_grad_(True)
+        with util.masked_oracle(_gpu_masks(keep, prec)) as mo:
+            ref = O.forward_train(p, H, W, F, rays_c, b["images_idx"], Ns, Ni, force_naive=bool(naive),
+                                  allkernel=bool(allk), kernel_pixel=b["fq_mask"], draws=cpu_draws)
+            O.train_loss(ref[0], ref[1], b["target"]).backward()
+        gate = MASKED_GATE.get(tuple(E2E_PLANES), 3e-2)
+        worst, wk = 0.0, ""
+        for k, v in grads.items():
+            if v is None:
+                continue
+            e = util.relerr(v, p[k].grad)
+            if not e <= worst:       # NaN propagates into worst
+                worst, wk = e, k
+        RESULTS.append((f"train {name} MASKED worst grad [{wk}]", worst, gate, bool(worst <= gate)))
+        print(f"{'ok  ' if worst <= gate else 'FAIL'} train {name} masked-oracle worst param grad {wk}: {worst:.3e} gate={gate:.1e}", flush=True)
+        if rays.grad is not None and rays_c.grad is not None:
+            rep(f"train {name} MASKED grad_rays", rays.grad, rays_c.grad, gate)
+        for pre, (d, t) in mo.flips.items():     # how many ReLU decisions differ from the fp32 oracle's own
+            frac = d / max(t, 1)
+            flip_gate = 2e-4 if E2E_PLANES[0] in (2, 3) else 5e-3
+            RESULTS.append((f"train {name} ReLU decisions differing from fp32 [{pre}]", frac, flip_gate, frac <= flip_gate))
+            print(f"{'ok  ' if frac <= flip_gate else 'FAIL'} train {name} {pre}: {int(d)} of {t} ReLU decisions differ from the fp32 oracle ({frac:.2e})")
+        # (2) SECONDARY: against the reference fixture, un-masked (includes the discrete effect of flipped kinks)
+        worst = util.check_grads({k: v for k, v in grads.items() if v is not None}, g, 1e9)
+        wk = max(worst, key=worst.get)
+        sec = 3e-2 if E2E_PLANES[0] in (2, 3) else 1e-1
+        RESULTS.append((f"train {name} worst grad vs fixture [{wk}]", worst[wk], sec, bool(worst[wk] <= sec)))
+        print(f"{'ok  ' if worst[wk] <= sec else 'FAIL'} train {name} worst grad vs reference fixture {wk}: {worst[wk]:.3e}")
+        for k in sorted(worst, key=worst.get, reverse=True)[:3]:
+            print(f"       {k}: {worst[k]:.3e}")
         if g["grad_rays"].size and rays.grad is not None:
-            rep(f"train {name} grad_rays", rays.grad, g["grad_rays"], 3e-2)
+            rep(f"train {name} grad_rays vs fixture", rays.grad, g["grad_rays"], sec)
 
 
 if __name__ == "__main__":
     lib.load()
     print("device:", torch.cuda.get_device_name(0))
     only = sys.argv[1:]
-    for fn in (t_zgrid_pack, t_gen_rays, t_composite, t_sample, t_mlp_fwd, t_mlp_ragged, t_mlp_bwd, t_rbk, t_mix, t_march_e2e, t_train_e2e):
+    for fn in (t_zgrid_pack, t_gen_rays, t_composite, t_sample, t_mlp_fwd, t_mlp_ragged, t_mlp_bwd, t_rbk, t_mix, t_march_e2e, t_train_e2e,
+               t_lindisp_white, t_eval_forward, t_consistency, t_faults):
         if not only or fn.__name__ in only:
             section(fn)
     bad = [r for r in RESULTS if not r[3]]

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     assert set(lib.EXPORTS) <= declared | {"lush_last_error"}
     l = lib.load()
-    assert l.lush_abi_version() == 1
+    assert l.lush_abi_version() == lib.ABI_VERSION == 2
     # pure host queries (no device work)
     p1, p3 = l.lush_mlp_packed_bytes(0, 1), l.lush_mlp_packed_bytes(0, 3)
     assert p1 > 2 * 593408 * 2 and 2.9 * p1 < p3 < 3 * p1      # fragments scale with planes, the fp32 bias block does not
@@ -145,6 +145,129 @@ def test_data_parallel_allreduce_two_ranks_gloo(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-1000:]
 
 
+_TRAINER_DIST_SCRIPT = r'''
+"""Two gloo ranks drive the REAL Trainer.step control flow (zero-grad, micro-batch loop, one all-reduce of the flat
+gradient, three Adam segments with grad_scale = 1/world, lr schedule); the HIP forward+backward of a slice is replaced
+by injected rank-dependent gradients and the Adam kernel by its torch restatement, nothing else."""
+import argparse, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lush_nerf_amd import model as M, synth
+from lush_nerf_amd.trainer import Trainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+                          N_importance=64, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                          rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma", render_rmnearplane=80)
+net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4))
+M.load_reference_weights(net, synth.all_weights(30, 50 + rank))       # ranks start DIFFERENT on purpose
+calls = []
+
+def fake_fwd_bwd(batch, a, b, i, draws, frac, force_naive):
+    g = torch.from_numpy(synth.normal((tr.flat.numel,), 7000 + 10 * i + rank, a)) * frac
+    if force_naive:                       # the reference leaves RBK + noise MLP with grad=None in the naive phase
+        s1 = tr.flat.segments[1]
+        g[s1[0]:s1[1]] = 0
+    s2 = tr.flat.segments[2]
+    g[s2[0]:s2[1]] = 0                    # mlp_noise_coarse.alpha_linear never receives a gradient
+    tr.flat.grad += g
+    calls.append((a, b, i, frac))
+    return torch.tensor(float(rank + 1) * frac)
+
+def torch_adam(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    g = grad * grad_scale
+    m.lerp_(g, 1 - beta1); v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = v.sqrt() / (1 - beta2 ** step) ** 0.5 + eps
+    param.sub_((lr / (1 - beta1 ** step)) * m / denom)
+
+tr = Trainer(net, 640, 1120, 1000.0, kernel_start_iter=1, distributed=True, micro_batch=16, step_fn=fake_fwd_bwd)
+tr._adam = torch_adam
+assert tr.world == 2 and tr.distributed
+# construction broadcast: both ranks now hold rank 0's weights
+w0 = torch.from_numpy(synth.all_weights(30, 50)["mlp_fine.pts_linears.3.weight"])
+assert torch.equal(net.mlp_fine.pts_linears[3].weight.detach(), w0), "parameters were not broadcast from rank 0"
+assert tr.replica_checksum() == 0.0
+ref_p = tr.flat.param.clone(); ref_m = torch.zeros_like(ref_p); ref_v = torch.zeros_like(ref_p)
+steps = [0, 0, 0]
+batch = {"target": torch.zeros(40, 3)}
+for i in range(3):                         # i = 0 is the naive phase (kernel_start_iter = 1)
+    before = tr.flat.param.clone()
+    lr_used = tr.lr()
+    loss = tr.step(batch, i)
+    assert [c[:2] for c in calls[-3:]] == [(0, 16), (16, 32), (32, 40)], calls[-3:]      # micro-batches of 16 input rays
+    # what the reference's DataParallel computes: gradient of the mean loss over the global batch = mean of rank grads
+    gsum = torch.zeros(tr.flat.numel)
+    for r in range(world):
+        for a, b in ((0, 16), (16, 32), (32, 40)):
+            g = torch.from_numpy(synth.normal((tr.flat.numel,), 7000 + 10 * i + r, a)) * ((b - a) / 40)
+            gsum += g
+    if i < 1:
+        s1 = tr.flat.segments[1]; gsum[s1[0]:s1[1]] = 0
+    s2 = tr.flat.segments[2]; gsum[s2[0]:s2[1]] = 0
+    assert torch.allclose(tr.flat.grad, gsum, rtol=1e-5, atol=2e-6), "flat gradient != sum over ranks"   # fp32 association differs
+    active = [True, i >= 1, False]
+    for s, (a, b) in enumerate(tr.flat.segments):
+        if active[s]:
+            steps[s] += 1
+            torch_adam(ref_p[a:b], gsum[a:b], ref_m[a:b], ref_v[a:b], lr_used, steps[s], grad_scale=1.0 / world)
+    assert torch.allclose(tr.flat.param, ref_p, rtol=1e-5, atol=1e-7), f"step {i}: parameters != Adam on the mean gradient"
+    s1, s2 = tr.flat.segments[1], tr.flat.segments[2]
+    assert torch.equal(tr.flat.param[s2[0]:s2[1]], before[s2[0]:s2[1]]), "dead segment was stepped"
+    if i < 1:
+        assert torch.equal(tr.flat.param[s1[0]:s1[1]], before[s1[0]:s1[1]]), "RBK/noise segment stepped in the naive phase"
+    else:
+        assert not torch.equal(tr.flat.param[s1[0]:s1[1]], before[s1[0]:s1[1]])
+    assert tr.replica_checksum() == 0.0, "replicas diverged"
+    chk = [torch.zeros_like(tr.flat.param) for _ in range(world)]
+    dist.all_gather(chk, tr.flat.param)
+    assert torch.equal(chk[0], chk[1])
+assert tr.steps == [3, 2, 0] and tr.global_step == 3
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], f"trainer_rank{rank}.ok"), "w").write("ok")
+'''
+
+
+def test_trainer_step_two_ranks_gloo(tmp_path):
+    """SURVEY 8e / BASELINE config 4 on CPU: the real Trainer.step over gloo, world size 2."""
+    import socket
+    script = tmp_path / "dp_trainer.py"
+    script.write_text(_TRAINER_DIST_SCRIPT)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT, str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / "trainer_rank0.ok").exists() and (tmp_path / "trainer_rank1.ok").exists()
+
+
+def test_bench_refuses_wrong_world(tmp_path):
+    """bench.py --gpus N must never print an N-GPU line from fewer ranks: it self-launches N ranks when no launcher set
+    WORLD_SIZE (and fails when the devices are missing) and refuses a launcher whose world size differs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "only" in (r.stdout + r.stderr) and '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr) and '"metric"' not in r.stdout
+
+
+def test_trainer_lr_follows_reference_loop():
+    """run_lushnerf.py:675-685, 788: step g runs with the rate computed from global_step g-1."""
+    from oracle import lush_oracle as O
+    _, tr = _small_trainer(1)
+    used = []
+    for g in range(6):
+        used.append(tr.lr())
+        tr.global_step += 1
+    assert used == O.lr_schedule(6)
+    tr.global_step = 250000
+    assert abs(tr.lr() - O.lr_at(249999)) < 1e-18 and abs(tr.lr() / 5e-5 - 1) < 1e-4
+
+
 def _small_trainer(seed=0):
     import argparse
     from lush_nerf_amd import model as M
@@ -196,3 +319,17 @@ def test_checkpoint_interop_with_reference_layout(tmp_path):
     assert tr2.steps == [7, 5, 0] and tr2.global_step == 7
     a, b = tr.flat.segments[1]
     assert torch.equal(tr2.m[:b], tr.m[:b]) and torch.equal(tr2.v[:b], tr.v[:b])
+    # the reference resumes with the rate its optimizer was saved with (lr of global_step 7), for one step
+    assert tr2._lr_next == pytest.approx(5e-4 * 0.1 ** (7 / 250000), rel=1e-12)
+    # without a trainer the file still carries the reference's two parameter groups (its loader calls
+    # optimizer.load_state_dict unconditionally, run_lushnerf.py:386) and global_step is restored
+    path2 = str(tmp_path / "000009.tar")
+    CK.save_checkpoint(path2, net, 9)
+    ck2 = torch.load(path2, weights_only=False)
+    opt2 = torch.optim.Adam([{"params": base}, {"params": noise, "lr": 5e-4}], lr=5e-4)
+    opt2.load_state_dict(ck2["optimizer_state_dict"])
+    assert len(opt2.state) == 0
+    net3, tr3 = _small_trainer(5)
+    tr3.m.fill_(1.0); tr3.steps = [4, 4, 0]
+    assert CK.load_checkpoint(path2, net3, tr3) == 9
+    assert tr3.global_step == 9 and tr3.steps == [0, 0, 0] and float(tr3.m.abs().max()) == 0.0

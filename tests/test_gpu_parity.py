@@ -7,7 +7,13 @@ Tolerances (normalised max error = max|a-b| / max|b|):
     differences by 1/pdf (a property of the reference algorithm in fp32, see DESIGN.md);
   * kernel-level backward vs torch autograd with the GPU's own ReLU decisions: 2e-5 (3 planes),
     2e-4 (2 planes), 3e-2 (1 plane = plain bf16);
-  * end-to-end gradients vs the reference fixture: 3e-2 (ReLU-kink conditioning).
+  * END-TO-END gradients, primary gate: the oracle's forward_train with every MLP ReLU replaced by the decision the
+    GPU took (read back from its stash), torch autograd on that -- per parameter tensor 2e-4 in the (2,2) mode, the
+    measured bound gpu_diag.MASKED_GATE in the others; plus the count of decisions that differ from the fp32 oracle;
+  * secondary: end-to-end gradients vs the reference fixture, un-masked: 3e-2 (includes the discrete effect of the
+    few flipped ReLU kinks, DESIGN.md);
+  * a 40-step training trajectory of the reference itself (tests/golden/train_trajectory.npz) that every precision
+    mode must follow inside a stated band.
 """
 import pytest
 import torch
@@ -15,7 +21,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SECTIONS = ["t_zgrid_pack", "t_gen_rays", "t_composite", "t_sample", "t_mlp_fwd", "t_mlp_ragged", "t_mlp_bwd", "t_rbk", "t_mix",
-            "t_march_e2e", "t_train_e2e"]
+            "t_march_e2e", "t_train_e2e", "t_lindisp_white", "t_eval_forward", "t_consistency", "t_faults"]
 
 
 @pytest.fixture(scope="module")
@@ -40,9 +46,9 @@ def test_kernel_parity(diag, section):
 
 def test_fp16_forward_mode(diag, monkeypatch):
     """Optional mode (h,1): ONE fp16 plane in the forward.  Render outputs stay inside the 1e-4 bound
-    (measured 2.7e-5) at a third of the MFMA work; the price is gradient noise from ReLU kinks flipped
-    by the larger forward rounding (measured 4e-2..7e-2 vs the reference fixtures, gated at 1e-1) and a
-    looser z_std (sample_pdf conditioning), which is why it is not the bench headline."""
+    (measured 2.7e-5) at a third of the MFMA work; the price is that more ReLU decisions differ from the fp32
+    oracle's (counted and gated in t_train_e2e) and a looser z_std (sample_pdf conditioning), which is why it is
+    not the bench headline.  Gradient gates are gpu_diag's mode-aware ones (masked primary, fixture secondary)."""
     monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes("h,1"))
     diag.RESULTS.clear()
     diag.t_march_e2e()
@@ -52,17 +58,12 @@ def test_fp16_forward_mode(diag, monkeypatch):
             assert e < 1e-4, (n, e)
         if n.endswith("depth_map"):
             assert e < 1e-3, (n, e)
-        if n.endswith("z_std"):
-            assert e < 3e-2, (n, e)
+        if n.endswith("z_std (worst ray)"):
+            assert e < 5e-2, (n, e)
     diag.RESULTS.clear()
     diag.t_train_e2e()
-    for n, e, t, ok in diag.RESULTS:
-        if "worst grad" in n or n.endswith("grad_rays"):
-            assert e < 1e-1, (n, e)
-        elif "grad-None" in n:
-            assert ok, n
-        else:
-            assert e < 1e-4, (n, e)
+    bad = [(n, e, t) for n, e, t, ok in diag.RESULTS if not ok]
+    assert not bad, bad[:8]
 
 
 @pytest.mark.parametrize("planes", ["2,1"])
@@ -70,7 +71,7 @@ def test_headline_mode_end_to_end(diag, planes, monkeypatch):
     """The bench headline mode (2 planes forward, bf16 backward): forward within 1e-4 of the reference
     fixtures, end-to-end gradients inside the same 3e-2 gate as the fp32-equivalent mode."""
     monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes(planes))
-    for section in ("t_march_e2e", "t_train_e2e"):
+    for section in ("t_march_e2e", "t_train_e2e", "t_consistency", "t_lindisp_white"):
         diag.RESULTS.clear()
         getattr(diag, section)()
         bad = [(n, e, t) for n, e, t, ok in diag.RESULTS if not ok]
@@ -240,3 +241,245 @@ def test_eval_path_runs(diag):
     rgbs, noise, depths = net(H, W, K, chunk=512, poses=poses, render_kwargs=rk)
     assert rgbs.shape == (2, H, W, 3) and noise.shape == (2, H, W, 3) and depths.shape == (2, H, W)
     assert bool(torch.isfinite(rgbs).all()) and bool(torch.isfinite(noise).all())
+
+
+def test_full_size_backward_is_additive_over_rays(diag):
+    """BASELINE config 2 size, backward: the loss is a mean over rays, so the gradient of the full 4096-ray batch
+    equals the sum of the gradients of its two halves (each weighted by its share) -- fp32-equivalent mode, 2e-4."""
+    from lush_nerf_amd import synth
+    from lush_nerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    n = 4096
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(n, 4).items()}
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(n * 5, 64, 64, 4).items()}
+    res = []
+    for mb in (0, 2048):
+        net = _model(seed=6, precision=(2, 2))
+        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64, micro_batch=mb)
+        loss = tr.step(b, 0, draws=d)
+        res.append((float(loss), tr.flat.grad.clone()))
+        assert tr.faults() == 0
+        del tr, net
+    assert abs(res[0][0] - res[1][0]) < 2e-6 * max(1.0, abs(res[0][0]))
+    assert diag.util.relerr(res[1][1], res[0][1]) < 2e-4
+    a, bb = 0, 2 * 595844          # per segment too: coarse + fine MLP block
+    assert diag.util.relerr(res[1][1][a:bb], res[0][1][a:bb]) < 2e-4
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C5"])
+def test_large_configs_spot_parity(diag, cfg):
+    """BASELINE configs 3 / 5 at their full marched-ray counts (40 960 rays 64+64; 81 920 rays 128+128), forward:
+    64 rays spread over the batch against the oracle at 1e-4, as for config 2."""
+    from lush_nerf_amd import ops, synth
+    from oracle import lush_oracle as O
+    dev = torch.device("cuda:0")
+    R, Ns, Ni = (40960, 64, 64) if cfg == "C3" else (81920, 128, 128)
+    net = _model(Ni=Ni).train()
+    b = synth.ray_batch(R, 15)
+    batch = ops.PackRays.apply(torch.from_numpy(b["rays"]).to(dev), synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, True, 0., 1.)
+    idx = torch.arange(0, R, R // 64)[:64]
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(R, Ns, Ni, 15).items()}
+    with torch.no_grad():
+        cfgm = ops.MarchCfg(Ns, Ni, 1., 1., precision=ops.Precision(2, 2), want_grad=False)
+        coarse, fine = net.mlp_coarse.tensors(), net.mlp_fine.tensors()
+        out = ops.March.apply(batch, cfgm, d, len(coarse), *coarse, *fine)
+        p = {k: v.detach().cpu() for k, v in _canon(net).items()}
+        ref = O.render_rays(p, batch[idx].cpu(), Ns, perturb=1., N_importance=Ni, raw_noise_std=1.,
+                            draws={k: v[idx].cpu() for k, v in d.items()}, with_noise_branch=False)
+    assert diag.util.relerr(out[0][idx], ref["rgb_map"]) < 1e-4
+    assert diag.util.relerr(out[7][idx], ref["rgb0"]) < 1e-4
+    assert diag.util.relerr(out[1][idx], ref["depth_map"]) < 1e-3
+    z = out[6]
+    assert bool((z[:, 1:] >= z[:, :-1]).all()) and float((out[2] - 1).abs().max()) < 4e-6
+
+
+# Band of the training-trajectory test: max over the 40 steps of |loss_gpu - loss_reference| / loss_reference.
+# The reference run is fp32 torch on CPU; rays and draws are fresh every step, so the curve tests the composed
+# forward + backward + Adam + lr path, and errors compound through the parameters.
+TRAJ_BAND = {"2,2": 2e-3, "2,1": 5e-3, "h,1": 1e-2}
+
+
+@pytest.mark.parametrize("planes", ["2,2", "2,1", "h,1"])
+def test_training_trajectory_follows_the_reference(diag, planes):
+    """40 optimisation steps (32 rays x 5 motions, 64+64, blur kernel on, fresh rays/draws each step) of the REAL
+    reference (make_golden.case_trajectory: its model, torch.optim.Adam in its two-group set-up, its lr rule) against
+    Trainer.step in each precision mode.  This, not a fixed gradient tolerance, is what qualifies a mode as headline."""
+    import numpy as np
+    from lush_nerf_amd import model as M, ops, synth
+    from lush_nerf_amd.trainer import Trainer
+    g = diag.util.golden("train_trajectory")
+    n, Ns, Ni, seed, steps = (int(x) for x in g["meta"])
+    dev = torch.device("cuda:0")
+    import argparse
+    args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+                              N_importance=Ni, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                              rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma", render_rmnearplane=80)
+    net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
+                    precision=ops.Precision(*ops.parse_planes(planes)))
+    M.load_reference_weights(net, synth.all_weights(30, seed, sharp=True, rbk_scale=2.0e4))
+    net = net.to(dev)
+    tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni, kernel_start_iter=0, allkernel_start_iter=0)
+    losses = []
+    for s in range(steps):
+        b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(n, seed, 30, step=s).items()}
+        d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(n * 5, Ns, Ni, seed, step=s).items()}
+        losses.append(float(tr.step(b, s, draws=d)))
+    assert tr.faults() == 0
+    ref = np.asarray(g["losses"], dtype=np.float64)
+    dev_rel = np.abs(np.asarray(losses) - ref) / ref
+    sd = _canon(net)
+    keys = [str(k) for k in g["final_keys"]]
+    norms = np.array([float(sd[k].double().norm()) for k in keys])
+    dn = np.abs(norms - g["final_norms"]) / np.maximum(g["final_norms"], 1e-12)
+    dw = diag.util.relerr(sd["mlp_fine.rgb_linear.weight"], g["final_rgb_w"])
+    print(f"trajectory {planes}: max loss deviation {dev_rel.max():.3e} (step {int(dev_rel.argmax())}), first step {dev_rel[0]:.1e}, "
+          f"last {dev_rel[-1]:.1e}; final parameter norms within {dn.max():.2e}; fine rgb head weights within {dw:.2e}")
+    assert dev_rel[0] < 1e-4                      # step 0 is a pure forward: the 1e-4 output bound
+    assert dev_rel.max() < TRAJ_BAND[planes], (planes, dev_rel.max())
+    assert dn.max() < 1e-3
+
+
+def test_reference_checkpoint_resumes_on_the_gpu(diag, tmp_path):
+    """SURVEY 8f row 2 on the GPU: a file in the reference's checkpoint format (run_lushnerf.py:687-694: 108
+    'module.'-prefixed keys, torch.optim.Adam state over its two parameter groups) written WITHOUT this package's
+    writer, loaded into a fresh model + trainer: the train_kernel_sharp fixture is reproduced and the next Adam step
+    is the one torch.optim.Adam takes from the same state."""
+    import numpy as np
+    from lush_nerf_amd import checkpoint as CK, synth
+    from lush_nerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    g = diag.util.golden("train_kernel_sharp")
+    lay = diag.util.golden("checkpoint_layout")
+    n, Ns, Ni, naive, sharp, seed, allk = (int(x) for x in g["meta"])
+    w = synth.all_weights(30, seed, sharp=True, rbk_scale=2.0e4)
+
+    def canon(k):
+        k = k[len("module."):]
+        if k.startswith("blur_kernel_net.RBK."):
+            return "mlp_rbk." + k[len("blur_kernel_net.RBK."):]
+        if k.startswith("blur_kernel_net.view_embed_layer.") or k.startswith("dbk_view_embedding."):
+            return "mlp_rbk.view_embedding_layer.view_embed_layer.weight"
+        return k
+    keys = [str(k) for k in lay["keys"]]
+    nsd = {k: torch.from_numpy(w[canon(k)].copy()) for k in keys}
+    assert len(nsd) == 108
+    # optimizer state as torch writes it: parameters in the reference's order (base group, then the noise MLP)
+    probe = _model(seed=1)
+    noise = list(probe.mlp_noise_coarse.parameters())
+    ids = set(map(id, noise))
+    base = [p for p in probe.parameters() if id(p) not in ids]
+    cpu_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in base + noise]
+    opt = torch.optim.Adam([{"params": cpu_params[:len(base)]}, {"params": cpu_params[len(base):], "lr": 5e-4}], lr=5e-4)
+    for i, p in enumerate(cpu_params):
+        p.grad = torch.from_numpy(synth.normal(tuple(p.shape), 300, i)) * 1e-3
+    for _ in range(3):
+        opt.step()
+    for gr in opt.param_groups:
+        gr["lr"] = 5e-4 * 0.1 ** (2 / 250000)
+    path = str(tmp_path / "000002.tar")
+    torch.save({"global_step": 2, "network_state_dict": nsd, "optimizer_state_dict": opt.state_dict()}, path)
+
+    net = _model(seed=9)                              # different weights: everything must come from the file
+    tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni, kernel_start_iter=0, allkernel_start_iter=1 << 30)
+    assert CK.load_checkpoint(path, net, tr) == 2
+    assert tr.global_step == 2 and tr.steps[0] == 3 and tr.steps[1] == 3
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(n, seed, 30).items()}
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(n * 5, Ns, Ni, seed).items()}
+    K = tr.K
+    net.train()
+    out = net(synth.H_DEF, synth.W_DEF, K, chunk=1 << 20, rays=b["rays"], rays_info={"images_idx": b["images_idx"]},
+              retraw=True, force_naive=False, allkernel=True, kernel_pixel=b["fq_mask"], draws=d, **tr.kw)
+    assert diag.util.relerr(out[0], g["rgb_blur"]) < 1e-4 and diag.util.relerr(out[1], g["rgb0_blur"]) < 1e-4
+    assert diag.util.relerr(out[5], g["rgb"]) < 1e-4
+    before = tr.flat.param.clone()
+    m0, v0 = tr.m.clone(), tr.v.clone()
+    tr.step(b, 5, draws=d)
+    grad = tr.flat.grad.clone()
+    # the same step on the CPU with torch.optim.Adam from the file's state and the GPU's gradient
+    name_of = {id(p): k for k, p in net.named_parameters()}
+    gpu_params = [p for p in net.parameters() if id(p) not in set(map(id, net.mlp_noise_coarse.parameters()))] + \
+        list(net.mlp_noise_coarse.parameters())
+    opt2 = torch.optim.Adam([{"params": cpu_params[:len(base)]}, {"params": cpu_params[len(base):], "lr": 5e-4}], lr=5e-4)
+    opt2.load_state_dict(torch.load(path, weights_only=False)["optimizer_state_dict"])
+    with torch.no_grad():
+        for cp, gp in zip(cpu_params, gpu_params):
+            off = (gp.data_ptr() - tr.flat.param.data_ptr()) // 4
+            cp.copy_(before[off:off + gp.numel()].view_as(gp).cpu())
+            cp.grad = grad[off:off + gp.numel()].view_as(gp).cpu().clone()
+    opt2.step()
+    for cp, gp in zip(cpu_params, gpu_params):
+        k = name_of[id(gp)]
+        if "mlp_noise_coarse.alpha_linear" in k:
+            off = (gp.data_ptr() - tr.flat.param.data_ptr()) // 4
+            assert torch.equal(gp.detach().reshape(-1), before[off:off + gp.numel()]), k     # never stepped
+            continue
+        assert diag.util.relerr(gp.detach(), cp.detach()) < 1e-6, k
+
+
+def test_trainer_over_rccl_world_size_one(diag):
+    """SURVEY 8e on the box we have: Trainer(distributed=True) with backend nccl (= RCCL), world size 1 -- the
+    broadcast at construction, the all-reduce of the flat gradient and grad_scale = 1/world run on RCCL -- and gives
+    the step of the non-distributed trainer."""
+    import torch.distributed as dist
+    from lush_nerf_amd import synth
+    from lush_nerf_amd.trainer import Trainer
+    import socket
+    dev = torch.device("cuda:0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(64, 9).items()}
+        d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(64 * 5, 64, 64, 9).items()}
+        res = []
+        for distributed in (True, False):
+            net = _model(seed=3)
+            tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64, distributed=distributed)
+            assert tr.distributed == distributed and tr.world == 1
+            loss = tr.step(b, 0, draws=d)
+            res.append((float(loss), tr.flat.grad.clone(), tr.flat.param.clone()))
+            if distributed:
+                assert tr.replica_checksum() == 0.0
+        assert abs(res[0][0] - res[1][0]) < 1e-6
+        assert diag.util.relerr(res[0][1], res[1][1]) < 2e-4           # fp32 atomics: summation order differs run to run
+        assert diag.util.relerr(res[0][2], res[1][2]) < 1e-5
+    finally:
+        dist.destroy_process_group()
+
+
+_TWO_RANK = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+rank = int(os.environ["RANK"]); torch.cuda.set_device(rank); dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+from lush_nerf_amd import lib, synth
+from lush_nerf_amd.trainer import Trainer
+import bench
+lib.load()
+net = bench.make_model(bench.model_args(64), dev, __import__("lush_nerf_amd.ops", fromlist=["x"]).Precision(2, 2), seed=rank)
+tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64, distributed=True)
+assert tr.replica_checksum() == 0.0                      # rank 1 started from another seed: the broadcast fixed it
+b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(64, 100 + rank).items()}
+tr.step(b, 0)
+assert tr.replica_checksum() == 0.0
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], f"r{rank}.ok"), "w").write("ok")
+'''
+
+
+def test_trainer_over_rccl_two_ranks(diag, tmp_path):
+    """Two ranks over RCCL (skipped on a one-GPU box; the driver's scaling run exercises N = 2, 4, 8)."""
+    import os, subprocess, sys, socket
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two.py"
+    script.write_text(_TWO_RANK)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", port, str(script), root, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

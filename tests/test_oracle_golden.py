@@ -93,3 +93,100 @@ def test_forward_train_golden(name):
     util.check_grads({k: v.grad for k, v in p.items()}, g, gtol)
     if g["grad_rays"].size:
         assert util.relerr(rays.grad, g["grad_rays"]) < gtol
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures
+def test_sample_pdf_on_midpoints_golden():
+    """bins = mid-points of a stored z: the vectors the GPU kernel (which takes z) is also run on."""
+    g = util.golden("sample_pdf_z")
+    z, w, u = (torch.from_numpy(g[k]) for k in ("z", "weights", "u"))
+    mid = .5 * (z[:, 1:] + z[:, :-1])
+    s_rand = O.sample_pdf(mid, w[:, 1:-1], 64, det=False, u=u)
+    s_det = O.sample_pdf(mid, w[:, 1:-1], 64, det=True)
+    assert util.relerr(s_rand, g["s_rand"]) < 1e-6 and util.relerr(s_det, g["s_det"]) < 1e-6
+    assert util.relerr(torch.sort(torch.cat([z, s_rand], -1), -1)[0], g["merged_rand"]) < 1e-6
+
+
+def nondc_batch(n, seed):
+    b = synth.ray_batch(n, seed, util.NUM_IMG)
+    o, d = b["rays"][..., 0], b["rays"][..., 1]
+    vd = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    ones = np.ones((n, 1), np.float32)
+    return torch.from_numpy(np.concatenate([o, d, 2.0 * ones, 6.0 * ones, vd], -1).astype(np.float32))
+
+
+def test_lindisp_white_bkgd_golden():
+    """lindisp=True (sampling linear in disparity, models/lushnerf.py:393-396) and white_bkgd=True (:349-350)."""
+    g = util.golden("rays_lindisp_white")
+    n, Ns, Ni, seed = (int(x) for x in g["meta"])
+    p = util.params(seed, sharp=True)
+    with torch.no_grad():
+        ret, ret_noise = O.render_rays(p, nondc_batch(n, seed), Ns, retraw=True, lindisp=True, perturb=1.,
+                                       N_importance=Ni, white_bkgd=True, raw_noise_std=1.,
+                                       draws=util.tdraws(n, Ns, Ni, seed))
+    for k in ("rgb_map", "depth_map", "acc_map", "density_map", "raw", "rgb0", "depth0", "acc0", "z_std"):
+        assert util.relerr(ret[k], g[k]) < TOL, k
+    assert util.relerr(ret_noise["rgb_map"], g["noise_rgb"]) < TOL
+    assert float(ret["_z_vals"].min()) >= 2.0 - 1e-5 and float(ret["_z_vals"].max()) <= 6.0 + 1e-5
+
+
+def test_eval_forward_golden():
+    """NeRFAll.forward(poses=...) in eval mode: render_path over all pixels, near-plane mask, tone map."""
+    g = util.golden("eval_forward")
+    H, W, seed = (int(x) for x in g["meta"])
+    F = float(g["focal"])
+    K = [[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]]
+    p = util.params(seed, sharp=True)
+    poses = torch.from_numpy(synth.poses(2, seed))
+    rgbs, noises, depths = [], [], []
+    with torch.no_grad():
+        for c2w in poses:
+            ro, rd = O.get_rays(H, W, K, c2w)
+            batch = O.pack_rays(H, W, F, torch.stack([ro, rd], -1))
+            ret, rn = O.render_rays(p, batch, 64, perturb=0., N_importance=64, raw_noise_std=0., training=False,
+                                    render_rmnearplane=80)
+            rgbs.append(ret["rgb_map"].reshape(H, W, 3))
+            depths.append(ret["depth_map"].reshape(H, W))
+            noises.append(rn["rgb_map"].reshape(H, W, 3))
+    assert util.relerr(O.tonemap(torch.stack(rgbs)), g["rgbs"]) < TOL
+    assert util.relerr(O.tonemap(0.1 * torch.sigmoid(torch.stack(noises))), g["noise"]) < TOL
+    assert util.relerr(torch.stack(depths), g["depths"]) < 5e-5
+
+
+def consistency_inputs(g):
+    """Dense Align_matrix[anchor] / Align_mask[anchor] rebuilt from the sparse fixture (values only exist at the samples)."""
+    V, ns, seed, anchor = (int(x) for x in g["meta"])
+    HW = util.H * util.W
+    st = torch.from_numpy(g["samples"])
+    am = torch.zeros(V, HW, 4)
+    am[:, st, 2] = torch.from_numpy(g["ax"])
+    am[:, st, 3] = torch.from_numpy(g["ay"])
+    cm = torch.zeros(V, HW, dtype=torch.bool)
+    cm[:, st] = torch.from_numpy(g["cert_in"]) != 0
+    return V, ns, seed, anchor, st, am, cm
+
+
+def test_consistency_branch_golden():
+    """Render_Aligned_Pixel + compute_mean_with_confidence + masked L1, with gradients."""
+    g = util.golden("consistency")
+    V, ns, seed, anchor, st, am, cm = consistency_inputs(g)
+    p = util.params(seed, sharp=True, requires_grad=True)
+    poses = torch.from_numpy(synth.poses(V, seed))
+    rgb_align, cert = O.render_aligned_pixel(p, util.H, util.W, util.FOCAL, poses, am, cm, st, 64, 64)
+    assert util.relerr(rgb_align, g["rgb_align"]) < TOL
+    assert np.array_equal(cert.numpy(), g["certainty"])
+    assert util.relerr(O.compute_mean_with_confidence(rgb_align, cert, 0.8), g["mean"]) < TOL
+    loss = O.consist_loss(rgb_align, cert, 0.8)
+    assert abs(loss.item() - float(g["loss_rgb"])) < 1e-6
+    loss.backward()
+    none = set(str(x) for x in g["grad_none"])
+    for k, v in p.items():
+        assert (v.grad is None) == (k in none), k
+    util.check_grads({k: v.grad for k, v in p.items()}, g, 2e-4)   # forward is bit-compatible: no kink flips
+
+
+def test_lr_schedule_matches_reference_loop():
+    """run_lushnerf.py:675-685, 788: the rate is updated after optimizer.step() from the un-incremented global_step."""
+    used = O.lr_schedule(5)
+    assert used[0] == used[1] == 5e-4
+    assert used[2] == O.lr_at(1) and used[4] == O.lr_at(3)

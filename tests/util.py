@@ -97,3 +97,52 @@ def nerf_mlp_masked(p, prefix, x, depth, masks):
     rgb = F.linear(hv, p[f"{prefix}.rgb_linear.weight"], p[f"{prefix}.rgb_linear.bias"])
     alpha = F.linear(h, p[f"{prefix}.alpha_linear.weight"], p[f"{prefix}.alpha_linear.bias"])
     return torch.cat([rgb, alpha], -1)
+
+
+def oracle_relu_decisions(p, prefix, x, depth):
+    """The ReLU decisions the fp32 oracle takes on input rows x [P, 90]: [h_0 > 0, ..., h_{D-1} > 0, hv > 0]."""
+    import torch.nn.functional as F
+    pts, views = x[..., :63], x[..., 63:90]
+    h, out = pts, []
+    with torch.no_grad():
+        for i in range(depth):
+            h = F.relu(F.linear(h, p[f"{prefix}.pts_linears.{i}.weight"], p[f"{prefix}.pts_linears.{i}.bias"]))
+            out.append((h > 0).float())
+            if i == 4:
+                h = torch.cat([pts, h], -1)
+        feat = F.linear(h, p[f"{prefix}.feature_linear.weight"], p[f"{prefix}.feature_linear.bias"])
+        hv = F.relu(F.linear(torch.cat([feat, views], -1), p[f"{prefix}.views_linears.0.weight"],
+                             p[f"{prefix}.views_linears.0.bias"]))
+        out.append((hv > 0).float())
+    return out
+
+
+class masked_oracle:
+    """Context manager: inside it the oracle's MLPs (oracle.lush_oracle.nerf_mlp) use GIVEN ReLU decisions instead of
+    their own -- {prefix: [mask per layer]} -- so gradients can be compared free of ReLU-kink flips.  Also records
+    how many of the given decisions differ from the ones the fp32 oracle would have taken (`flips[prefix]`)."""
+
+    def __init__(self, masks_by_prefix):
+        self.masks = masks_by_prefix
+        self.flips = {}
+
+    def __enter__(self):
+        from oracle import lush_oracle as O
+        self.O, self.orig = O, O.nerf_mlp
+
+        def patched(p, prefix, x, in_ch, in_ch_views, depth, skips=(4,), return_alpha=True):
+            if prefix not in self.masks:
+                return self.orig(p, prefix, x, in_ch, in_ch_views, depth, skips, return_alpha)
+            m = self.masks[prefix]
+            own = oracle_relu_decisions({k: v.detach() for k, v in p.items() if k.startswith(prefix)}, prefix, x.detach(), depth)
+            diff = sum(float((a != b).sum()) for a, b in zip(own, m))
+            tot = sum(a.numel() for a in own)
+            d0, t0 = self.flips.get(prefix, (0.0, 0))
+            self.flips[prefix] = (d0 + diff, t0 + tot)
+            out = nerf_mlp_masked(p, prefix, x, depth, m)
+            return out if return_alpha else out[..., :3]
+        O.nerf_mlp = patched
+        return self
+
+    def __exit__(self, *a):
+        self.O.nerf_mlp = self.orig
