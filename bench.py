@@ -50,11 +50,32 @@ def model_args(n_importance):
 
 
 def _host_cpu():
+    """(threads to use, CPU model, note): the cores this process may run on = min(scheduler affinity, cgroup CPU quota).
+    A 1-GPU box owns a share of a large host: its affinity mask can list every core of the host while the cgroup
+    quota grants 16; a torch thread pool sized by the mask is then oversubscribed ~10x (measured: 146 s per step)."""
     cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))          # the cores this process may actually run on
+        cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    affinity = cores
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())        # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        cores = max(1, min(cores, int(quota + 0.5)))
+    if os.environ.get("LUSH_CPU_THREADS"):
+        cores = int(os.environ["LUSH_CPU_THREADS"])
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -63,18 +84,20 @@ def _host_cpu():
                 break
     except OSError:
         pass
-    return cores, model
+    return cores, model, f"affinity {affinity} cores, cgroup quota {quota if quota is not None else 'none'}"
 
 
-def cpu_baseline(n_rand, n_samples, n_importance, steps=5, warmup=2, c1_steps=5):
+def cpu_baseline(n_rand, n_samples, n_importance, steps=5, warmup=2, c1_steps=5, progress=None):
     """The oracle (CPU restatement of the reference path, parity-pinned against the reference's own outputs)
     timed on this box's host cores, as SURVEY 8d / BASELINE.md section 3 plan it: all cores the process may use,
     >= 2 warm-up and >= 5 timed steps, median; (a) the poster 64+64 kernel-on training step at N_rand 512
     (forward + loss + backward) and (b) BASELINE config 1 (N_rand 256, 32+0, naive, entry render_infer)."""
     from lush_nerf_amd import synth
     from oracle import lush_oracle as O
-    cores, model = _host_cpu()
+    cores, model, cpu_note = _host_cpu()
     torch.set_num_threads(cores)
+    if progress:
+        progress(f"  host: {model}, using {cores} threads ({cpu_note})")
     w = synth.all_weights(30, 0)
     p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in w.items()}
 
@@ -84,6 +107,8 @@ def cpu_baseline(n_rand, n_samples, n_importance, steps=5, warmup=2, c1_steps=5)
             t = time.perf_counter()
             fn(s)
             ts.append(time.perf_counter() - t)
+            if progress:
+                progress(f"  cpu step {s}: {ts[-1]:.2f} s")
             for v in p.values():
                 v.grad = None
         ts = sorted(ts[n_warm:])
@@ -106,7 +131,7 @@ def cpu_baseline(n_rand, n_samples, n_importance, steps=5, warmup=2, c1_steps=5)
 
     t_k = timed(kernel_on, warmup, steps)
     t_1 = timed(config1, warmup, c1_steps)
-    return {"value": n_rand / t_k, "unit": "rays/s", "cores": cores, "cpu_model": model, "kind": "port",
+    return {"value": n_rand / t_k, "unit": "rays/s", "cores": cores, "cpu_model": model, "cpu_share": cpu_note, "kind": "port",
             "sample": f"N_rand={n_rand} (x5 marched), {n_samples}+{n_importance}, blur kernel on, forward+loss+backward, "
                       f"median of {steps} steps after {warmup} warm-up, torch CPU fp32, {cores} threads",
             "s_per_step": round(t_k, 3),
@@ -188,6 +213,11 @@ def main():
     from lush_nerf_amd import lib, ops, synth
     from lush_nerf_amd.trainer import Trainer
     lib.load()
+    t_start = time.perf_counter()
+
+    def progress(msg):       # stderr only (stdout carries the ONE JSON line); also keeps gpurun's idle watchdog fed
+        if rank == 0:
+            print(f"[bench {time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     n_batches = 4
     poses = torch.from_numpy(synth.poses(30, 1000 + rank)).to(dev)
@@ -319,16 +349,20 @@ def main():
 
     pf, pb = ops.parse_planes(a.planes)
     evals_step = evals_per_step(a.n_rand, a.n_samples, a.n_importance)
+    progress(f"headline mode {a.planes}: {a.warmup} warm-up + {a.steps} timed steps on {world} rank(s)")
     dt, groups = run_mode(pf, pb, a.steps, a.warmup)
+    progress(f"headline: {dt / a.steps * 1e3:.2f} ms/step")
     others = []
     for m in [x for x in a.also.split(";") if x and x != a.planes]:
         qf, qb = ops.parse_planes(m)
         osteps = max(2, a.steps // 2)
         odt, ogroups = run_mode(qf, qb, osteps, 1)
+        progress(f"mode {m}: {odt / osteps * 1e3:.2f} ms/step")
         others.append((m, qf, qb, odt, ogroups, osteps))
     extra_names = [x for x in (a.extra if a.extra is not None else ("C1,C3,C5,eval" if world == 1 else "")).split(",") if x]
     extras = {}
     for name in extra_names:       # the other BASELINE configs with the SAME kernels and precision mode as the headline
+        progress(f"extra config {name}")
         if name == "eval":
             n_pose = 2
             edt = run_eval(pf, n_pose)
@@ -406,7 +440,9 @@ def main():
         if extras:
             out["extra_configs"] = extras
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, 64, 64)
+            progress(f"CPU baseline (oracle on the host cores, N_rand {a.cpu_n_rand} kernel-on + config 1)")
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, 64, 64, progress=progress)
+            progress("CPU baseline done")
             out["gpu_over_cpu"] = round(rays_per_s / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()

@@ -121,10 +121,19 @@ struct ChCtx {
 // of the stream -> the same offset inside ring slot `dst`.
 template <int PIECES, int SLOT>
 __device__ __forceinline__ void ch_issue(const ChCtx& cx, unsigned off, int slot) {
+#ifdef LUSH_DMA_V2
+    constexpr int ND = PIECES / 4;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)slot * SLOT + (unsigned)cx.w * (ND * 1024u));
+    const char* src = cx.gbase + off + (unsigned)cx.w * (ND * 1024u);
+    if constexpr (ND == 4) { dma16_grp<0, 2>(src, cx.voff[0], dst); dma16_grp<2048, 2>(src, cx.voff[0], dst); }
+    else if constexpr (ND == 2) dma16_grp<0, 2>(src, cx.voff[0], dst);
+    else { static_assert(ND == 1, "pieces per wave and position"); dma16_grp<0, 1>(src, cx.voff[0], dst); }
+#else
     const unsigned dst = cx.ring_lds + (unsigned)slot * SLOT + (unsigned)cx.w * 1024u;
     const char* src = cx.gbase + off;
 #pragma unroll
     for (int d = 0; d < PIECES / 4; ++d) dma16s(src, cx.voff[d], __builtin_amdgcn_readfirstlane(dst + (unsigned)d * 4096u));
+#endif
 }
 
 template <int NS, int NU>
@@ -264,6 +273,17 @@ struct ChPhase {
                     const bool is_dma = (k < 2 * PAIRS) ? (k % 2 == 0) : (ND > NL);
                     const int d = (k < 2 * PAIRS) ? k / 2 : k - PAIRS;
                     if (is_dma) {
+#if defined(LUSH_ABL_NODMA)     // timing ablation only (wrong results): the refill DMAs are not issued
+                        (void)dma_off; (void)dma_dst;
+#elif defined(LUSH_DMA_V2)
+                        // (d is a constant after unrolling; the immediate offset must be one in the source too)
+                        if (d == 0) {
+                            if (ND >= 2) dma16_grp<0, 2>(cx.gbase + dma_off, cx.voff[0], dma_dst);
+                            else dma16_grp<0, 1>(cx.gbase + dma_off, cx.voff[0], dma_dst);
+                        } else if (d == 2) {
+                            dma16_grp<2048, 2>(cx.gbase + dma_off, cx.voff[0], dma_dst);
+                        }
+#else
                         // pieces go in pairs under one M0 save/restore (the odd one of a pair is a no-op filler)
                         if (d % 2 == 0) {
                             if (d + 1 < ND)
@@ -272,6 +292,7 @@ struct ChPhase {
                             else
                                 dma16s(cx.gbase + dma_off, cx.voff[d], __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)d * 4096u));
                         }
+#endif
                     } else {
                         r.a0[d / NS][d % NS] = *reinterpret_cast<const bf16x8*>(rd_next + d * 1024 + cx.lane * 16);
                     }
@@ -320,7 +341,13 @@ struct ChPhase {
 #else
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-        const unsigned dma_dst = cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * 1024u;
+#ifdef LUSH_DMA_V2
+        static_assert(dma_count(I) == 1 || dma_count(I) == 2 || dma_count(I) == 4, "pieces per wave and position");
+        constexpr unsigned WSTRIDE = (unsigned)dma_count(I) * 1024u;      // this wave's pieces are consecutive KiB
+#else
+        constexpr unsigned WSTRIDE = 1024u;
+#endif
+        const unsigned dma_dst = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * WSTRIDE);
         unsigned dma_off;
         if constexpr (TRUNK) {
             unsigned np = cx.trunk_pos + CH_S;
@@ -330,6 +357,9 @@ struct ChPhase {
         } else {
             dma_off = SC::tail_off(T0 + I + CH_S);
         }
+#ifdef LUSH_DMA_V2
+        dma_off += (unsigned)cx.w * WSTRIDE;
+#endif
         cx.cslot = cx.cslot + 1 == CH_S ? 0 : cx.cslot + 1;
         __builtin_amdgcn_sched_barrier(0);
         h2<I>(cx, acc, r, xin, cx.ring + cx.cslot * SC::SLOT, dma_off, dma_dst, st, std::make_integer_sequence<int, NM>{});
@@ -485,8 +515,13 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     cx.trunk_pos = 0;
     cx.w = w;
     cx.lane = lane;
+#ifdef LUSH_DMA_V2
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u;
+#else
 #pragma unroll
     for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
+#endif
 #pragma unroll
     for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
 
@@ -701,8 +736,13 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
     cx.trunk_pos = 0;
     cx.w = w;
     cx.lane = lane;
+#ifdef LUSH_DMA_V2
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u;
+#else
 #pragma unroll
     for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
+#endif
 #pragma unroll
     for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
     char* tile_w = stage + w * 4096;

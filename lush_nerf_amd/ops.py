@@ -272,7 +272,8 @@ class March(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, batch, cfg: MarchCfg, draws: Dict[str, torch.Tensor], n_coarse: int, *params):
-        batch = _f32(batch)
+        ctx.set_materialize_grads(False)     # outputs nothing depends on arrive as None, not as zero tensors: a pass whose
+        batch = _f32(batch)                  # outputs are all unused (the coarse net of the consistency branch) is skipped
         coarse = [_f32(p) for p in params[:n_coarse]]
         fine = [_f32(p) for p in params[n_coarse:]]
         if not fine:

@@ -18,6 +18,10 @@ draw is None it is taken from torch's global generator with the same call shape
 the reference uses, so a shared torch.manual_seed reproduces the reference.
 
 All file:line citations are into /root/reference.
+
+Every function also runs in float64 when its tensor inputs are float64 (the reference's explicit ``.float()`` casts
+are then skipped): tests use that as the exact-arithmetic yardstick against which BOTH the fp32 oracle's and the
+GPU's gradient errors are measured (tests/gpu_diag.py).
 """
 from __future__ import annotations
 
@@ -144,10 +148,10 @@ def sample_pdf(bins: Tensor, weights: Tensor, n_samples: int, det: bool,
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
     if det:
-        u = torch.linspace(0., 1., steps=n_samples).expand(list(cdf.shape[:-1]) + [n_samples])
+        u = torch.linspace(0., 1., steps=n_samples).to(cdf.dtype).expand(list(cdf.shape[:-1]) + [n_samples])
     elif u is None:
         u = torch.rand(list(cdf.shape[:-1]) + [n_samples])
-    u = u.contiguous()
+    u = u.contiguous().to(cdf.dtype)
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp(inds - 1, min=0)
     above = torch.clamp(inds, max=cdf.shape[-1] - 1)
@@ -161,7 +165,7 @@ def sample_pdf(bins: Tensor, weights: Tensor, n_samples: int, det: bool,
 
 # --------------------------------------------------------------------------- a8/a9/a10
 def _z_grid(near: Tensor, far: Tensor, n: int, lindisp: bool) -> Tensor:
-    t = torch.linspace(0., 1., steps=n)
+    t = torch.linspace(0., 1., steps=n).to(near.dtype)
     if not lindisp:
         z = near * (1. - t) + far * t
     else:
@@ -260,10 +264,11 @@ def pack_rays(H: int, W: int, focal: float, rays: Tensor, ndc: bool = True,
     (models/lushnerf.py:706-729, 772-795, 827-850): rays[...,3,2] -> [R,11]
     = [o, d, near, far, viewdir] with viewdir normalised BEFORE the NDC map."""
     rays_o, rays_d = rays[..., 0], rays[..., 1]
-    viewdirs = (rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3).float()
+    f32 = (lambda x: x) if rays.dtype == torch.float64 else (lambda x: x.float())   # .float() of :716, :727-729
+    viewdirs = f32((rays_d / torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1, 3))
     if ndc:
         rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
-    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    rays_o, rays_d = f32(rays_o.reshape(-1, 3)), f32(rays_d.reshape(-1, 3))
     ones = torch.ones_like(rays_d[..., :1])
     return torch.cat([rays_o, rays_d, near * ones, far * ones, viewdirs], -1)
 

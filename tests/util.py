@@ -125,6 +125,7 @@ class masked_oracle:
     def __init__(self, masks_by_prefix):
         self.masks = masks_by_prefix
         self.flips = {}
+        self.cursor = {}          # a prefix may be evaluated in several calls (one per pose, per chunk): rows in call order
 
     def __enter__(self):
         from oracle import lush_oracle as O
@@ -133,7 +134,11 @@ class masked_oracle:
         def patched(p, prefix, x, in_ch, in_ch_views, depth, skips=(4,), return_alpha=True):
             if prefix not in self.masks:
                 return self.orig(p, prefix, x, in_ch, in_ch_views, depth, skips, return_alpha)
-            m = self.masks[prefix]
+            c0 = self.cursor.get(prefix, 0)
+            P = x.shape[0]
+            m = [mm[c0:c0 + P] for mm in self.masks[prefix]]
+            assert m[0].shape[0] == P, f"{prefix}: mask rows exhausted ({c0}+{P} of {self.masks[prefix][0].shape[0]})"
+            self.cursor[prefix] = c0 + P
             own = oracle_relu_decisions({k: v.detach() for k, v in p.items() if k.startswith(prefix)}, prefix, x.detach(), depth)
             diff = sum(float((a != b).sum()) for a, b in zip(own, m))
             tot = sum(a.numel() for a in own)
