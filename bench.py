@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--n-importance", type=int, default=64)
     ap.add_argument("--planes", type=str, default="2,1", help="planes per MFMA operand fwd,bwd: h = one fp16 plane, 1..3 = bf16 planes")
-    ap.add_argument("--also", type=str, default="h,1;2,2", help="second mode timed after the headline (rank 0 reports it under modes); empty to skip")
+    ap.add_argument("--also", type=str, default="2,h;h,h;h,1;2,2", help="second mode timed after the headline (rank 0 reports it under modes); empty to skip")
     ap.add_argument("--micro-batch", type=int, default=0, help="input rays per forward+backward slice (0 = whole batch); "
                     "bounds the activation stash for the larger BASELINE configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -327,8 +327,9 @@ def main():
         """Per kernel group: average launch time (HIP events on the launch stream), algorithmic
         FLOP/s and algorithmic HBM bytes/s per launch (DESIGN.md section 5 gives the per-evaluation figures)."""
         sp = ops.nplanes(ops.stash_code(pf, pb))
-        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH + 16 + 44 / 64, "mlp_bwd_chain": pb * BYTES_DZ_STASH + 288 + 16 + 32,
-                      "mlp_bwd_weights": pb * (BYTES_X_STASH + BYTES_DZ_STASH)}
+        pbn = ops.nplanes(pb)
+        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH + 16 + 44 / 64, "mlp_bwd_chain": pbn * BYTES_DZ_STASH + 288 + 16 + 32,
+                      "mlp_bwd_weights": pbn * (BYTES_X_STASH + BYTES_DZ_STASH)}
         per_prod = lambda c: {1: 1, 2: 3, 3: 6}[ops.nplanes(c)]
         mfma_mult = {"mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
         kern = {}
@@ -410,7 +411,9 @@ def main():
         dtype = {1: "bf16", 2: "bf16 MFMA, operands split in 2 bf16 planes (~2^-17, fp32-equivalent outputs), fp32 accumulate",
                  3: "bf16 MFMA, 3 planes (~fp32), fp32 accumulate",
                  ops.PLANES_F16: "fp16 MFMA forward (one plane, outputs within 3e-5 of fp32), fp32 accumulate"}[pf]
-        if pb != pf:
+        if pb == ops.PLANES_F16:
+            dtype += "; backward fp16 MFMA (one plane, per-launch power-of-two loss scale), fp32 accumulate"
+        elif pb != pf:
             dtype += f"; backward {pb}-plane bf16 MFMA"
         out = {
             "metric": "training rays/sec (fwd+bwd), N_samples=64+64", "value": round(rays_per_s, 1), "unit": "rays/s",
@@ -420,11 +423,13 @@ def main():
                                    f"N_importance={a.n_importance} blur kernel (DSK/RBK) on, fwd+bwd+Adam, "
                                    f"one RCCL all-reduce of the flat gradient (BASELINE config {a.config if world == 1 else '4' if a.config == 'C2' else a.config})",
                        "rays_per_gpu": a.n_rand, "marched_rays_per_gpu": a.n_rand * M, "mlp_evals_per_step": evals_step,
-                       "planes_fwd": ("fp16x1" if pf == ops.PLANES_F16 else f"bf16x{pf}"), "planes_bwd": f"bf16x{pb}", "parallelism": f"dp{world}"},
+                       "planes_fwd": ("fp16x1" if pf == ops.PLANES_F16 else f"bf16x{pf}"), "planes_bwd": ("fp16x1 (loss-scaled)" if pb == ops.PLANES_F16 else f"bf16x{pb}"), "parallelism": f"dp{world}"},
             "step_tflops_algorithmic": round(flop_step * world * a.steps / dt / 1e12, 2),
             "kernels": kern, "roofline": roof,
         }
-        notes = {"2,2": "every MFMA operand in 2 bf16 planes, forward AND backward (fp32-equivalent gradients)",
+        notes = {"2,h": "forward 2 bf16 planes, backward ONE loss-scaled fp16 plane (11-bit operands at the bf16 backward's cost)",
+                 "h,h": "forward ONE fp16 plane (outputs within 3e-5 of fp32), backward ONE loss-scaled fp16 plane",
+                 "2,2": "every MFMA operand in 2 bf16 planes, forward AND backward (fp32-equivalent gradients)",
                  "2,1": "forward 2 bf16 planes (outputs within 5e-7 of fp32), backward plain bf16",
                  "h,1": "forward ONE fp16 plane (outputs within 3e-5 of fp32: inside the 1e-4 bound; end-to-end "
                         "gradients 4e-2..7e-2 from the reference fixtures because the larger forward rounding flips "

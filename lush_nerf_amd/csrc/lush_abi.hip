@@ -41,11 +41,12 @@ StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
     L.total = off;
     return L;
 }
-struct DStashLayout { size_t dz[NET_MAX_LAYERS], dfeat, dzv, total; };
+struct DStashLayout { size_t scale, dz[NET_MAX_LAYERS], dfeat, dzv, total; };
 DStashLayout dstash_layout(const NetInfo& n, int ns, long long P) {
     DStashLayout L{};
     const long long Ppad = pad_pts(P);
     size_t off = 0;
+    L.scale = off; off += 256;      // {loss scale, 1/scale, 2 work words} of the fp16 gradient chain
     for (int l = 0; l < n.NL; ++l) { L.dz[l] = off; off += al256((size_t)ns * Ppad * n.HW * 2); }
     L.dfeat = off; off += al256((size_t)ns * Ppad * n.HW * 2);
     L.dzv = off;   off += al256((size_t)ns * Ppad * n.HV * 2);
@@ -150,8 +151,8 @@ size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long
 }
 size_t lush_mlp_dstash_bytes(int net, int planes, long long P) {
     NetInfo n;
-    if (!net_info(net, n)) return 0;
-    return dstash_layout(n, planes, P).total;
+    if (!net_info(net, n) || !code_ok(planes)) return 0;
+    return dstash_layout(n, nplanes(planes), P).total;
 }
 
 int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
@@ -207,6 +208,9 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
     const bool x_f16 = planes_f == PLANES_F16;     // the stash was written by the fp16 forward
     if (x_f16) planes_f = 1;
+    const bool z_f16 = planes_b == PLANES_F16;     // loss-scaled fp16 gradient chain (one plane)
+    const int code_b = planes_b;
+    if (z_f16) planes_b = 1;
     if (planes_b < 1 || planes_b > planes_f || planes_f > 3) return set_error("lush_mlp_bwd: need 1 <= planes_b <= planes_f <= 3");
     if (!stash || !dstash) return set_error("lush_mlp_bwd: stash and dstash are required");
     const long long P = (long long)R * S;
@@ -218,7 +222,10 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     const long long plane_h = L.Ppad * n.HW, plane_hv = L.Ppad * n.HV, plane_pe = L.Ppad * PE_ROW;
 
     MlpBwdArgs a{};
-    const bool chain = mlp_bwd_chain_enabled(planes_b);
+    const bool chain = mlp_bwd_chain_enabled(code_b);
+    if (z_f16 && !chain) return set_error("lush_mlp_bwd: the fp16 gradient chain needs the chain kernels");
+    float* gscale = z_f16 ? (float*)(db + D.scale) : nullptr;
+    a.scale = gscale;
     a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / (chain ? 128 : mlp_bwd_tile(planes_b)));
     a.wpk = (const uint4*)packed_b;
     (void)prm;
@@ -234,7 +241,13 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.dpts = dpts;
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
-    if (do_chain) rc = chain ? launch_mlp_chain_bwd(net, planes_b, a, st) : launch_mlp_bwd(net, planes_b, a, grid, st);
+    if (do_chain && z_f16) {
+        if (!draw) return set_error("lush_mlp_bwd: draw is required");
+        LUSH_HIP(hipMemsetAsync(gscale, 0, 16, st));
+        rc = launch_grad_scale(draw, P * 4, gscale, st);
+        if (rc) return rc;
+    }
+    if (do_chain) rc = chain ? launch_mlp_chain_bwd(net, code_b, a, st) : launch_mlp_bwd(net, planes_b, a, grid, st);
     if (rc || !do_weights) return rc;
 
     const __bf16* pe = (const __bf16*)(sb + L.pe);
@@ -247,6 +260,8 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         d.X = X; d.x_plane = xplane; d.ldx = ldx; d.xcol0 = xcol0; d.k_in = k_in;
         d.dW = dW; d.ldw = ldw; d.wcol0 = wcol0; d.db = dbias;
         d.x_f16 = x_f16 ? 1 : 0;
+        d.z_f16 = z_f16 ? 1 : 0;
+        d.scale = gscale;
         d.Ppad = (int)L.Ppad;
         const int tiles = ((n_out + 127) / 128) * ((k_in + 127) / 128);
         const int splits = dw_splits(L.Ppad, tiles);

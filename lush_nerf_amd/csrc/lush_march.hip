@@ -628,7 +628,147 @@ __global__ void rbk_warp_bwd_kernel(const float* __restrict__ rays, const int64_
 
 // ------------------------------------------------------------------- RBK MLP
 // One workgroup; num_img rows.  y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]).
-__device__ void rbk_dense(const float* W, const float* b, const float* x, int xs, float* y, int ys, int n, int IN,
+// The activation table (num_img x 512 floats) lives in LDS for the whole kernel with an ODD row stride (RBK_LS), so
+// the per-image column reads of 64 lanes hit 64 different banks; the dense loops read weights from L2 with the image
+// index fastest across lanes (one weight broadcast per wave instruction).  The first version worked on the global
+// table directly: every one of its ~20 dependent stages paid global-memory latency (0.47 ms for a few MFLOP).
+constexpr int RBK_LS = LUSH_RBK_ACT_STRIDE + 1;
+
+__device__ void rbk_dense(const float* W, const float* b, const float* x, float* y, int n, int IN, int OUT, int relu) {
+    for (int t = threadIdx.x; t < n * OUT; t += blockDim.x) {
+        const int i = t % n, o = t / n;
+        float s = b[o];
+        const float* w = W + o * IN;
+        const float* xi = x + i * RBK_LS;
+        for (int k = 0; k < IN; ++k) s += w[k] * xi[k];
+        y[i * RBK_LS + o] = relu ? fmaxf(s, 0.f) : s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
+                                                          float* __restrict__ acts) {
+    extern __shared__ float rbk_lds[];          // [n][RBK_LS]
+    float* A = rbk_lds;
+    const int ST = LUSH_RBK_ACT_STRIDE;
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) A[(t / 64) * RBK_LS + RA_E + (t % 64)] = p.embed[t];
+    __syncthreads();
+    for (int l = 0; l < 4; ++l)
+        rbk_dense(p.w_trunk[l], p.b_trunk[l], A + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1)), A + RA_H0 + 64 * l, n, 64, 64, 1);
+    const float* h3 = A + RA_H0 + 192;
+    rbk_dense(p.w_rb, p.b_rb, h3, A + RA_HR, n, 64, 32, 1);
+    rbk_dense(p.w_vb, p.b_vb, h3, A + RA_HV, n, 64, 32, 1);
+    rbk_dense(p.w_wb, p.b_wb, h3, A + RA_HW, n, 64, 32, 1);
+    rbk_dense(p.w_r, p.b_r, A + RA_HR, A + RA_R, n, 32, 3 * M, 0);
+    rbk_dense(p.w_v, p.b_v, A + RA_HV, A + RA_V, n, 32, 3 * M, 0);
+    rbk_dense(p.w_w, p.b_w, A + RA_HW, A + RA_WS, n, 32, M + 1, 0);
+    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
+        const int i = t / (3 * M), o = t % (3 * M);
+        A[i * RBK_LS + RA_R + o] *= window;
+        A[i * RBK_LS + RA_V + o] *= window;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float sum = 0.f;
+        for (int m = 0; m <= M; ++m) {
+            const float s = 1.f / (1.f + expf(-A[i * RBK_LS + RA_WS + m]));
+            A[i * RBK_LS + RA_WS + m] = s;
+            sum += s;
+        }
+        for (int m = 0; m <= M; ++m) A[i * RBK_LS + RA_WN + m] = A[i * RBK_LS + RA_WS + m] / (sum + 1e-10f);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n * ST; t += blockDim.x) acts[t] = (t % ST) < RA_WN + 8 ? A[(t / ST) * RBK_LS + (t % ST)] : 0.f;
+}
+
+// dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
+__device__ void rbk_dense_bwd_x(const float* W, const float* dz, float* dx, const float* gate, int n, int IN, int OUT,
+                                int accumulate) {
+    for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
+        const int i = t % n, k = t / n;
+        float s = 0.f;
+        const float* zi = dz + i * RBK_LS;
+        for (int o = 0; o < OUT; ++o) s += W[o * IN + k] * zi[o];
+        if (accumulate) s += dx[i * RBK_LS + k];
+        dx[i * RBK_LS + k] = s;
+    }
+    __syncthreads();
+    if (gate) {
+        for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
+            const int i = t % n, k = t / n;
+            if (!(gate[i * RBK_LS + k] > 0.f)) dx[i * RBK_LS + k] = 0.f;
+        }
+        __syncthreads();
+    }
+}
+__device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, float* db, int n, int IN, int OUT) {
+    for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
+        const int o = t / IN, k = t % IN;
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o] * x[i * RBK_LS + k];
+        dW[t] = s;
+    }
+    for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o];
+        db[o] = s;
+    }
+    // (no barrier: dW / db are outputs only; the adjoints a later stage overwrites are guarded by that stage's barrier)
+}
+
+__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
+                                                          const float* __restrict__ acts,
+                                                          const float* __restrict__ d_rvw, lush_rbk_grads g,
+                                                          float* __restrict__ /*scratch: unused since the LDS version*/) {
+    // LDS: activations [n][RBK_LS] then adjoints of the pre-activations in the same per-image layout
+    extern __shared__ float rbk_lds[];
+    float* A = rbk_lds;
+    float* sc = rbk_lds + n * RBK_LS;
+    const int ST = LUSH_RBK_ACT_STRIDE, RS = LUSH_RBK_RVW_STRIDE;
+    for (int t = threadIdx.x; t < n * ST; t += blockDim.x) {
+        A[(t / ST) * RBK_LS + (t % ST)] = acts[t];
+        sc[(t / ST) * RBK_LS + (t % ST)] = 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
+        const int i = t / (3 * M), o = t % (3 * M);
+        sc[i * RBK_LS + RA_R + o] = d_rvw[i * RS + o] * window;
+        sc[i * RBK_LS + RA_V + o] = d_rvw[i * RS + 12 + o] * window;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float sum = 1e-10f, dotp = 0.f;
+        for (int m = 0; m <= M; ++m) { sum += A[i * RBK_LS + RA_WS + m]; dotp += d_rvw[i * RS + 24 + m] * A[i * RBK_LS + RA_WS + m]; }
+        for (int m = 0; m <= M; ++m) {
+            const float ws = A[i * RBK_LS + RA_WS + m];
+            const float dws = d_rvw[i * RS + 24 + m] / sum - dotp / (sum * sum);
+            sc[i * RBK_LS + RA_WS + m] = dws * ws * (1.f - ws);
+        }
+    }
+    __syncthreads();
+    rbk_dense_bwd_w(sc + RA_R, A + RA_HR, g.w_r, g.b_r, n, 32, 3 * M);
+    rbk_dense_bwd_w(sc + RA_V, A + RA_HV, g.w_v, g.b_v, n, 32, 3 * M);
+    rbk_dense_bwd_w(sc + RA_WS, A + RA_HW, g.w_w, g.b_w, n, 32, M + 1);
+    rbk_dense_bwd_x(p.w_r, sc + RA_R, sc + RA_HR, A + RA_HR, n, 32, 3 * M, 0);
+    rbk_dense_bwd_x(p.w_v, sc + RA_V, sc + RA_HV, A + RA_HV, n, 32, 3 * M, 0);
+    rbk_dense_bwd_x(p.w_w, sc + RA_WS, sc + RA_HW, A + RA_HW, n, 32, M + 1, 0);
+    const float* h3 = A + RA_H0 + 192;
+    rbk_dense_bwd_w(sc + RA_HR, h3, g.w_rb, g.b_rb, n, 64, 32);
+    rbk_dense_bwd_w(sc + RA_HV, h3, g.w_vb, g.b_vb, n, 64, 32);
+    rbk_dense_bwd_w(sc + RA_HW, h3, g.w_wb, g.b_wb, n, 64, 32);
+    float* dh3 = sc + RA_H0 + 192;
+    rbk_dense_bwd_x(p.w_rb, sc + RA_HR, dh3, nullptr, n, 64, 32, 0);
+    rbk_dense_bwd_x(p.w_vb, sc + RA_HV, dh3, nullptr, n, 64, 32, 1);
+    rbk_dense_bwd_x(p.w_wb, sc + RA_HW, dh3, h3, n, 64, 32, 1);
+    for (int l = 3; l >= 0; --l) {
+        const float* x = A + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
+        rbk_dense_bwd_w(sc + RA_H0 + 64 * l, x, g.w_trunk[l], g.b_trunk[l], n, 64, 64);
+        float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
+        rbk_dense_bwd_x(p.w_trunk[l], sc + RA_H0 + 64 * l, dx, l == 0 ? nullptr : x, n, 64, 64, 0);
+    }
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) g.embed[t] = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
+}
+
+// Fallback for image counts whose tables do not fit the LDS (num_img > 39): the same stages on the global tables.
+__device__ void rbk_dense_g(const float* W, const float* b, const float* x, int xs, float* y, int ys, int n, int IN,
                           int OUT, int relu) {
     for (int t = threadIdx.x; t < n * OUT; t += blockDim.x) {
         const int i = t / OUT, o = t % OUT;
@@ -639,21 +779,21 @@ __device__ void rbk_dense(const float* W, const float* b, const float* x, int xs
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
+__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel_g(lush_rbk_params p, int n, int M, float window,
                                                           float* __restrict__ acts) {
     const int ST = LUSH_RBK_ACT_STRIDE;
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) acts[(t / 64) * ST + RA_E + (t % 64)] = p.embed[t];
     __syncthreads();
     for (int l = 0; l < 4; ++l)
-        rbk_dense(p.w_trunk[l], p.b_trunk[l], acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1)), ST,
+        rbk_dense_g(p.w_trunk[l], p.b_trunk[l], acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1)), ST,
                   acts + RA_H0 + 64 * l, ST, n, 64, 64, 1);
     const float* h3 = acts + RA_H0 + 192;
-    rbk_dense(p.w_rb, p.b_rb, h3, ST, acts + RA_HR, ST, n, 64, 32, 1);
-    rbk_dense(p.w_vb, p.b_vb, h3, ST, acts + RA_HV, ST, n, 64, 32, 1);
-    rbk_dense(p.w_wb, p.b_wb, h3, ST, acts + RA_HW, ST, n, 64, 32, 1);
-    rbk_dense(p.w_r, p.b_r, acts + RA_HR, ST, acts + RA_R, ST, n, 32, 3 * M, 0);
-    rbk_dense(p.w_v, p.b_v, acts + RA_HV, ST, acts + RA_V, ST, n, 32, 3 * M, 0);
-    rbk_dense(p.w_w, p.b_w, acts + RA_HW, ST, acts + RA_WS, ST, n, 32, M + 1, 0);
+    rbk_dense_g(p.w_rb, p.b_rb, h3, ST, acts + RA_HR, ST, n, 64, 32, 1);
+    rbk_dense_g(p.w_vb, p.b_vb, h3, ST, acts + RA_HV, ST, n, 64, 32, 1);
+    rbk_dense_g(p.w_wb, p.b_wb, h3, ST, acts + RA_HW, ST, n, 64, 32, 1);
+    rbk_dense_g(p.w_r, p.b_r, acts + RA_HR, ST, acts + RA_R, ST, n, 32, 3 * M, 0);
+    rbk_dense_g(p.w_v, p.b_v, acts + RA_HV, ST, acts + RA_V, ST, n, 32, 3 * M, 0);
+    rbk_dense_g(p.w_w, p.b_w, acts + RA_HW, ST, acts + RA_WS, ST, n, 32, M + 1, 0);
     for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
         const int i = t / (3 * M), o = t % (3 * M);
         acts[i * ST + RA_R + o] *= window;
@@ -671,7 +811,7 @@ __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, in
 }
 
 // dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
-__device__ void rbk_dense_bwd_x(const float* W, const float* dz, int zs, float* dx, int xs, const float* gate,
+__device__ void rbk_dense_bwd_x_g(const float* W, const float* dz, int zs, float* dx, int xs, const float* gate,
                                 int gs, int n, int IN, int OUT, int accumulate) {
     for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
         const int i = t / IN, k = t % IN;
@@ -689,7 +829,7 @@ __device__ void rbk_dense_bwd_x(const float* W, const float* dz, int zs, float* 
         __syncthreads();
     }
 }
-__device__ void rbk_dense_bwd_w(const float* dz, int zs, const float* x, int xs, float* dW, float* db, int n, int IN,
+__device__ void rbk_dense_bwd_w_g(const float* dz, int zs, const float* x, int xs, float* dW, float* db, int n, int IN,
                                 int OUT) {
     for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
         const int o = t / IN, k = t % IN;
@@ -705,7 +845,7 @@ __device__ void rbk_dense_bwd_w(const float* dz, int zs, const float* x, int xs,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
+__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel_g(lush_rbk_params p, int n, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
                                                           float* __restrict__ sc) {
@@ -726,25 +866,25 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
         }
     }
     __syncthreads();
-    rbk_dense_bwd_w(sc + RA_R, ST, acts + RA_HR, ST, g.w_r, g.b_r, n, 32, 3 * M);
-    rbk_dense_bwd_w(sc + RA_V, ST, acts + RA_HV, ST, g.w_v, g.b_v, n, 32, 3 * M);
-    rbk_dense_bwd_w(sc + RA_WS, ST, acts + RA_HW, ST, g.w_w, g.b_w, n, 32, M + 1);
-    rbk_dense_bwd_x(p.w_r, sc + RA_R, ST, sc + RA_HR, ST, acts + RA_HR, ST, n, 32, 3 * M, 0);
-    rbk_dense_bwd_x(p.w_v, sc + RA_V, ST, sc + RA_HV, ST, acts + RA_HV, ST, n, 32, 3 * M, 0);
-    rbk_dense_bwd_x(p.w_w, sc + RA_WS, ST, sc + RA_HW, ST, acts + RA_HW, ST, n, 32, M + 1, 0);
+    rbk_dense_bwd_w_g(sc + RA_R, ST, acts + RA_HR, ST, g.w_r, g.b_r, n, 32, 3 * M);
+    rbk_dense_bwd_w_g(sc + RA_V, ST, acts + RA_HV, ST, g.w_v, g.b_v, n, 32, 3 * M);
+    rbk_dense_bwd_w_g(sc + RA_WS, ST, acts + RA_HW, ST, g.w_w, g.b_w, n, 32, M + 1);
+    rbk_dense_bwd_x_g(p.w_r, sc + RA_R, ST, sc + RA_HR, ST, acts + RA_HR, ST, n, 32, 3 * M, 0);
+    rbk_dense_bwd_x_g(p.w_v, sc + RA_V, ST, sc + RA_HV, ST, acts + RA_HV, ST, n, 32, 3 * M, 0);
+    rbk_dense_bwd_x_g(p.w_w, sc + RA_WS, ST, sc + RA_HW, ST, acts + RA_HW, ST, n, 32, M + 1, 0);
     const float* h3 = acts + RA_H0 + 192;
-    rbk_dense_bwd_w(sc + RA_HR, ST, h3, ST, g.w_rb, g.b_rb, n, 64, 32);
-    rbk_dense_bwd_w(sc + RA_HV, ST, h3, ST, g.w_vb, g.b_vb, n, 64, 32);
-    rbk_dense_bwd_w(sc + RA_HW, ST, h3, ST, g.w_wb, g.b_wb, n, 64, 32);
+    rbk_dense_bwd_w_g(sc + RA_HR, ST, h3, ST, g.w_rb, g.b_rb, n, 64, 32);
+    rbk_dense_bwd_w_g(sc + RA_HV, ST, h3, ST, g.w_vb, g.b_vb, n, 64, 32);
+    rbk_dense_bwd_w_g(sc + RA_HW, ST, h3, ST, g.w_wb, g.b_wb, n, 64, 32);
     float* dh3 = sc + RA_H0 + 192;
-    rbk_dense_bwd_x(p.w_rb, sc + RA_HR, ST, dh3, ST, nullptr, 0, n, 64, 32, 0);
-    rbk_dense_bwd_x(p.w_vb, sc + RA_HV, ST, dh3, ST, nullptr, 0, n, 64, 32, 1);
-    rbk_dense_bwd_x(p.w_wb, sc + RA_HW, ST, dh3, ST, h3, ST, n, 64, 32, 1);
+    rbk_dense_bwd_x_g(p.w_rb, sc + RA_HR, ST, dh3, ST, nullptr, 0, n, 64, 32, 0);
+    rbk_dense_bwd_x_g(p.w_vb, sc + RA_HV, ST, dh3, ST, nullptr, 0, n, 64, 32, 1);
+    rbk_dense_bwd_x_g(p.w_wb, sc + RA_HW, ST, dh3, ST, h3, ST, n, 64, 32, 1);
     for (int l = 3; l >= 0; --l) {
         const float* x = acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_w(sc + RA_H0 + 64 * l, ST, x, ST, g.w_trunk[l], g.b_trunk[l], n, 64, 64);
+        rbk_dense_bwd_w_g(sc + RA_H0 + 64 * l, ST, x, ST, g.w_trunk[l], g.b_trunk[l], n, 64, 64);
         float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_x(p.w_trunk[l], sc + RA_H0 + 64 * l, ST, dx, ST, l == 0 ? nullptr : x, ST, n, 64, 64, 0);
+        rbk_dense_bwd_x_g(p.w_trunk[l], sc + RA_H0 + 64 * l, ST, dx, ST, l == 0 ? nullptr : x, ST, n, 64, 64, 0);
     }
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) g.embed[t] = sc[(t / 64) * ST + RA_E + (t % 64)];
 }
@@ -969,14 +1109,28 @@ int lush_consist_loss_fwd_bwd(const float* rgb, const float* cert, int V, int ns
 
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
-    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts);
+    if (num_img < 1) return set_error("lush_rbk_mlp_fwd: no images");
+    const size_t lds = (size_t)num_img * RBK_LS * sizeof(float);
+    if (lds > 160 * 1024) {     // table larger than the LDS: global-memory stages
+        hipLaunchKernelGGL(rbk_mlp_fwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts);
+    } else {
+        LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts);
+    }
     CHECK_LAUNCH();
     return 0;
 }
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
                      const float* d_rvw, const lush_rbk_grads* g, float* scratch, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
-    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+    if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
+    const size_t lds = (size_t)2 * num_img * RBK_LS * sizeof(float);
+    if (lds > 160 * 1024) {
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+    } else {
+        LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+    }
     CHECK_LAUNCH();
     return 0;
 }

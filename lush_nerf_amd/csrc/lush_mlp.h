@@ -153,6 +153,7 @@ struct MlpBwdArgs {
     long long dz_stride;
     long long plane_h, plane_hv;
     float* dpts;                   // [P][8]: d/dx (3), pad, d/dviewdir (3), pad
+    const float* scale;            // fp16 chain only: {loss scale, 1/scale} written by grad_scale_kernel
 };
 
 struct DwArgs {
@@ -161,6 +162,8 @@ struct DwArgs {
     float* dW; int ldw; int wcol0;
     float* db;                     // may be null
     int x_f16;                     // X stash holds fp16 (one plane) instead of bf16 planes
+    int z_f16;                     // dZ holds loss-scaled fp16 (one plane): fp16 MFMA, epilogue multiplies by scale[1]
+    const float* scale;            // {loss scale, 1/scale} of the fp16 gradient chain, or null
     int Ppad;                      // multiple of 32
     int pts_per_split;             // multiple of 32
 };

@@ -657,7 +657,7 @@ struct BwSched {
 };
 
 // acc (* stored ReLU decision) -> NS planes, the next B operand
-template <int NS, bool MASKED, int NB, int KX>
+template <int NS, bool MASKED, int NB, int KX, int DT = DT_BF16>
 __device__ __forceinline__ void bw_convert(const f32x16 (&acc)[NB], bf16x8 (&xin)[KX][NS], const unsigned (&mw)[NB]) {
     static_assert(2 * NB <= KX, "gradient planes do not fit");
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void bw_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 unsigned o[NS];
-                split_pair<NS, DT_BF16>(acc[rb][8 * t + 2 * i], acc[rb][8 * t + 2 * i + 1], o);
+                split_pair<NS, DT>(acc[rb][8 * t + 2 * i], acc[rb][8 * t + 2 * i + 1], o);
 #pragma unroll
                 for (int p = 0; p < NS; ++p) {
                     if (MASKED) {   // x * {0,1} per halfword: zero where the ReLU was off (planes of a dropped value are both dropped)
@@ -704,12 +704,18 @@ __device__ __forceinline__ void bw_stash_all(const bf16x8 (&xin)[KX][NS], char* 
     ch_stash_all<NS, NS, KB, KX, LD>(xin, tile, rows, plane, lane);
 }
 
-template <class N, int NS, bool HAS_ALPHA>
+// DT = DT_F16 (one plane): the gradient chain in fp16 with a per-launch power-of-two loss scale (A.scale[0], chosen from
+// max|d_raw| by grad_scale_kernel so that scaled gradients sit far inside fp16's range): 11-bit operands at the cost
+// of the 8-bit bf16 chain.  dZ rows are stored scaled; d(point) is un-scaled (A.scale[1]) on the way out and the
+// weight-gradient GEMMs un-scale in their epilogue.
+template <class N, int NS, bool HAS_ALPHA, int DT = DT_BF16>
 __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A) {
     using SC = BwSched<N, NS>;
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL, NRB = N::NRB, NRBV = N::NRBV, KKH = N::KKH, KKV = N::KKV;
     constexpr int PARTS = CH_NT / CH_MT;
-    constexpr int DT = DT_BF16;
+    static_assert(DT == DT_BF16 || NS == 1, "fp16 gradients are a single-plane format");
+    float gscale = 1.f, ginv = 1.f;
+    if constexpr (DT == DT_F16) { gscale = A.scale[0]; ginv = A.scale[1]; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                              // [CH_S][SLOT]
     char* stage = smem + CH_S * SC::SLOT;                           // [4 waves][4 KiB]
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
         };
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gpt < A.P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
+        if constexpr (DT == DT_F16) { dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale; }
         wait_vm<0>();          // first tile: the prologue DMAs (later tiles: published by the last mid-step)
         lds_barrier();         // also orders wtab and the previous tile's dpe/dxbuf traffic
 
@@ -800,7 +807,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
             unsigned mv[NRBV];
 #pragma unroll
             for (int rb = 0; rb < NRBV; ++rb) mv[rb] = mw[rb];
-            bw_convert<NS, true, NRBV, KKH>(av, xin, mv);
+            bw_convert<NS, true, NRBV, KKH, DT>(av, xin, mv);
         }
         // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
         bw_zero<NRB>(acc);
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
         ChPhase<SC, NS, DT, 1, SC::G_D, SC::NP_VB, B_REG, true, 0, KKH, 0, 1>::run(cx, apd, xin, nullptr, row, nullptr, nullptr, 0);
         {
             unsigned none[NRB];
-            bw_convert<NS, false, NRB, KKH>(acc, xin, none);
+            bw_convert<NS, false, NRB, KKH, DT>(acc, xin, none);
         }
         // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
         mask_words(mw, NL - 1, NRB);
@@ -820,7 +827,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[rb][q] += w_alpha[32 * rb + 16 * (q >> 3) + 8 * h + (q & 7)] * dr.w;
         }
-        bw_convert<NS, true, NRB, KKH>(acc, xin, mw);
+        bw_convert<NS, true, NRB, KKH, DT>(acc, xin, mw);
         // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
 #pragma unroll 1
         for (int l = NL - 1; l >= 1; --l) {
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
                                                                                       A.dz0 + l * A.dz_stride + wpt * HW, A.plane_h);
             PROF_ADD(3, t_ph);
             PROF_T(t_cv);
-            bw_convert<NS, true, NRB, KKH>(acc, xin, mw);
+            bw_convert<NS, true, NRB, KKH, DT>(acc, xin, mw);
             asm volatile("" ::"v"(xin[0][0]), "v"(xin[KKH - 1][0]));
             PROF_ADD(4, t_cv);
         }
@@ -888,7 +895,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
 #pragma unroll
             for (int p = 0; p < PARTS; ++p) sum += dxbuf[(p * CH_MT + pt) * 6 + c];
             const long long gp = pt0 + pt;
-            if (gp < A.P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum;
+            if (gp < A.P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum * ginv;
         }
         PROF_ADD(1, t_pe);
     }
@@ -973,9 +980,9 @@ int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, hipStream_t s
     return set_error("launch_mlp_chain_fwd: bad net/planes");
 }
 
-template <class N, int NS, bool HAS_ALPHA>
+template <class N, int NS, bool HAS_ALPHA, int DT = DT_BF16>
 static int launch_chain_bwd_k(const MlpBwdArgs& a, hipStream_t s) {
-    auto k = mlp_chain_bwd_kernel<N, NS, HAS_ALPHA>;
+    auto k = mlp_chain_bwd_kernel<N, NS, HAS_ALPHA, DT>;
     const size_t lds = (size_t)CH_S * BwSched<N, NS>::SLOT + (size_t)CH_NW * 4096 + (size_t)CH_MT * BW_DPE_LD * 4 +
                        (size_t)(CH_NT / CH_MT) * CH_MT * 6 * 4 + (size_t)(3 * N::HV + N::HW) * 4;
     static int n_cu = 0;
@@ -999,10 +1006,15 @@ bool mlp_bwd_chain_enabled(int planes) {
         const char* e = getenv("LUSH_BWD_OLD");
         old = (e && e[0] == '1') ? 1 : 0;
     }
-    return !old && (planes == 1 || planes == 2);
+    return !old && (planes == 1 || planes == 2 || planes == PLANES_F16);
 }
 
 int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s) {
+    if (planes == PLANES_F16) {
+        if (a.scale == nullptr) return set_error("launch_mlp_chain_bwd: the fp16 chain needs its loss scale");
+        if (net == 0) return launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
+        return launch_chain_bwd_k<NetNoise, 1, false, DT_F16>(a, s);
+    }
     if (net == 0) {
         if (planes == 1) return launch_chain_bwd_k<NetNerf, 1, true>(a, s);
         if (planes == 2) return launch_chain_bwd_k<NetNerf, 2, true>(a, s);

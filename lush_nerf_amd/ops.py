@@ -23,15 +23,16 @@ def nplanes(code: int) -> int:
 
 
 def stash_code(pf: int, pb: int) -> int:
-    """What the forward keeps for the backward: an fp16 forward stashes its single fp16 plane (the dW
-    GEMM converts it to bf16 in registers), otherwise the first min(pf, pb) bf16 planes."""
-    return PLANES_F16 if pf == PLANES_F16 else min(pf, pb)
+    """What the forward keeps for the backward: an fp16 forward stashes its single fp16 plane, otherwise the
+    first min(pf, planes of the backward) bf16 planes (the dW GEMM converts between bf16 and fp16 in registers when the
+    stash and the gradient chain differ)."""
+    return PLANES_F16 if pf == PLANES_F16 else min(pf, nplanes(pb))
 
 
 def parse_planes(text: str):
-    """'2,1' / 'h,1' -> (fwd code, bwd planes)."""
-    f, b = text.split(",")
-    return (PLANES_F16 if f.strip() in ("h", "17") else int(f)), int(b)
+    """'2,1' / 'h,1' / '2,h' / 'h,h' -> (fwd code, bwd code); h = one fp16 plane (backward: loss-scaled)."""
+    f, b = (PLANES_F16 if x.strip() in ("h", "17") else int(x) for x in text.split(","))
+    return f, b
 _NL = {NET_NERF: 8, NET_NOISE: 4}
 N_MLP_TENSORS = {NET_NERF: 24, NET_NOISE: 16}
 
@@ -53,7 +54,8 @@ class Precision:
     """16-bit planes per MFMA operand: forward / backward.  fwd = 2 (two bf16 planes, outputs within
     5e-7 of fp32) or PLANES_F16 (one fp16 plane, outputs within ~3e-5; the tiny noise MLP then stays on
     two bf16 planes) satisfy the 1e-4 bound; (1, 1) plain bf16 does not; (3, 3) is ~fp32.  The backward
-    is always bf16 (1 plane = plain bf16, 2 = fp32-equivalent): fp16's range is unsafe for gradients."""
+    is bf16 (1 plane = plain bf16, 2 = fp32-equivalent) or PLANES_F16: ONE fp16 plane under a per-launch
+    power-of-two loss scale chosen on the device from max|d_raw| -- 11-bit operands at the cost of the 8-bit ones."""
     fwd: int = 2
     bwd: int = 2
 
