@@ -3,6 +3,8 @@
 #include "lush_host.h"
 #include "../../include/lush_march.h"
 
+#include <cstdlib>
+
 using namespace lush;
 
 namespace {
@@ -271,6 +273,46 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         const int real_splits = (int)((L.Ppad + pps - 1) / pps);
         return launch_dw(planes_b, d, real_splits, st);
     };
+    const __bf16* feat = (const __bf16*)(sb + L.feat);
+    const __bf16* hv = (const __bf16*)(sb + L.hv);
+    static const bool per_layer = getenv("LUSH_DW_OLD") != nullptr;        // A/B switch: one launch per layer
+    if (planes_b == 1 && !per_layer) {
+        // one grouped launch: every layer of the pass, the two pairs that share a dZ merged (DwJob::X2)
+        DwGroup G{};
+        auto job = [&](const __bf16* Z, int ldz, int n_out, const __bf16* X, int ldx, int xcol0, int k_in, float* dW,
+                       int ldw, int wcol0, float* dbias) -> DwJob& {
+            DwJob& j = G.j[G.n++];
+            j.Z = Z; j.ldz = ldz; j.n_out = n_out; j.X = X; j.ldx = ldx; j.xcol0 = xcol0; j.k_in = k_in;
+            j.X2 = nullptr; j.ldx2 = 0; j.x2col0 = 0; j.k2_in = 0;
+            j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.wcol2 = 0; j.db = dbias;
+            return j;
+        };
+        for (int l = 0; l < n.NL; ++l) {
+            if (l == 0) {
+                job(dzp[0], n.HW, n.HW, pe, PE_ROW, 0, XV, g->w[0], XV, 0, g->b[0]);
+            } else if (l == n.SKIP) {
+                DwJob& j = job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], XV + n.HW, XV, g->b[l]);
+                j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = 0; j.k2_in = XV; j.wcol2 = 0;
+            } else {
+                job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], n.HW, 0, g->b[l]);
+            }
+        }
+        job(a.dfeat, n.HW, n.HW, H(n.NL - 1), n.HW, 0, n.HW, g->w_feat, n.HW, 0, g->b_feat);
+        {
+            DwJob& j = job(a.dzv, n.HV, n.HV, feat, n.HW, 0, n.HW, g->w_views, n.HW + DV, 0, g->b_views);
+            j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = PE_X; j.k2_in = DV; j.wcol2 = n.HW;
+        }
+        const int splits = dw_splits(L.Ppad, 0);
+        long long pps = (L.Ppad + splits - 1) / splits;
+        pps = (pps + 31) / 32 * 32;
+        G.Ppad = (int)L.Ppad;
+        G.pts_per_split = (int)pps;
+        G.scale = gscale;
+        rc = launch_dw_group(G, (int)((L.Ppad + pps - 1) / pps), x_f16, z_f16, st);
+        if (rc) return rc;
+        return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
+                              net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
+    }
     for (int l = 0; l < n.NL && !rc; ++l) {
         const __bf16* Z = dzp[l];
         if (l == 0) {
@@ -285,12 +327,10 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     if (rc) return rc;
     rc = dw(a.dfeat, plane_h, n.HW, n.HW, H(n.NL - 1), plane_h, n.HW, 0, n.HW, g->w_feat, n.HW, 0, g->b_feat);
     if (rc) return rc;
-    const __bf16* feat = (const __bf16*)(sb + L.feat);
     rc = dw(a.dzv, plane_hv, n.HV, n.HV, feat, plane_h, n.HW, 0, n.HW, g->w_views, n.HW + DV, 0, g->b_views);
     if (rc) return rc;
     rc = dw(a.dzv, plane_hv, n.HV, n.HV, pe, plane_pe, PE_ROW, PE_X, DV, g->w_views, n.HW + DV, n.HW, nullptr);
     if (rc) return rc;
-    const __bf16* hv = (const __bf16*)(sb + L.hv);
     return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
                           net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
 }

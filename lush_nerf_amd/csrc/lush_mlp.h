@@ -168,4 +168,23 @@ struct DwArgs {
     int pts_per_split;             // multiple of 32
 };
 
+// One weight-gradient GEMM of a grouped launch (dw_group_kernel): dW[o][wcol0 + i] += sum_p Z[p][o] X[p][xcol0 + i],
+// optionally a second input block that shares the same Z (the skip layer's gamma(x) columns, the views layer's
+// gamma(d) columns): dW[o][wcol2 + i] += sum_p Z[p][o] X2[p][x2col0 + i], and the bias gradient db[o] += sum_p Z[p][o].
+struct DwJob {
+    const __bf16* Z; int ldz; int n_out;
+    const __bf16* X; int ldx; int xcol0; int k_in;
+    const __bf16* X2; int ldx2; int x2col0; int k2_in;     // X2 == null: none; k2_in <= 64
+    float* dW; int ldw; int wcol0; int wcol2;
+    float* db;                                              // may be null
+};
+enum { DW_MAX_JOBS = 14 };
+struct DwGroup {
+    DwJob j[DW_MAX_JOBS];
+    int n;
+    int Ppad;                      // multiple of 32
+    int pts_per_split;             // multiple of 32
+    const float* scale;            // {loss scale, 1/scale} when Z is loss-scaled fp16, else null
+};
+
 }  // namespace lush

@@ -996,6 +996,184 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_dma_kernel(const DwArgs A
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight-gradient launch: ONE launch per network pass instead of one per layer.
+// Measured on the per-layer kernel above (fine / coarse trunk layers, 2.68 / 1.34 GB each): 500 / 295 us, i.e. an
+// asymptotic 6.5 TB/s plus ~90 us of fixed cost per launch -- every workgroup drains its 256 KB of fp32 atomics at
+// the same moment (64 MB per launch at the chip's ~1.3 TB/s atomic rate) while nothing streams, then the next launch
+// refills its ring from cold.  Here a persistent workgroup owns one slice of the points and walks the layer list;
+// workgroup b starts at job b mod n, so at any moment the workgroups of the chip are spread over all layers: the
+// atomics of one overlap the streaming of the others and no two neighbours add into the same matrix at once.
+// A job may carry a second input block X2 that shares its dZ (skip layer: gamma(x) | h; views layer: feature |
+// gamma(d)): the per-layer launches read that dZ twice (7 GB per step).
+//   stage = [Z 32 x 512 B | X 32 x 512 B | X2 32 x 128 B]; X2 is swizzled chunk ^= ((row >> 1) & 1) << 2 (rows of 128 B:
+//   the four rows of a transposing read then sit on four different 16-bank groups).
+constexpr int GRP_X2_ROWB = 128, GRP_X2 = DMA_KT * GRP_X2_ROWB, GRP_STAGE = 2 * DMA_OPER + GRP_X2;
+
+__device__ __forceinline__ bf16x8 tr_frag_x2(const char* tile, int k0, int col0, int lane) {
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row = k0 + 8 * (G >> 1) + q;                 // ((row + 4) >> 1) & 1 == (row >> 1) & 1: same swizzle for both reads
+    const int col = col0 + 16 * (G & 1) + 4 * p;
+    const char* a0 = tile + row * GRP_X2_ROWB + ((((col >> 3) ^ (((row >> 1) & 1) << 2))) << 4) + (col & 7) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * GRP_X2_ROWB));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.v;
+}
+
+template <bool XF16, bool ZF16>
+__global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) {
+    extern __shared__ __attribute__((aligned(16))) char tiles[];   // [4 stages][GRP_STAGE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = w >> 2, wi = w & 3;
+    const long long p_begin = (long long)blockIdx.x * G.pts_per_split;
+    long long p_end = p_begin + G.pts_per_split;
+    if (p_end > G.Ppad) p_end = G.Ppad;
+    const int n_tiles = (int)((p_end - p_begin) / DMA_KT);
+    if (n_tiles <= 0) return;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = ZF16 ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
+    auto mm = [](bf16x8 a, bf16x8 b, f32x16 c) { return ZF16 ? mfma_f16(a, b, c) : mfma_bf16(a, b, c); };
+    auto xcv = [](bf16x8 v) {
+        if constexpr (XF16 && !ZF16) return f16_frag_to_bf16(v);
+        else if constexpr (!XF16 && ZF16) return bf16_frag_to_f16(v);
+        else return v;
+    };
+    const float unscale = ZF16 ? G.scale[1] : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)tiles;
+    const int r = lane & 31, h = lane >> 5;
+
+    for (int jj = 0; jj < G.n; ++jj) {
+        int jsel = (int)((blockIdx.x + (unsigned)jj) % (unsigned)G.n);
+        jsel = __builtin_amdgcn_readfirstlane(jsel);
+        const DwJob& A = G.j[jsel];
+        const bool has_x2 = A.X2 != nullptr;
+        const bool do_bias = A.db != nullptr;
+        const bool wave_live = (wo * 128 < A.n_out) && (wi * 64 < A.k_in);
+        const bool row_live = wo * 128 + wi * 32 < A.n_out;           // this wave's 32 rows of the bias / X2 blocks
+        const bool side = row_live && (do_bias || has_x2);
+        const int nv2 = has_x2 ? (A.k2_in > 32 ? 2 : 1) : 0;
+        // columns beyond a job's widths are never written by its DMAs: start every job from a zeroed ring
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone has left the previous job's tiles
+        for (int i = tid; i < DMA_STAGES * GRP_STAGE / 16; i += DW_THREADS2)
+            reinterpret_cast<uint4*>(tiles)[i] = make_uint4(0, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // side accumulators: with X2, accs[v] = its 32-column blocks and the bias rides in the last (unused, zero-padded)
+        // column of the last block, whose B fragment is forced to ones; without X2, accs[0] = bias against an all-ones B
+        f32x16 acc[4][2], accs[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { acc[a][0][q] = 0.f; acc[a][1][q] = 0.f; }
+            accs[0][q] = 0.f; accs[1][q] = 0.f;
+        }
+        const int bias_blk = nv2 ? nv2 - 1 : 0;                    // block that carries the bias column (its column 31)
+        const bool x2_wave = has_x2 && w < 4;          // waves 0..3 move the four 1-KiB pieces of the X2 tile
+        auto issue = [&](int t) {
+            const long long p0 = p_begin + (long long)t * DMA_KT;
+            const unsigned stage = lds0 + (unsigned)((t % DMA_STAGES) * GRP_STAGE);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = w * 4 + i;
+                const int op = j >> 4, rp = j & 15;
+                const int row = 2 * rp + (lane >> 5);
+                const int gch = (lane & 31) ^ ((row & 3) << 2);            // source chunk that belongs at this position
+                const int ncols = op ? A.k_in : A.n_out;
+                const __bf16* src = op ? A.X + (p0 + row) * A.ldx + A.xcol0 + gch * 8 : A.Z + (p0 + row) * A.ldz + gch * 8;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)(op * DMA_OPER + 2 * rp * DMA_ROWB));
+                if (gch * 8 < ncols) dma16(src, dst);
+            }
+            if (x2_wave) {
+                const int row = 8 * w + (lane >> 3);
+                const int gch = (lane & 7) ^ (((row >> 1) & 1) << 2);
+                const __bf16* src = A.X2 + (p0 + row) * A.ldx2 + A.x2col0 + gch * 8;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)(2 * DMA_OPER + 8 * w * GRP_X2_ROWB));
+                if (gch * 8 < A.k2_in) dma16(src, dst);
+            }
+        };
+        for (int t = 0; t < DMA_STAGES - 1 && t < n_tiles; ++t) issue(t);
+        for (int t = 0; t < n_tiles; ++t) {
+            const int younger = n_tiles - 1 - t < DMA_STAGES - 2 ? n_tiles - 1 - t : DMA_STAGES - 2;   // stages issued after tile t
+            if (x2_wave) {
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + DMA_STAGES - 1 < n_tiles) issue(t + DMA_STAGES - 1);
+            const char* zt = tiles + (t % DMA_STAGES) * GRP_STAGE;
+            const char* xt = zt + DMA_OPER;
+            const char* x2t = zt + 2 * DMA_OPER;
+#pragma unroll
+            for (int ks = 0; ks < DMA_KT / 16; ++ks) {
+                if (wave_live) {
+                    bf16x8 a[4], b[2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = tr_frag_sw(zt, ks * 16, wo * 128 + u * 32, lane);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) b[u] = xcv(tr_frag_sw(xt, ks * 16, wi * 64 + u * 32, lane));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) acc[u][v] = mm(a[u], b[v], acc[u][v]);
+                }
+                if (side) {      // (re-reads this wave's row block of Z: 2 LDS reads against keeping a copy of a[wi] alive)
+                    const bf16x8 sel = tr_frag_sw(zt, ks * 16, wo * 128 + wi * 32, lane);
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        if (v < nv2 || (v == 0 && do_bias)) {
+                            bf16x8 bb = ones;
+                            if (v < nv2) {
+                                bb = xcv(tr_frag_x2(x2t, ks * 16, v * 32, lane));
+                                if (do_bias && v == bias_blk && r == 31) bb = ones;
+                            }
+                            accs[v] = mm(sel, bb, accs[v]);
+                        }
+                    }
+                }
+            }
+        }
+        if (side) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                if (v < nv2 || (v == 0 && do_bias)) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int o = wo * 128 + wi * 32 + acc_row(q, h);
+                        const int i = v * 32 + r;
+                        if (o < A.n_out) {
+                            if (v < nv2 && i < A.k2_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol2 + i, accs[v][q] * unscale);
+                            if (do_bias && v == bias_blk && r == 31) atomicAdd(A.db + o, accs[v][q] * unscale);
+                        }
+                    }
+                }
+            }
+        }
+        if (wave_live) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int o = wo * 128 + u * 32 + acc_row(q, h);
+                        const int i = wi * 64 + v * 32 + r;
+                        if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[u][v][q] * unscale);
+                    }
+        }
+    }
+}
+
 // Loss scale of the fp16 gradient chain: scale = 2^k with max|d_raw| * scale in [8, 16) (gradients grow by at most
 // ~2^5 through the heads of the sharpest test networks; fp16 tops out at 2^16), 1 when d_raw is all zero or not
 // finite.  One launch: per-block maxima by atomicMax on the bit pattern (non-negative floats order as integers),
@@ -1260,6 +1438,28 @@ int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
     if (ns == 2) return launch_dw_t<2>(a, splits, s);
     if (ns == 3) return launch_dw_t<3>(a, splits, s);
     return set_error("launch_dw: bad planes");
+}
+
+template <bool XF16, bool ZF16>
+static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
+    const size_t lds = (size_t)DMA_STAGES * GRP_STAGE;
+    auto k = dw_group_kernel<XF16, ZF16>;
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, g);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+// one launch for all the weight-gradient GEMMs of a network pass (one 16-bit plane per operand)
+int launch_dw_group(const DwGroup& g, int splits, bool x_f16, bool z_f16, hipStream_t s) {
+    for (int i = 0; i < g.n; ++i) {
+        const DwJob& j = g.j[i];
+        if (j.n_out > DW_T || j.k_in > DW_T || j.n_out < 8 || j.k_in < 8) return set_error("launch_dw_group: layer width out of range");
+        // the bias rides in column 31 of the last 32-column block of X2, which must therefore be a padding column
+        if (j.X2 && (j.k2_in < 8 || j.k2_in > 63 || j.k2_in % 32 == 0)) return set_error("launch_dw_group: second input block must leave its last column free");
+    }
+    if (z_f16 && g.scale == nullptr) return set_error("launch_dw_group: the fp16 gradient GEMM needs its loss scale");
+    if (z_f16) return x_f16 ? launch_dw_group_t<true, true>(g, splits, s) : launch_dw_group_t<false, true>(g, splits, s);
+    return x_f16 ? launch_dw_group_t<true, false>(g, splits, s) : launch_dw_group_t<false, false>(g, splits, s);
 }
 
 int launch_grad_scale(const float* draw, long long n, float* scale /* {scale, 1/scale, 2 work words} */, hipStream_t s) {

@@ -640,6 +640,11 @@ def t_faults():
 MASKED_FLOOR = {(3, 3): 1e-4, (2, 2): 2e-4, (2, 1): 4e-2, (ops.PLANES_F16, 1): 4e-2, (1, 1): 8e-2,
                 (2, ops.PLANES_F16): 1e-2, (ops.PLANES_F16, ops.PLANES_F16): 5e-3}
 MASKED_FACTOR = 32.0
+# one fp16 plane in the forward carries 2^-11 per operand: the same cancelling sums sit at up to ~2^13 x fp32's error
+# (measured 370 x on the alpha bias, 2.6e-2 absolute, identical with the bf16 and the fp16 backward: it is the
+# forward's rounding that the condition number amplifies).  Capped in absolute terms.
+MASKED_FACTOR_F16_FWD = 1024.0
+MASKED_CAP = 5e-2
 MASKED_GATE = MASKED_FLOOR      # (name kept for the sections that only need the floor)
 
 
@@ -656,18 +661,19 @@ def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
             flips = mo.flips
     (p64, x64), (p32, x32) = res[torch.float64], res[torch.float32]
     floor = MASKED_FLOOR.get(tuple(E2E_PLANES), 3e-2)
+    factor = MASKED_FACTOR_F16_FWD if E2E_PLANES[0] == ops.PLANES_F16 else MASKED_FACTOR
     worst_excess, worst = 0.0, ("", 0.0, 0.0)
     items = [(k, v, p64[k].grad, p32[k].grad) for k, v in gpu_grads.items() if v is not None]
     items += [(k, v, x64[k].grad, x32[k].grad) for k, v in gpu_extra.items() if v is not None and x64[k].grad is not None]
     for k, got, t64, t32 in items:
         e_gpu, e_f32 = util.relerr(got, t64), util.relerr(t32, t64)
-        excess = e_gpu / max(floor, MASKED_FACTOR * e_f32)
+        excess = e_gpu / max(floor, min(MASKED_CAP, factor * e_f32))
         if not excess <= worst_excess:          # NaN propagates
             worst_excess, worst = excess, (k, e_gpu, e_f32)
     ok = bool(worst_excess <= 1.0)
     RESULTS.append((f"{tag} MASKED grads vs float64 [{worst[0]}] (e_gpu / allowed)", worst_excess, 1.0, ok))
     print(f"{'ok  ' if ok else 'FAIL'} {tag} masked oracle: worst tensor {worst[0]}: e_gpu {worst[1]:.2e}, fp32 oracle {worst[2]:.2e}, "
-          f"allowed max({floor:.0e}, {MASKED_FACTOR:.0f} x fp32) -> {worst_excess:.2f} of the allowance", flush=True)
+          f"allowed max({floor:.0e}, min({MASKED_CAP:.0e}, {factor:.0f} x fp32)) -> {worst_excess:.2f} of the allowance", flush=True)
     # informational: the largest plain error among well-conditioned tensors (fp32 oracle within 1e-5 of float64)
     wc = [(util.relerr(got, t64), k) for k, got, t64, t32 in items if util.relerr(t32, t64) < 1e-5]
     if wc:
