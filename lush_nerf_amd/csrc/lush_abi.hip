@@ -115,6 +115,42 @@ void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
     perm = 0; base = 0;
 }
 
+// Third forward copy (NetT::fwd3_base): half-row stream of mlp_chain_fwd_half_kernel.  Its own table: the kernel
+// argument block holds 64 jobs.
+template <class N>
+void build_pack_table_half(const lush_mlp_params* p, PackTable& T, int& blocks) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP, HR = N::HW / 2, NRBH = N::NRB / 2;
+    T.n = 0;
+    blocks = 0;
+    int dst = N::fwd3_base;
+    auto add = [&](const float* src, int sr, int rows, int cols, int nrb, int kk) {
+        PackJob& j = T.j[T.n++];
+        j.src = src; j.sr = sr; j.sk = 1; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk; j.perm = 1;
+        j.dst_entry = dst; j.first_block = blocks;
+        blocks += nrb * kk;
+        dst += nrb * kk;
+    };
+    const int XV = PE_X_VALID, DV = PE_D_VALID;
+    for (int half = 0; half < 2; ++half) add(p->w[0] + (long long)half * HR * XV, XV, HR, XV, NRBH, N::KKX);
+    for (int l = 1; l < NL; ++l) {
+        const int ld = l == SK ? XV + HW : HW;
+        for (int half = 0; half < 2; ++half) {
+            const float* w = p->w[l] + (long long)half * HR * ld;
+            if (l == SK) {
+                add(w, ld, HR, XV, NRBH, N::KKX);
+                add(w + XV, ld, HR, HW, NRBH, N::KKH);
+            } else {
+                add(w, ld, HR, HW, NRBH, N::KKH);
+            }
+        }
+    }
+    for (int half = 0; half < 2; ++half) add(p->w_feat + (long long)half * HR * HW, HW, HR, HW, NRBH, N::KKH);
+    add(p->w_alpha, HW, 1, HW, 1, N::KKH);
+    add(p->w_views, HW + DV, HV, HW, N::NRBV, N::KKH);
+    add(p->w_views + HW, HW + DV, HV, DV, N::NRBV, N::KKD);
+    add(p->w_rgb, HV, 3, HV, 1, N::KKV);
+}
+
 int dw_splits(long long Ppad, int /*tiles*/) {
     int s = 256;                                   // one 256x256-tile workgroup per CU
     const long long max_s = Ppad / 32;
@@ -141,6 +177,11 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
     if (!code_ok(planes)) return set_error("lush_mlp_pack: planes must be 1..3 or 17 (fp16)");
     int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
     if (rc) return rc;
+    if (net == 0 && nplanes(planes) == 1) {      // the half-row stream is read by the one-plane forward only
+        build_pack_table_half<NetNerf>(prm, T, blocks);
+        rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
 }
 

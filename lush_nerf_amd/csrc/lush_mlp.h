@@ -63,7 +63,11 @@ struct NetT {
     static constexpr int fwd2_base = bwd_END;
     // ... and of the backward (transposed) segments for mlp_chain_bwd_kernel: bwd2_X = bwd2_base + (bwd_X - bwd_VAT)
     static constexpr int bwd2_base = fwd2_base + fwd_END;
-    static constexpr int total_entries = bwd2_base + (bwd_END - bwd_VAT);
+    // third copy of the forward segments for the 256-register chain kernel (mlp_chain_fwd_half_kernel): rows permuted by
+    // chain_row() as in the second copy, but every full-width segment is cut into its two 128-row halves and the stream
+    // runs [half 0 of the layer | half 1 of the layer] (skip layer: [a0 | b0 | a1 | b1]); narrow segments unchanged.
+    static constexpr int fwd3_base = bwd2_base + (bwd_END - bwd_VAT);
+    static constexpr int total_entries = fwd3_base + fwd_END;
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
 

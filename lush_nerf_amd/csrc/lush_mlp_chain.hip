@@ -27,6 +27,7 @@
 #include "lush_mlp_dev.h"
 #include "lush_host.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 
@@ -44,6 +45,7 @@ enum { B_REG = 0, B_PEX = 1, B_PED = 2 };     // where a phase takes its B opera
 template <class N, int NS, bool HAS_ALPHA>
 struct ChSched {
     static constexpr int ENTRY = NS * 1024;
+    static constexpr int S = CH_S;
     // trunk positions hold GT k-blocks: with one plane a single k-block is only 8 MFMAs per wave, too
     // little to cover the LDS latency of the next half's fragments
     static constexpr int GT = NS == 1 ? 2 : 1;
@@ -255,7 +257,7 @@ struct ChPhase {
 
     // ---- half 2: MFMAs on a1; fillers: D0 L0 D1 L1 ... (refill DMAs / next position's a0 reads), then a
     // stash job's 4 LDS writes and 4 read-backs (and its stores, when jobs come every position) ----
-    static constexpr int dma_count(int i) { return (TRUNK ? SC::TRUNK_PIECES : SC::tail_pieces(T0 + i + CH_S)) / 4; }
+    static constexpr int dma_count(int i) { return (TRUNK ? SC::TRUNK_PIECES : SC::tail_pieces(T0 + i + SC::S)) / 4; }
     template <int I, int M>
     static __device__ __forceinline__ void h2_step(ChCtx& cx, f32x16 (&acc)[NRBS], Regs& r, const bf16x8 (&xin)[KX][NS],
                                                    const char* rd_next, unsigned dma_off, unsigned dma_dst, const Stash& st) {
@@ -350,17 +352,17 @@ struct ChPhase {
         const unsigned dma_dst = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * WSTRIDE);
         unsigned dma_off;
         if constexpr (TRUNK) {
-            unsigned np = cx.trunk_pos + CH_S;
+            unsigned np = cx.trunk_pos + SC::S;
             if constexpr (SC::WRAP > 0) np = np >= (unsigned)SC::WRAP ? np - (unsigned)SC::WRAP : np;   // next tile restarts the stream
             dma_off = np * (unsigned)SC::SLOT;
             cx.trunk_pos += 1;
         } else {
-            dma_off = SC::tail_off(T0 + I + CH_S);
+            dma_off = SC::tail_off(T0 + I + SC::S);
         }
 #ifdef LUSH_DMA_V2
         dma_off += (unsigned)cx.w * WSTRIDE;
 #endif
-        cx.cslot = cx.cslot + 1 == CH_S ? 0 : cx.cslot + 1;
+        cx.cslot = cx.cslot + 1 == SC::S ? 0 : cx.cslot + 1;
         __builtin_amdgcn_sched_barrier(0);
         h2<I>(cx, acc, r, xin, cx.ring + cx.cslot * SC::SLOT, dma_off, dma_dst, st, std::make_integer_sequence<int, NM>{});
     }
@@ -629,6 +631,193 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
 }
 
 // ----------------------------------------------------------------------------
+// one-plane forward in 256 registers: TWO workgroups per CU
+// ----------------------------------------------------------------------------
+// The kernel above runs one wave per SIMD: whatever is not an MFMA (plane conversion, positional encoding, DMA issue,
+// barrier waits) leaves the matrix pipe idle -- with one plane that is more than half of the time (per 128-point
+// tile: 38 k cycles of MFMA in 81 k).  A second wave on the SIMD hides it only if the two are out of phase, and two
+// waves of ONE workgroup never are (they meet at every position barrier; measured in round 1).  So the one-plane
+// forward runs as two INDEPENDENT workgroups per CU -- own ring, own barriers, free to drift apart -- which needs the
+// kernel in 256 registers and 80 KiB of LDS:
+//   * every full-width layer is computed in two passes over K, rows 0..127 then rows 128..255 (NetT::fwd3 stream):
+//     64 accumulators instead of 128; the first half is converted to its 8 k-blocks of the next B operand while the
+//     second half runs, so the peak is 64 (acc) + 64 (B operand) + 32 (half of the next one);
+//   * ring slots of 8 KiB (2 k-blocks x 4 row blocks), every segment cut into whole slots (uniform stream, WRAP per
+//     tile, as in the backward kernel); biases come from L2 (their LDS copy does not fit 80 KiB).
+template <class N>
+struct HfSched {
+    static constexpr int NS = 1, GT = 2, NRBH = N::NRB / 2;
+#ifndef LUSH_HF_S
+#define LUSH_HF_S 4
+#endif
+    static constexpr int S = LUSH_HF_S;                                    // ring slots
+    static constexpr int TRUNK_PIECES = NRBH * NS * GT;                    // 8 pieces = 8 KiB per position
+    static constexpr int SLOT = TRUNK_PIECES * 1024;
+    static constexpr int trunk_wait = (S - 2) * TRUNK_PIECES / 4;
+    static constexpr int G_A = TRUNK_PIECES, G_R = TRUNK_PIECES;            // 1-row-block segments: 8 k-blocks per position
+    static constexpr int G_V = TRUNK_PIECES / N::NRBV;                     // views layer: NRBV row blocks
+    static constexpr int NP_X = N::KKX / GT, NP_H = N::KKH / GT, NP_A = N::KKH / G_A, NP_VA = N::KKH / G_V,
+                         NP_VB = N::KKD / G_V, NP_R = N::KKV / G_R;
+    static constexpr int WRAP = 2 * NP_X + (N::NL - 1) * 2 * NP_H + (N::SKIP > 0 ? 2 * NP_X : 0) + 2 * NP_H + NP_A + NP_VA + NP_VB + NP_R;
+    static_assert(N::NRB % 2 == 0 && N::NRBV == NRBH, "half-row kernel: the views layer is one half wide");
+    static_assert(N::KKX % GT == 0 && N::KKH % GT == 0 && N::KKH % G_A == 0 && N::KKD % G_V == 0 && N::KKV % G_R == 0 &&
+                  TRUNK_PIECES % 4 == 0, "segments must tile into whole positions");
+    static_assert(N::fwd_END == WRAP * TRUNK_PIECES, "the half-row stream must cover the forward segments exactly");
+    static constexpr int tail_pieces(int) { return TRUNK_PIECES; }     // (unused: every phase is TRUNK)
+    static constexpr unsigned tail_off(int) { return 0; }
+    static constexpr int tail_wait(int) { return trunk_wait; }
+};
+
+// acc[rb][q] = bias[32 rb + 16 (q>>3) + 8 h + (q&7)] straight from global memory (L2-resident fp32 block)
+template <int NB>
+__device__ __forceinline__ void ch_bias_g(f32x16 (&acc)[NB], const float* __restrict__ b, int h) {
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(b + rb * 32 + 8 * h);
+        const f32x4 v0 = p[0], v1 = p[1], v2 = p[4], v3 = p[5];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[rb][e] = v0[e];
+            acc[rb][4 + e] = v1[e];
+            acc[rb][8 + e] = v2[e];
+            acc[rb][12 + e] = v3[e];
+        }
+    }
+}
+
+template <class N, int DT, int SPK>
+__global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpFwdArgs A) {
+    using SC = HfSched<N>;
+    constexpr int NS = 1;
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, NRB = N::NRB, NRBH = N::NRB / 2, NRBV = N::NRBV, KKH = N::KKH;
+    constexpr int PE_PLANE = CH_MT * PE_ROW * 2;
+    static_assert(SPK <= 1, "one plane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                  // [CH_S][SLOT]
+    char* peimg = smem + SC::S * SC::SLOT;               // [128 points][256 B], XOR-swizzled
+    char* stage = peimg + PE_PLANE;                     // [4 waves][4 KiB] stash transposition tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const char* wbase = reinterpret_cast<const char*>(A.wpk);
+    const float* f32b = reinterpret_cast<const float*>(wbase + (long long)N::total_entries * NS * 1024);
+    ChCtx cx;
+    cx.ring = ring;
+    cx.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    cx.gbase = wbase + (long long)N::fwd3_base * NS * 1024;
+    cx.cslot = 0;
+    cx.trunk_pos = 0;
+    cx.w = w;
+    cx.lane = lane;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
+#pragma unroll
+    for (int j = 0; j < SC::S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
+
+    constexpr bool stash_on = SPK > 0;
+    const int row = w * 32 + n;
+    char* tile_w = stage + w * 4096;
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * CH_MT;
+        const long long gpt = pt0 + row;
+        const long long wpt = pt0 + w * 32;
+#ifndef LUSH_ABL_NOPE    // timing ablation only (wrong results)
+        pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
+#endif
+        wait_vm<0>();      // first tile: the prologue DMAs; later tiles: already published by the last mid-step
+        lds_barrier();
+        if (stash_on) {
+            for (int i = tid; i < CH_MT * 12; i += CH_NT) {
+                const int c = i % 12, pt = i / 12;
+                const uint4 v = *reinterpret_cast<const uint4*>(peimg + swz(pt, c, PE_ROW * 2));
+                *reinterpret_cast<uint4*>(A.pe + (pt0 + pt) * PE_ROW + c * 8) = v;
+            }
+        }
+        cx.trunk_pos = 0;
+        {
+            unsigned long long gb = (unsigned long long)cx.gbase;
+            asm volatile("" : "+s"(gb));
+            cx.gbase = (const char*)gb;
+        }
+        const long long blk = pt0 / 32 + w;
+        auto mrow = [&](int ml, int half) -> unsigned short* {
+            return stash_on ? reinterpret_cast<unsigned short*>(A.mask + ((blk * N::n_mask_layers + ml) * NRB + half * NRBH) * 16) + lane : nullptr;
+        };
+        f32x16 acc[NRBH];
+        bf16x8 xin[KKH][NS], xnx[KKH][NS];
+        typedef bf16x8 (&half_ref)[KKH / 2][NS];
+        // ---- layer 0: gamma(x) from the PE image, two row halves ----
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            ch_bias_g<NRBH>(acc, f32b + N::f32_b_trunk + half * (HW / 2), h);
+            ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_X, B_PEX, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
+            ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(0, half), lane);
+        }
+#pragma unroll
+        for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
+        // ---- layers 1 .. NL-1 ----
+#pragma unroll 1
+        for (int l = 1; l < NL; ++l) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                ch_bias_g<NRBH>(acc, f32b + N::f32_b_trunk + l * HW + half * (HW / 2), h);
+                if (l == N::SKIP)
+                    ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_X, B_PEX, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
+                if (half == 0)      // the stash of h_{l-1} (this phase's B operand) rides in the first pass
+                    ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w,
+                                                                                             A.h0 + (l - 1) * A.h_stride + wpt * HW, A.plane_h);
+                else
+                    ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
+                ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(l, half), lane);
+            }
+#pragma unroll
+            for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
+        }
+        // ---- feature head (no activation), two halves; then the alpha head, both on h_{NL-1} ----
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            ch_bias_g<NRBH>(acc, f32b + N::f32_b_feat + half * (HW / 2), h);
+            if (half == 0)
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w,
+                                                                                         A.h0 + (NL - 1) * A.h_stride + wpt * HW, A.plane_h);
+            else
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
+            ch_convert<NS, DT, false, NRBH, KKH / 2, false>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), nullptr, lane);
+        }
+        float alpha;
+        {
+            f32x16 aa[1];
+            ch_bias_g<1>(aa, f32b + N::f32_b_alpha, h);
+            ChPhase<SC, NS, DT, 1, SC::G_A, SC::NP_A, B_REG, true, 0, KKH, 0, 1>::run(cx, aa, xin, peimg, row, nullptr, nullptr, 0);
+            alpha = aa[0][0];
+        }
+#pragma unroll
+        for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
+        // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
+        ch_bias_g<NRBV>(acc, f32b + N::f32_b_views, h);
+        ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VA, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w, A.feat + wpt * HW, A.plane_h);
+        ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VB, B_PED, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
+        ch_convert<NS, DT, true, NRBV, KKH, stash_on>(acc, xin, mrow(NL, 0), lane);
+        // ---- rgb head ----
+        f32x16 ar[1];
+        ch_bias_g<1>(ar, f32b + N::f32_b_rgb, h);
+        if constexpr (SPK > 0) ch_stash_all<NS, SPK, N::KKV, KKH, HV>(xin, tile_w, A.hv + wpt * HV, A.plane_hv, lane);
+        ChPhase<SC, NS, DT, 1, SC::G_R, SC::NP_R, B_REG, true, 0, KKH, 0, 1>::run(cx, ar, xin, peimg, row, nullptr, nullptr, 0);
+        if (h == 0 && gpt < A.P) {
+            float4 o;
+            o.x = ar[0][0];
+            o.y = ar[0][1];
+            o.z = ar[0][2];
+            o.w = alpha;
+            *reinterpret_cast<float4*>(A.raw + gpt * 4) = o;
+        }
+    }
+    wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
+}
+
+// ----------------------------------------------------------------------------
 // backward chain: dZ_{l-1} = relu'(h_{l-1}) * (W_l^T dZ_l), down to d/d(point), d/d(viewdir)
 // ----------------------------------------------------------------------------
 // Same organisation as the forward (autograd of utils/run_lushnerf_helpers.py:394-423, 483-512): a wave
@@ -643,6 +832,7 @@ constexpr int BW_DPE_LD = 100;      // fp32 words per point in the d(gamma) scra
 template <class N, int NS>
 struct BwSched {
     static constexpr int GT = NS == 1 ? 2 : 1;                           // k-blocks per full-width position (see ChSched)
+    static constexpr int S = CH_S;
     static constexpr int TRUNK_PIECES = N::NRB * NS * GT;
     static constexpr int SLOT = TRUNK_PIECES * 1024;
     static constexpr int trunk_wait = (CH_S - 2) * TRUNK_PIECES / 4;
@@ -935,9 +1125,47 @@ static int launch_chain_sp(const MlpFwdArgs& a, hipStream_t s) {
     return 0;
 }
 
+template <class N, int DT, int SPK>
+static int launch_chain_half_sp(const MlpFwdArgs& a, hipStream_t s) {
+    auto k = mlp_chain_fwd_half_kernel<N, DT, SPK>;
+    const size_t lds = (size_t)HfSched<N>::S * HfSched<N>::SLOT + (size_t)CH_MT * PE_ROW * 2 + (size_t)CH_NW * 4096;
+    static int n_cu = 0;
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        LUSH_HIP(hipGetDevice(&dev));
+        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+        if (getenv("LUSH_DEBUG_OCC")) {
+            int nb = 0;
+            LUSH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), CH_NT, lds));
+            fprintf(stderr, "[lush] mlp_chain_fwd_half_kernel: %d workgroups per CU (LDS %zu B each)\n", nb, lds);
+        }
+    }
+    const int grid = a.n_tiles < 2 * n_cu ? a.n_tiles : 2 * n_cu;     // two workgroups per CU, tiles strided
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+static bool fwd_half_enabled() {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("LUSH_FWD_512");       // A/B switch: 1 = the one-wave-per-SIMD kernel for one plane too
+        off = (e && e[0] == '1') ? 1 : 0;
+    }
+    return !off;
+}
+
 template <class N, int NS, bool HAS_ALPHA, int DT>
 static int launch_chain_k(const MlpFwdArgs& a, hipStream_t s) {
     const int sp = a.write_stash ? a.stash_planes : 0;
+    if constexpr (NS == 1 && HAS_ALPHA && N::HW == 256) {
+        if (fwd_half_enabled()) {
+            if (sp == 0) return launch_chain_half_sp<N, DT, 0>(a, s);
+            if (sp == 1) return launch_chain_half_sp<N, DT, 1>(a, s);
+        }
+    }
     if (sp == 0) return launch_chain_sp<N, NS, HAS_ALPHA, DT, 0>(a, s);
     if (sp == 1) return launch_chain_sp<N, NS, HAS_ALPHA, DT, 1>(a, s);
     if constexpr (NS == 2) {
