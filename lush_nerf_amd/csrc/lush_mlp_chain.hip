@@ -186,6 +186,18 @@ struct ChPhase {
     static constexpr int job_st1(int i) { return (SPACING >= 2 && i >= 1) ? job_wr(i - 1) : -1; }   // stores in half 1
     static constexpr int job_st2(int i) { return SPACING >= 2 ? -1 : job_wr(i); }                   // stores in half 2
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    // Stash stores this wave has issued AFTER the DMA of position I+1 (issued in half 2 of position I+1-S, ahead of that
+    // half's stash fillers) by the time position I reaches its mid-step wait.  vmcnt counts stores and DMAs together in
+    // issue order, so the wait must name them: leaving them out turns "position I+1 has landed" into "positions I+1 ..
+    // I+S-1 have landed" whenever stores were issued in between, i.e. a wait for DMAs issued only a position ago.  Only
+    // stores of THIS phase are counted (an undercount is safe, an overcount would release the wait early).
+    static constexpr int st1_at(int i) { return (i >= 0 && i < NPOS && job_st1(i) >= 0) ? 4 : 0; }
+    static constexpr int st2_at(int i) { return (i >= 0 && i < NPOS && job_st2(i) >= 0) ? 4 : 0; }
+    static constexpr int younger_stores(int I) {
+        int n = st2_at(I + 1 - SC::S) + st1_at(I);
+        for (int i = I + 2 - SC::S; i < I; ++i) n += st1_at(i) + st2_at(i);
+        return n;
+    }
 
     struct Regs {
         bf16x8 a0[H][NS], a1[H][NS];
@@ -214,14 +226,28 @@ struct ChPhase {
     }
 
     static __device__ __forceinline__ void st_write(const Stash& st, const bf16x8 (&xin)[KX][NS], int job, int kq, int lane) {
+#ifdef LUSH_ABL_FRAGSTORE   // timing experiment (wrong layout): k-block fragments stored straight from registers, 1 KiB contiguous each
+        {
+            const int j = job / SP, p = job % SP;
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, xin[4 * j + kq][p]),
+                                        reinterpret_cast<u32x4*>(reinterpret_cast<char*>(st.rows + p * st.plane) + (4 * j + kq) * 1024 + lane * 16));
+            return;
+        }
+#endif
         const int n = lane & 31, hh = lane >> 5, j = job / SP, p = job % SP;
         *reinterpret_cast<u32x4*>(st.tile + n * 128 + (((2 * kq + hh) ^ (n & 7)) << 4)) = __builtin_bit_cast(u32x4, xin[4 * j + kq][p]);
     }
     static __device__ __forceinline__ void st_read(const Stash& st, Regs& r, int i, int lane) {
+#ifdef LUSH_ABL_FRAGSTORE
+        return;
+#endif
         const int row = 8 * i + (lane >> 3);
         r.sb[i] = *reinterpret_cast<const u32x4*>(st.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
     }
     static __device__ __forceinline__ void st_store(const Stash& st, const Regs& r, int job, int i, int lane) {
+#ifdef LUSH_ABL_FRAGSTORE
+        return;
+#endif
         const int j = job / SP, p = job % SP;
         u32x4* dst = reinterpret_cast<u32x4*>(st.rows + p * st.plane + (long long)(8 * i + (lane >> 3)) * LD + j * 64 + (lane & 7) * 8);
 #if defined(LUSH_ABL_NOSTORE)     // timing ablation only
@@ -336,7 +362,11 @@ struct ChPhase {
         // mid-step: my pieces of position +1 have landed; after the barrier everyone's have, and nobody
         // reads this position's slot any more (a1 is in registers: lgkmcnt(0) inside lds_barrier)
 #ifndef LUSH_ABL_NOVMWAIT   // timing ablations only (wrong results)
+#ifdef LUSH_ABL_OLDWAIT
         wait_vm<TRUNK ? SC::trunk_wait : SC::tail_wait(T0 + I)>();
+#else
+        wait_vm<(TRUNK ? SC::trunk_wait : SC::tail_wait(T0 + I)) + younger_stores(I)>();
+#endif
 #endif
 #ifndef LUSH_ABL_NOBAR
         lds_barrier();
@@ -715,7 +745,11 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
 #pragma unroll
     for (int j = 0; j < SC::S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
 
+#ifdef LUSH_ABL_NOMASK      // timing ablation only: no ReLU-decision words
+    constexpr bool stash_on = false;
+#else
     constexpr bool stash_on = SPK > 0;
+#endif
     const int row = w * 32 + n;
     char* tile_w = stage + w * 4096;
 
@@ -728,13 +762,15 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
 #endif
         wait_vm<0>();      // first tile: the prologue DMAs; later tiles: already published by the last mid-step
         lds_barrier();
-        if (stash_on) {
+#ifndef LUSH_ABL_NOPECOPY
+        if (SPK > 0) {
             for (int i = tid; i < CH_MT * 12; i += CH_NT) {
                 const int c = i % 12, pt = i / 12;
                 const uint4 v = *reinterpret_cast<const uint4*>(peimg + swz(pt, c, PE_ROW * 2));
                 *reinterpret_cast<uint4*>(A.pe + (pt0 + pt) * PE_ROW + c * 8) = v;
             }
         }
+#endif
         cx.trunk_pos = 0;
         {
             unsigned long long gb = (unsigned long long)cx.gbase;

@@ -14,11 +14,12 @@ try:
 except Exception as e:
     print("no bench json", e)
 _pf, _pb = str(bench.get("config", {}).get("planes_fwd", "?")), str(bench.get("config", {}).get("planes_bwd", "?"))
-planes = ("h" if _pf.startswith("fp16") else _pf.replace("bf16x", "")) + "," + _pb.replace("bf16x", "")
+planes = ("h" if _pf.startswith("fp16") else _pf.replace("bf16x", "")) + "," + ("h" if _pb.startswith("fp16") else _pb.replace("bf16x", ""))
 steps = bench.get("steps", 4) + bench.get("warmup", 2)
 
 GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
+         "mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_fwd", "dw_group_kernel": "mlp_bwd_weights",
          "dw_gemm_kernel": "mlp_bwd_weights", "dw_gemm_dma_kernel": "mlp_bwd_weights", "head_dw_kernel": "mlp_bwd_weights"}
 
 
@@ -42,7 +43,7 @@ if stats:
                         f'{float(r["AverageNs"]) / 1e6:.4f}', r["Percentage"]])
     lines.append(f"## rocprofv3 --kernel-trace --stats of `bench.py` (planes {planes}, {steps} steps incl. warm-up)\n")
     lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
-    for r in rows[:10]:
+    for r in rows[:14]:
         lines.append(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e6:.3f} | '
                      f'{float(r["TotalDurationNs"]) / 1e6:.1f} | {r["Percentage"]} |')
     if bench.get("kernels"):
@@ -65,7 +66,8 @@ if per:
     lines.append(f"\n## HBM traffic from PMC counters (separate passes; FETCH_SIZE x2 gfx950 correction)\n")
     lines.append("| kernel group | fetch GB/step | write GB/step | total GB/step | algorithmic GB/step |\n|---|---|---|---|---|")
     evals = bench.get("config", {}).get("mlp_evals_per_step", 3932160)
-    pf, pb = ((1 if planes.split(",")[0] == "h" else int(planes.split(",")[0])), int(planes.split(",")[1])) if "?" not in planes else (2, 1)
+    _n = lambda x: 1 if x == "h" else int(x)
+    pf, pb = (_n(planes.split(",")[0]), _n(planes.split(",")[1])) if "?" not in planes else (2, 1)
     alg = {"mlp_fwd": evals * (min(pf, pb) * 5120 + 16), "mlp_bwd_chain": evals * (pb * 4864 + 336),
            "mlp_bwd_weights": evals * pb * 9984}
     lps = {k: v["launches_per_step"] for k, v in bench.get("kernels", {}).items()}
