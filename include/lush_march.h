@@ -146,9 +146,11 @@ typedef struct {
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts,
                      lush_stream_t stream);
 /* d_rvw [num_img][32] = gradients w.r.t. r(12), v(12), normalised w(5).
- * All of `g` is overwritten; scratch >= num_img*512 floats. */
+ * `g` is overwritten, or added to when accumulate != 0 (gradient buffers that already hold a slice's
+ * contribution); scratch >= num_img*512 floats. */
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
-                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, lush_stream_t stream);
+                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, int accumulate,
+                     lush_stream_t stream);
 /* rbk_warp (models/lushnerf.py:75-98) + SE3Field.warp (utils/rigid_warping.py:20-140):
  * rays [N][3][2], idx [N] int64 -> new_rays [N*(M+1)][3][2] (slot 0 = input ray),
  * ccw [N][M+1]. */
@@ -177,10 +179,19 @@ int lush_tonemap_bwd(const float* x, const float* nraw, int n, int gamma, const 
 int lush_noise_act_fwd(const float* x, int n, float* y, lush_stream_t stream);
 int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_stream_t stream); /* accumulate */
 /* Training loss of run_lushnerf.py:652-661: sum over the two colours of
- * 0.5*MSE + 0.5*L1 against target [n][3].  loss[0] accumulate (zero it first);
- * ga / gb = d loss / d a, d loss / d b (overwritten). */
-int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float* loss,
+ * 0.5*MSE + 0.5*L1 against target [n][3], times `scale` (the share of a micro-batch in the step's
+ * mean; 1 for the plain loss).  loss[0] accumulate (zero it first); ga / gb = d loss / d a, d loss / d b
+ * (overwritten). */
+int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float scale, float* loss,
                       float* ga, float* gb, lush_stream_t stream);
+
+/* ----------------------------------------------------------------- random draws
+ * The four draws of one march in the reference's shapes -- torch.rand [R][Ns] (models/lushnerf.py:515),
+ * torch.randn_like [R][Ns-1] (:322), torch.rand [R][Ni] (utils/run_lushnerf_helpers.py:578), torch.randn_like
+ * [R][Ns+Ni-1] (:322) -- from one Philox4x32-10 launch; any pointer may be NULL (that draw is not made).
+ * (seed, offset) select the stream: the caller advances offset per call.  Uniforms lie in [0, 1). */
+int lush_draws(unsigned long long seed, unsigned long long offset, float* t_rand, long long n_t, float* noise_c,
+               long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t stream);
 
 /* ------------------------------------------------------------------- the MLPs
  * Embedder + NeRF.forward / NeRF_Noise.forward behind NeRFAll.mlpforward /

@@ -700,17 +700,17 @@ __device__ void rbk_dense_bwd_x(const float* W, const float* dz, float* dx, cons
         __syncthreads();
     }
 }
-__device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, float* db, int n, int IN, int OUT) {
+__device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, float* db, int n, int IN, int OUT, int accumulate) {
     for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
         const int o = t / IN, k = t % IN;
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o] * x[i * RBK_LS + k];
-        dW[t] = s;
+        dW[t] = accumulate ? dW[t] + s : s;
     }
     for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o];
-        db[o] = s;
+        db[o] = accumulate ? db[o] + s : s;
     }
     // (no barrier: dW / db are outputs only; the adjoints a later stage overwrites are guarded by that stage's barrier)
 }
@@ -718,7 +718,7 @@ __device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, floa
 __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
-                                                          float* __restrict__ /*scratch: unused since the LDS version*/) {
+                                                          float* __restrict__ /*scratch: unused since the LDS version*/, int accumulate) {
     // LDS: activations [n][RBK_LS] then adjoints of the pre-activations in the same per-image layout
     extern __shared__ float rbk_lds[];
     float* A = rbk_lds;
@@ -744,27 +744,30 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
         }
     }
     __syncthreads();
-    rbk_dense_bwd_w(sc + RA_R, A + RA_HR, g.w_r, g.b_r, n, 32, 3 * M);
-    rbk_dense_bwd_w(sc + RA_V, A + RA_HV, g.w_v, g.b_v, n, 32, 3 * M);
-    rbk_dense_bwd_w(sc + RA_WS, A + RA_HW, g.w_w, g.b_w, n, 32, M + 1);
+    rbk_dense_bwd_w(sc + RA_R, A + RA_HR, g.w_r, g.b_r, n, 32, 3 * M, accumulate);
+    rbk_dense_bwd_w(sc + RA_V, A + RA_HV, g.w_v, g.b_v, n, 32, 3 * M, accumulate);
+    rbk_dense_bwd_w(sc + RA_WS, A + RA_HW, g.w_w, g.b_w, n, 32, M + 1, accumulate);
     rbk_dense_bwd_x(p.w_r, sc + RA_R, sc + RA_HR, A + RA_HR, n, 32, 3 * M, 0);
     rbk_dense_bwd_x(p.w_v, sc + RA_V, sc + RA_HV, A + RA_HV, n, 32, 3 * M, 0);
     rbk_dense_bwd_x(p.w_w, sc + RA_WS, sc + RA_HW, A + RA_HW, n, 32, M + 1, 0);
     const float* h3 = A + RA_H0 + 192;
-    rbk_dense_bwd_w(sc + RA_HR, h3, g.w_rb, g.b_rb, n, 64, 32);
-    rbk_dense_bwd_w(sc + RA_HV, h3, g.w_vb, g.b_vb, n, 64, 32);
-    rbk_dense_bwd_w(sc + RA_HW, h3, g.w_wb, g.b_wb, n, 64, 32);
+    rbk_dense_bwd_w(sc + RA_HR, h3, g.w_rb, g.b_rb, n, 64, 32, accumulate);
+    rbk_dense_bwd_w(sc + RA_HV, h3, g.w_vb, g.b_vb, n, 64, 32, accumulate);
+    rbk_dense_bwd_w(sc + RA_HW, h3, g.w_wb, g.b_wb, n, 64, 32, accumulate);
     float* dh3 = sc + RA_H0 + 192;
     rbk_dense_bwd_x(p.w_rb, sc + RA_HR, dh3, nullptr, n, 64, 32, 0);
     rbk_dense_bwd_x(p.w_vb, sc + RA_HV, dh3, nullptr, n, 64, 32, 1);
     rbk_dense_bwd_x(p.w_wb, sc + RA_HW, dh3, h3, n, 64, 32, 1);
     for (int l = 3; l >= 0; --l) {
         const float* x = A + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_w(sc + RA_H0 + 64 * l, x, g.w_trunk[l], g.b_trunk[l], n, 64, 64);
+        rbk_dense_bwd_w(sc + RA_H0 + 64 * l, x, g.w_trunk[l], g.b_trunk[l], n, 64, 64, accumulate);
         float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
         rbk_dense_bwd_x(p.w_trunk[l], sc + RA_H0 + 64 * l, dx, l == 0 ? nullptr : x, n, 64, 64, 0);
     }
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) g.embed[t] = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {
+        const float v = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
+        g.embed[t] = accumulate ? g.embed[t] + v : v;
+    }
 }
 
 // Fallback for image counts whose tables do not fit the LDS (num_img > 39): the same stages on the global tables.
@@ -830,17 +833,17 @@ __device__ void rbk_dense_bwd_x_g(const float* W, const float* dz, int zs, float
     }
 }
 __device__ void rbk_dense_bwd_w_g(const float* dz, int zs, const float* x, int xs, float* dW, float* db, int n, int IN,
-                                int OUT) {
+                                int OUT, int accumulate) {
     for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
         const int o = t / IN, k = t % IN;
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += dz[i * zs + o] * x[i * xs + k];
-        dW[t] = s;
+        dW[t] = accumulate ? dW[t] + s : s;
     }
     for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += dz[i * zs + o];
-        db[o] = s;
+        db[o] = accumulate ? db[o] + s : s;
     }
     __syncthreads();
 }
@@ -848,7 +851,7 @@ __device__ void rbk_dense_bwd_w_g(const float* dz, int zs, const float* x, int x
 __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel_g(lush_rbk_params p, int n, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
-                                                          float* __restrict__ sc) {
+                                                          float* __restrict__ sc, int accumulate) {
     // scratch uses the same per-image layout as acts, holding adjoints of the pre-activations
     const int ST = LUSH_RBK_ACT_STRIDE, RS = LUSH_RBK_RVW_STRIDE;
     for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
@@ -866,27 +869,30 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel_g(lush_rbk_params p, 
         }
     }
     __syncthreads();
-    rbk_dense_bwd_w_g(sc + RA_R, ST, acts + RA_HR, ST, g.w_r, g.b_r, n, 32, 3 * M);
-    rbk_dense_bwd_w_g(sc + RA_V, ST, acts + RA_HV, ST, g.w_v, g.b_v, n, 32, 3 * M);
-    rbk_dense_bwd_w_g(sc + RA_WS, ST, acts + RA_HW, ST, g.w_w, g.b_w, n, 32, M + 1);
+    rbk_dense_bwd_w_g(sc + RA_R, ST, acts + RA_HR, ST, g.w_r, g.b_r, n, 32, 3 * M, accumulate);
+    rbk_dense_bwd_w_g(sc + RA_V, ST, acts + RA_HV, ST, g.w_v, g.b_v, n, 32, 3 * M, accumulate);
+    rbk_dense_bwd_w_g(sc + RA_WS, ST, acts + RA_HW, ST, g.w_w, g.b_w, n, 32, M + 1, accumulate);
     rbk_dense_bwd_x_g(p.w_r, sc + RA_R, ST, sc + RA_HR, ST, acts + RA_HR, ST, n, 32, 3 * M, 0);
     rbk_dense_bwd_x_g(p.w_v, sc + RA_V, ST, sc + RA_HV, ST, acts + RA_HV, ST, n, 32, 3 * M, 0);
     rbk_dense_bwd_x_g(p.w_w, sc + RA_WS, ST, sc + RA_HW, ST, acts + RA_HW, ST, n, 32, M + 1, 0);
     const float* h3 = acts + RA_H0 + 192;
-    rbk_dense_bwd_w_g(sc + RA_HR, ST, h3, ST, g.w_rb, g.b_rb, n, 64, 32);
-    rbk_dense_bwd_w_g(sc + RA_HV, ST, h3, ST, g.w_vb, g.b_vb, n, 64, 32);
-    rbk_dense_bwd_w_g(sc + RA_HW, ST, h3, ST, g.w_wb, g.b_wb, n, 64, 32);
+    rbk_dense_bwd_w_g(sc + RA_HR, ST, h3, ST, g.w_rb, g.b_rb, n, 64, 32, accumulate);
+    rbk_dense_bwd_w_g(sc + RA_HV, ST, h3, ST, g.w_vb, g.b_vb, n, 64, 32, accumulate);
+    rbk_dense_bwd_w_g(sc + RA_HW, ST, h3, ST, g.w_wb, g.b_wb, n, 64, 32, accumulate);
     float* dh3 = sc + RA_H0 + 192;
     rbk_dense_bwd_x_g(p.w_rb, sc + RA_HR, ST, dh3, ST, nullptr, 0, n, 64, 32, 0);
     rbk_dense_bwd_x_g(p.w_vb, sc + RA_HV, ST, dh3, ST, nullptr, 0, n, 64, 32, 1);
     rbk_dense_bwd_x_g(p.w_wb, sc + RA_HW, ST, dh3, ST, h3, ST, n, 64, 32, 1);
     for (int l = 3; l >= 0; --l) {
         const float* x = acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_w_g(sc + RA_H0 + 64 * l, ST, x, ST, g.w_trunk[l], g.b_trunk[l], n, 64, 64);
+        rbk_dense_bwd_w_g(sc + RA_H0 + 64 * l, ST, x, ST, g.w_trunk[l], g.b_trunk[l], n, 64, 64, accumulate);
         float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
         rbk_dense_bwd_x_g(p.w_trunk[l], sc + RA_H0 + 64 * l, ST, dx, ST, l == 0 ? nullptr : x, ST, n, 64, 64, 0);
     }
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) g.embed[t] = sc[(t / 64) * ST + RA_E + (t % 64)];
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {
+        const float v = sc[(t / 64) * ST + RA_E + (t % 64)];
+        g.embed[t] = accumulate ? g.embed[t] + v : v;
+    }
 }
 
 // ------------------------------------------------------- blur mix / tone map
@@ -943,11 +949,11 @@ __global__ void noise_act_bwd_kernel(const float* __restrict__ x, int n, const f
     if (t < n) { const float s = 1.f / (1.f + expf(-x[t])); dx[t] += dy[t] * 0.1f * s * (1.f - s); }
 }
 __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ tg,
-                            int n3, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
+                            int n3, float scale, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0.f;
     if (t < n3) {
-        const float inv = 1.f / (float)n3;
+        const float inv = scale / (float)n3;
         const float da = a[t] - tg[t], db = b[t] - tg[t];
         l = 0.5f * (da * da + fabsf(da) + db * db + fabsf(db)) * inv;
         ga[t] = (da + 0.5f * (da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f))) * inv;
@@ -955,6 +961,62 @@ __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict
     }
     l = wave_sum(l);
     if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+}
+
+// ------------------------------------------------------------------ random draws
+// The four draws of one march (models/lushnerf.py:515 torch.rand [R,Ns]; :322 torch.randn_like [R,Ns-1]; helpers:578
+// torch.rand [R,Ni]; :322 [R,Ns+Ni-1]) in ONE launch: Philox4x32-10 counter RNG, key = (seed, stream), counter = (element
+// quad, array id, call offset).  Uniforms are 24-bit in [0, 1) as torch.rand's; normals are Box-Muller pairs.  The
+// reference's own torch RNG stream cannot be reproduced (it differs between CPU and GPU builds of torch itself);
+// parity tests pass explicit draws instead.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+struct DrawArr { float* p; long long n; int normal; };
+struct DrawSet { DrawArr a[4]; };
+__global__ void draws_kernel(DrawSet S, unsigned long long seed, unsigned long long offset, long long total_quads) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total_quads) return;
+    long long base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long nq = (S.a[i].n + 3) / 4;
+        if (q >= base && q < base + nq) {
+            const long long e = q - base;
+            unsigned c[4] = {(unsigned)e, (unsigned)(e >> 32), (unsigned)i, (unsigned)offset};
+            philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32));
+            float v[4];
+            if (S.a[i].normal) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float u1 = ((float)(c[2 * h] >> 8) + 1.0f) * 5.9604644775390625e-08f;          // (0, 1]
+                    const float u2 = (float)(c[2 * h + 1] >> 8) * 5.9604644775390625e-08f;                // [0, 1)
+                    const float rad = sqrtf(-2.0f * logf(u1));
+                    float sn, cs;
+                    sincosf(6.283185307179586f * u2, &sn, &cs);
+                    v[2 * h] = rad * cs;
+                    v[2 * h + 1] = rad * sn;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) v[h] = (float)(c[h] >> 8) * 5.9604644775390625e-08f;          // [0, 1), 24 bits
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                if (4 * e + h < S.a[i].n) S.a[i].p[4 * e + h] = v[h];
+        }
+        base += nq;
+    }
 }
 
 // ------------------------------------------------------- d rays from d points
@@ -1009,7 +1071,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 2; }
+int lush_abi_version(void) { return 3; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
@@ -1121,15 +1183,15 @@ int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window,
     return 0;
 }
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
-                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, lush_stream_t st) {
+                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, int accumulate, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
     const size_t lds = (size_t)2 * num_img * RBK_LS * sizeof(float);
     if (lds > 160 * 1024) {
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate);
     } else {
         LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch);
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate);
     }
     CHECK_LAUNCH();
     return 0;
@@ -1179,9 +1241,24 @@ int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_s
     CHECK_LAUNCH();
     return 0;
 }
-int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float* loss, float* ga, float* gb,
-                      lush_stream_t st) {
-    hipLaunchKernelGGL(loss_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), a, b, target, 3 * n, loss, ga, gb);
+int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float scale, float* loss, float* ga,
+                      float* gb, lush_stream_t st) {
+    hipLaunchKernelGGL(loss_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), a, b, target, 3 * n, scale, loss, ga, gb);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_draws(unsigned long long seed, unsigned long long offset, float* t_rand, long long n_t, float* noise_c,
+               long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t st) {
+    DrawSet S{};
+    S.a[0] = {t_rand, t_rand ? n_t : 0, 0};
+    S.a[1] = {noise_c, noise_c ? n_c : 0, 1};
+    S.a[2] = {u, u ? n_u : 0, 0};
+    S.a[3] = {noise_f, noise_f ? n_f : 0, 1};
+    long long quads = 0;
+    for (int i = 0; i < 4; ++i) quads += (S.a[i].n + 3) / 4;
+    if (quads == 0) return 0;
+    hipLaunchKernelGGL(draws_kernel, dim3(cdiv(quads, 256)), dim3(256), 0, S_(st), S, seed, offset, quads);
     CHECK_LAUNCH();
     return 0;
 }

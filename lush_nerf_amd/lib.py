@@ -93,7 +93,7 @@ _SIGS = {
     "lush_align_rays": ([_p, _p, _p, _i, _p, _i, _i, _ll, _i, _i, _f, _f, _f, _f, _p, _p, _p], _i),
     "lush_consist_loss_fwd_bwd": ([_p, _p, _i, _i, _f, _p, _p, _p], _i),
     "lush_rbk_mlp_fwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p], _i),
-    "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, C.POINTER(RbkParams), _p, _p], _i),
+    "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, C.POINTER(RbkParams), _p, _i, _p], _i),
     "lush_rbk_warp_fwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
     "lush_rbk_warp_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p], _i),
     "lush_wsum_fwd": ([_p, _p, _i, _i, _i, _p, _p], _i),
@@ -102,7 +102,8 @@ _SIGS = {
     "lush_tonemap_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
     "lush_noise_act_fwd": ([_p, _i, _p, _p], _i),
     "lush_noise_act_bwd": ([_p, _i, _p, _p, _p], _i),
-    "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _p, _p, _p, _p], _i),
+    "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _f, _p, _p, _p, _p], _i),
+    "lush_draws": ([C.c_ulonglong, C.c_ulonglong, _p, _ll, _p, _ll, _p, _ll, _p, _ll, _p], _i),
     "lush_mlp_packed_bytes": ([_i, _i], _sz),
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
     "lush_mlp_stash_bytes": ([_i, _i, _i, _ll], _sz),
@@ -117,7 +118,7 @@ _SIGS = {
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 2
+ABI_VERSION = 3
 # include/lush_march.h: LUSH_FAULT_*
 FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
                128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}

@@ -147,6 +147,7 @@ class NeRFAll(nn.Module):
         # numerical-fault word (include/lush_march.h LUSH_FAULT_*): the kernels OR bits into it, read_faults()
         # fetches and clears it.  Not persistent: the reference state_dict has exactly 108 keys.
         self.register_buffer("_faults", torch.zeros(1, dtype=torch.int32), persistent=False)
+        self.rng_stream = 0      # Philox stream of the march draws; the trainer sets it to the data-parallel rank
 
     # ------------------------------------------------------------------ helpers
     def tonemapping(self, x, noise_raw=None):
@@ -168,20 +169,10 @@ class NeRFAll(nn.Module):
 
     def _draws(self, R, N_samples, N_importance, perturb, raw_noise_std, device, draws):
         """Random draws in the reference's order and shapes (models/lushnerf.py:515, :322;
-        helpers:578) unless given explicitly (parity tests)."""
+        helpers:578) unless given explicitly (parity tests): one device-side Philox launch."""
         if draws is not None:
             return draws
-        d = {}
-        if perturb > 0:
-            d["t_rand"] = torch.rand(R, N_samples, device=device)
-        if raw_noise_std > 0:
-            d["noise_c"] = torch.randn(R, N_samples - 1, device=device)
-        if N_importance > 0:
-            if perturb > 0:
-                d["u"] = torch.rand(R, N_importance, device=device)
-            if raw_noise_std > 0:
-                d["noise_f"] = torch.randn(R, N_samples + N_importance - 1, device=device)
-        return d
+        return ops.march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, stream_id=self.rng_stream)
 
     def _march(self, ray_batch, N_samples, N_importance, perturb, raw_noise_std, white_bkgd, lindisp, retraw,
                draws=None):

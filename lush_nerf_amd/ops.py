@@ -426,11 +426,14 @@ class RbkWarp(torch.autograd.Function):
         lib.call("lush_rbk_warp_bwd", lib.ptr(ctx.rays), lib.ptr(ctx.idx), N, M, lib.ptr(ctx.acts),
                  lib.ptr(_opt(g_rays)), lib.ptr(_opt(g_ccw)), lib.ptr(ctx.mask), lib.ptr(d_rvw), lib.ptr(drays),
                  _stream())
-        grads = [torch.empty_like(t) for t in ctx.tensors]
+        sink = grad_sink(ctx.tensors)          # the trainer's flat gradient: add straight into it
+        grads = list(sink) if sink is not None else [torch.empty_like(t) for t in ctx.tensors]
         scratch = torch.empty(num_img, RBK_ACT, dtype=torch.float32, device=dev)
         st, gs = lib.rbk_struct(ctx.tensors), lib.rbk_struct(grads)
         lib.call("lush_rbk_mlp_bwd", C.byref(st), num_img, M, window, lib.ptr(ctx.acts), lib.ptr(d_rvw),
-                 C.byref(gs), lib.ptr(scratch), _stream())
+                 C.byref(gs), lib.ptr(scratch), int(sink is not None), _stream())
+        if sink is not None:
+            grads = [None] * len(grads)
         return (drays, None, None, None, None, *grads)
 
 
@@ -501,6 +504,17 @@ class NoiseAct(torch.autograd.Function):
         return dx
 
 
+def train_loss_grads(a, b, target, scale: float = 1.0):
+    """run_lushnerf.py:652-661 without an autograd node: (scale * loss, scale * d loss/d a, scale * d loss/d b) from one
+    kernel.  The trainer feeds the two gradients to torch.autograd.backward itself (no ones-fill, no grad * g kernels)."""
+    a, b, target = _f32(a.detach()), _f32(b.detach()), _f32(target)
+    loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+    ga, gb = torch.empty_like(a), torch.empty_like(b)
+    lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(target), a.shape[0], float(scale), lib.ptr(loss),
+             lib.ptr(ga), lib.ptr(gb), _stream())
+    return loss[0], ga, gb
+
+
 class TrainLoss(torch.autograd.Function):
     """run_lushnerf.py:652-661: 0.5*MSE + 0.5*L1 on rgb_blur and on rgb0_blur."""
 
@@ -509,7 +523,7 @@ class TrainLoss(torch.autograd.Function):
         a, b, target = _f32(a), _f32(b), _f32(target)
         loss = torch.zeros(1, dtype=torch.float32, device=a.device)
         ga, gb = torch.empty_like(a), torch.empty_like(b)
-        lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(target), a.shape[0], lib.ptr(loss), lib.ptr(ga),
+        lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(target), a.shape[0], 1.0, lib.ptr(loss), lib.ptr(ga),
                  lib.ptr(gb), _stream())
         ctx.save_for_backward(ga, gb)
         return loss[0]
@@ -590,3 +604,32 @@ class ConsistLoss(torch.autograd.Function):
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
         return grad * g, None, None
+
+
+_DRAW_OFFSET = [0]
+
+
+def march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, seed=None, stream_id=0):
+    """The random draws of one march, in the reference's shapes (models/lushnerf.py:515, :322;
+    utils/run_lushnerf_helpers.py:578), from ONE Philox launch (lush_draws) instead of four torch RNG kernels.
+    seed defaults to torch's CUDA seed (so torch.manual_seed governs it); every call takes the next offset;
+    stream_id separates data-parallel ranks that share a seed."""
+    if seed is None:
+        seed = torch.cuda.initial_seed()
+    _DRAW_OFFSET[0] += 1
+    d = {}
+    if perturb > 0:
+        d["t_rand"] = torch.empty(R, N_samples, dtype=torch.float32, device=device)
+    if raw_noise_std > 0:
+        d["noise_c"] = torch.empty(R, N_samples - 1, dtype=torch.float32, device=device)
+    if N_importance > 0:
+        if perturb > 0:
+            d["u"] = torch.empty(R, N_importance, dtype=torch.float32, device=device)
+        if raw_noise_std > 0:
+            d["noise_f"] = torch.empty(R, N_samples + N_importance - 1, dtype=torch.float32, device=device)
+    if d:
+        g = lambda k: (lib.ptr(d.get(k)), d[k].numel() if k in d else 0)
+        lib.call("lush_draws", C.c_ulonglong(int(seed) & (2 ** 64 - 1)),
+                 C.c_ulonglong((int(stream_id) << 40) + _DRAW_OFFSET[0]), *g("t_rand"), *g("noise_c"), *g("u"), *g("noise_f"),
+                 _stream())
+    return d

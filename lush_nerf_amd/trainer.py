@@ -92,6 +92,7 @@ class Trainer:
         self.micro_batch = micro_batch
         self.distributed = distributed and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
+        model.rng_stream = dist.get_rank() if self.distributed else 0     # ranks draw different jitter / noise
         self.flat = FlatParams(adam_segments(model))
         n = self.flat.numel
         self.m = torch.zeros(n, dtype=torch.float32, device=self.flat.param.device)
@@ -145,9 +146,9 @@ class Trainer:
         out = self.model(self.H, self.W, self.K, chunk=self.chunk, rays=rays, rays_info={"images_idx": idx},
                          retraw=True, force_naive=force_naive, allkernel=i < self.allkernel_start_iter,
                          kernel_pixel=batch["fq_mask"][a:b], draws=d, **self.kw)
-        part = ops.TrainLoss.apply(out[0], out[1], batch["target"][a:b]) * frac
-        part.backward()
-        return part.detach()
+        part, ga, gb = ops.train_loss_grads(out[0], out[1], batch["target"][a:b], frac)
+        torch.autograd.backward([out[0], out[1]], [ga, gb])
+        return part
 
     def _consistency(self, consist, weight):
         """The aligned-pixel branch (run_lushnerf.py:629-650): loss_rgb and its backward; returns loss_rgb."""

@@ -21,7 +21,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SECTIONS = ["t_zgrid_pack", "t_gen_rays", "t_composite", "t_sample", "t_mlp_fwd", "t_mlp_ragged", "t_mlp_bwd", "t_rbk", "t_mix",
-            "t_march_e2e", "t_train_e2e", "t_lindisp_white", "t_eval_forward", "t_consistency", "t_faults"]
+            "t_march_e2e", "t_train_e2e", "t_lindisp_white", "t_eval_forward", "t_consistency", "t_faults", "t_draws"]
 
 
 @pytest.fixture(scope="module")
