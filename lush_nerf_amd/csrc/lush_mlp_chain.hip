@@ -123,19 +123,10 @@ struct ChCtx {
 // of the stream -> the same offset inside ring slot `dst`.
 template <int PIECES, int SLOT>
 __device__ __forceinline__ void ch_issue(const ChCtx& cx, unsigned off, int slot) {
-#ifdef LUSH_DMA_V2
-    constexpr int ND = PIECES / 4;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)slot * SLOT + (unsigned)cx.w * (ND * 1024u));
-    const char* src = cx.gbase + off + (unsigned)cx.w * (ND * 1024u);
-    if constexpr (ND == 4) { dma16_grp<0, 2>(src, cx.voff[0], dst); dma16_grp<2048, 2>(src, cx.voff[0], dst); }
-    else if constexpr (ND == 2) dma16_grp<0, 2>(src, cx.voff[0], dst);
-    else { static_assert(ND == 1, "pieces per wave and position"); dma16_grp<0, 1>(src, cx.voff[0], dst); }
-#else
     const unsigned dst = cx.ring_lds + (unsigned)slot * SLOT + (unsigned)cx.w * 1024u;
     const char* src = cx.gbase + off;
 #pragma unroll
     for (int d = 0; d < PIECES / 4; ++d) dma16s(src, cx.voff[d], __builtin_amdgcn_readfirstlane(dst + (unsigned)d * 4096u));
-#endif
 }
 
 template <int NS, int NU>
@@ -226,28 +217,14 @@ struct ChPhase {
     }
 
     static __device__ __forceinline__ void st_write(const Stash& st, const bf16x8 (&xin)[KX][NS], int job, int kq, int lane) {
-#ifdef LUSH_ABL_FRAGSTORE   // timing experiment (wrong layout): k-block fragments stored straight from registers, 1 KiB contiguous each
-        {
-            const int j = job / SP, p = job % SP;
-            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, xin[4 * j + kq][p]),
-                                        reinterpret_cast<u32x4*>(reinterpret_cast<char*>(st.rows + p * st.plane) + (4 * j + kq) * 1024 + lane * 16));
-            return;
-        }
-#endif
         const int n = lane & 31, hh = lane >> 5, j = job / SP, p = job % SP;
         *reinterpret_cast<u32x4*>(st.tile + n * 128 + (((2 * kq + hh) ^ (n & 7)) << 4)) = __builtin_bit_cast(u32x4, xin[4 * j + kq][p]);
     }
     static __device__ __forceinline__ void st_read(const Stash& st, Regs& r, int i, int lane) {
-#ifdef LUSH_ABL_FRAGSTORE
-        return;
-#endif
         const int row = 8 * i + (lane >> 3);
         r.sb[i] = *reinterpret_cast<const u32x4*>(st.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
     }
     static __device__ __forceinline__ void st_store(const Stash& st, const Regs& r, int job, int i, int lane) {
-#ifdef LUSH_ABL_FRAGSTORE
-        return;
-#endif
         const int j = job / SP, p = job % SP;
         u32x4* dst = reinterpret_cast<u32x4*>(st.rows + p * st.plane + (long long)(8 * i + (lane >> 3)) * LD + j * 64 + (lane & 7) * 8);
 #if defined(LUSH_ABL_NOSTORE)     // timing ablation only
@@ -303,14 +280,6 @@ struct ChPhase {
                     if (is_dma) {
 #if defined(LUSH_ABL_NODMA)     // timing ablation only (wrong results): the refill DMAs are not issued
                         (void)dma_off; (void)dma_dst;
-#elif defined(LUSH_DMA_V2)
-                        // (d is a constant after unrolling; the immediate offset must be one in the source too)
-                        if (d == 0) {
-                            if (ND >= 2) dma16_grp<0, 2>(cx.gbase + dma_off, cx.voff[0], dma_dst);
-                            else dma16_grp<0, 1>(cx.gbase + dma_off, cx.voff[0], dma_dst);
-                        } else if (d == 2) {
-                            dma16_grp<2048, 2>(cx.gbase + dma_off, cx.voff[0], dma_dst);
-                        }
 #else
                         // pieces go in pairs under one M0 save/restore (the odd one of a pair is a no-op filler)
                         if (d % 2 == 0) {
@@ -373,13 +342,7 @@ struct ChPhase {
 #else
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-#ifdef LUSH_DMA_V2
-        static_assert(dma_count(I) == 1 || dma_count(I) == 2 || dma_count(I) == 4, "pieces per wave and position");
-        constexpr unsigned WSTRIDE = (unsigned)dma_count(I) * 1024u;      // this wave's pieces are consecutive KiB
-#else
-        constexpr unsigned WSTRIDE = 1024u;
-#endif
-        const unsigned dma_dst = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * WSTRIDE);
+        const unsigned dma_dst = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)cx.cslot * SC::SLOT + (unsigned)cx.w * 1024u);
         unsigned dma_off;
         if constexpr (TRUNK) {
             unsigned np = cx.trunk_pos + SC::S;
@@ -389,9 +352,7 @@ struct ChPhase {
         } else {
             dma_off = SC::tail_off(T0 + I + SC::S);
         }
-#ifdef LUSH_DMA_V2
-        dma_off += (unsigned)cx.w * WSTRIDE;
-#endif
+
         cx.cslot = cx.cslot + 1 == SC::S ? 0 : cx.cslot + 1;
         __builtin_amdgcn_sched_barrier(0);
         h2<I>(cx, acc, r, xin, cx.ring + cx.cslot * SC::SLOT, dma_off, dma_dst, st, std::make_integer_sequence<int, NM>{});
@@ -547,13 +508,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     cx.trunk_pos = 0;
     cx.w = w;
     cx.lane = lane;
-#ifdef LUSH_DMA_V2
-#pragma unroll
-    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u;
-#else
 #pragma unroll
     for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
-#endif
 #pragma unroll
     for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
 
@@ -701,6 +657,13 @@ struct HfSched {
 // acc[rb][q] = bias[32 rb + 16 (q>>3) + 8 h + (q&7)] straight from global memory (L2-resident fp32 block)
 template <int NB>
 __device__ __forceinline__ void ch_bias_g(f32x16 (&acc)[NB], const float* __restrict__ b, int h) {
+#ifdef LUSH_ABL_NOBIAS     // timing ablation only (wrong results): no bias loads
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[rb][q] = 0.f;
+    return;
+#endif
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) {
         const f32x4* p = reinterpret_cast<const f32x4*>(b + rb * 32 + 8 * h);
@@ -968,13 +931,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
     cx.trunk_pos = 0;
     cx.w = w;
     cx.lane = lane;
-#ifdef LUSH_DMA_V2
-#pragma unroll
-    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u;
-#else
 #pragma unroll
     for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
-#endif
 #pragma unroll
     for (int j = 0; j < CH_S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
     char* tile_w = stage + w * 4096;

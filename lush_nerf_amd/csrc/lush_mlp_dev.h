@@ -134,20 +134,4 @@ __device__ __forceinline__ void dma16s_x2(const void* sbase, unsigned voff0, uns
                  : "=&s"(keep) : "v"(voff0), "s"(sbase), "s"(lds0), "v"(voff1), "s"(lds1) : "memory");
 }
 
-// DMA form 2 (LUSH_DMA_V2): a wave's pieces of a ring position are CONSECUTIVE KiB, so they differ only in the
-// instruction's immediate offset, which the hardware adds to the global address AND to the LDS address
-// (LDS_addr = M0 base + inst_offset + 16*lane): one M0 write serves the whole group, no M0 save/restore (nothing else
-// in these kernels uses M0: checked in the ISA), one per-lane offset register (16*lane) for every DMA of the kernel.
-template <int OFF0, int N>
-__device__ __forceinline__ void dma16_grp(const void* sbase /* uniform */, unsigned vlane16, unsigned lds_base /* uniform */) {
-    static_assert(N == 1 || N == 2, "1 or 2 pieces per statement");
-    static_assert(OFF0 >= 0 && OFF0 + (N - 1) * 1024 < 4096, "13-bit signed immediate offset");
-    if constexpr (N == 2)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4"
-                     :: "v"(vlane16), "s"(sbase), "s"(lds_base), "n"(OFF0), "n"(OFF0 + 1024) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
-                     :: "v"(vlane16), "s"(sbase), "s"(lds_base), "n"(OFF0) : "memory");
-}
-
 }  // namespace lush
