@@ -64,8 +64,9 @@ MlpParams to_params(const lush_mlp_params* p) {
     return q;
 }
 
+// copy 0 = natural rows (tiled 3-plane kernels), copy 1 = chain_row() permutation (chain kernels)
 template <class N>
-void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
+void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks, int copy_lo, int copy_hi) {
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP;
     T.n = 0;
     blocks = 0;
@@ -78,7 +79,7 @@ void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
     };
     const int XV = PE_X_VALID, DV = PE_D_VALID;
     // forward: natural rows for mlp_fwd_kernel, then the row-permuted copy for the chain kernel
-    for (int copy = 0; copy < 2; ++copy) {
+    for (int copy = copy_lo; copy <= copy_hi; ++copy) {
         perm = copy; base = copy ? N::fwd2_base : 0;
         add(p->w[0], XV, 1, HW, XV, N::NRB, N::KKX, N::fwd_L(0, false));
         for (int l = 1; l < NL; ++l) {
@@ -97,7 +98,7 @@ void build_pack_table(const lush_mlp_params* p, PackTable& T, int& blocks) {
     }
     perm = 0; base = 0;
     // transposed: element (row, k) = W[k][c0 + row]; natural rows for mlp_bwd_kernel, permuted copy for the chain kernel
-    for (int copy = 0; copy < 2; ++copy) {
+    for (int copy = copy_lo; copy <= copy_hi; ++copy) {
         perm = copy; base = copy ? N::bwd2_base - N::bwd_VAT : 0;
         add(p->w_views, 1, HW + DV, HW, HV, N::NRB, N::KKV, N::bwd_VAT);
         add(p->w_views + HW, 1, HW + DV, DV, HV, 1, N::KVB, N::bwd_VBT);
@@ -153,7 +154,9 @@ void build_pack_table_half(const lush_mlp_params* p, PackTable& T, int& blocks) 
 
 int dw_splits(long long Ppad, int /*tiles*/) {
     int s = 256;                                   // one 256x256-tile workgroup per CU
-    const long long max_s = Ppad / 32;
+    // every workgroup ends a layer with 256 KB of atomics and starts it with a ring refill: give it at least 128
+    // points (the 4096-point noise net ran 128 workgroups of one tile each: 189 us for 7 tiny GEMMs)
+    const long long max_s = Ppad / 128 > 0 ? Ppad / 128 : 1;
     if (s > max_s) s = (int)max_s;
     return s < 1 ? 1 : s;
 }
@@ -171,10 +174,13 @@ size_t lush_mlp_packed_bytes(int net, int planes) {
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream) {
     PackTable T;
     int blocks = 0;
-    if (net == 0) build_pack_table<NetNerf>(prm, T, blocks);
-    else if (net == 1) build_pack_table<NetNoise>(prm, T, blocks);
-    else return set_error("lush_mlp_pack: bad net");
     if (!code_ok(planes)) return set_error("lush_mlp_pack: planes must be 1..3 or 17 (fp16)");
+    // only the copies the kernels of this plane count read (the rest of the buffer stays unwritten)
+    const bool fc = mlp_fwd_chain_enabled(planes), bc = mlp_bwd_chain_enabled(planes);
+    const int lo = (fc && bc) ? 1 : 0, hi = (fc || bc) ? 1 : 0;
+    if (net == 0) build_pack_table<NetNerf>(prm, T, blocks, lo, hi);
+    else if (net == 1) build_pack_table<NetNoise>(prm, T, blocks, lo, hi);
+    else return set_error("lush_mlp_pack: bad net");
     int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
     if (rc) return rc;
     if (net == 0 && nplanes(planes) == 1) {      // the half-row stream is read by the one-plane forward only

@@ -312,6 +312,8 @@ class March(torch.autograd.Function):
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.update(stash_c=saved.get("stash_c"), stash_f=saved.get("stash_f"), P_c=zc.numel(),
                               P_f=saved["zf"].numel() if "zf" in saved else 0, batch=batch)
+        if pf == pb:      # the packed buffer holds forward and transposed fragments: the backward reuses it
+            saved.update(pk_c=pk_c, pk_f=pk_f if cfg.N_importance > 0 else None)
         ctx.cfg, ctx.n_coarse, ctx.n_params = cfg, n_coarse, len(params)
         ctx.batch, ctx.coarse, ctx.fine, ctx.saved = batch, coarse, fine, saved
         nd = [outs[3], outs[4], outs[5], outs[6]] + ([outs[10], outs[11]] if cfg.N_importance > 0 else [])
@@ -329,9 +331,10 @@ class March(torch.autograd.Function):
         grads_c: List[Optional[torch.Tensor]] = [None] * len(ctx.coarse)
         grads_f: List[Optional[torch.Tensor]] = []
 
-        def run(tensors, z, raw, noise, stash, gg):
+        def run(tensors, z, raw, noise, stash, gg, pk=None):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
-            pk = mlp_pack(NET_NERF, pb, tensors)
+            if pk is None:
+                pk = mlp_pack(NET_NERF, pb, tensors)
             gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash,
                                     sink=grad_sink(tensors))
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays),
@@ -339,9 +342,9 @@ class March(torch.autograd.Function):
             return gr
 
         if fine_on and any(x is not None for x in g_main):
-            grads_f = run(ctx.fine, sv["zf"], sv["raw_f"], sv["noise_f"], sv["stash_f"], g_main)
+            grads_f = run(ctx.fine, sv["zf"], sv["raw_f"], sv["noise_f"], sv["stash_f"], g_main, sv.get("pk_f"))
         if any(x is not None for x in g_c):
-            grads_c = run(ctx.coarse, sv["zc"], sv["raw_c"], sv["noise_c"], sv["stash_c"], g_c)
+            grads_c = run(ctx.coarse, sv["zc"], sv["raw_c"], sv["noise_c"], sv["stash_c"], g_c, sv.get("pk_c"))
         ctx.saved = None
         if fine_on and ctx.fine is ctx.coarse and grads_f:
             grads_c = [(a + b if b is not None else a) if a is not None else b for a, b in zip(grads_c, grads_f)]
