@@ -152,6 +152,33 @@ void build_pack_table_half(const lush_mlp_params* p, PackTable& T, int& blocks) 
     add(p->w_rgb, HV, 3, HV, 1, N::KKV);
 }
 
+// Third transposed copy (NetT::bwd3_base): half-row stream of mlp_chain_bwd_half_kernel.
+template <class N>
+void build_pack_table_half_bwd(const lush_mlp_params* p, PackTable& T, int& blocks) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP, HR = N::HW / 2, NRBH = N::NRB / 2;
+    T.n = 0;
+    blocks = 0;
+    int dst = N::bwd3_base;
+    // element (row, k) = W[k][c0 + row]: src = W + c0, row stride 1, k stride = W's row length
+    auto add = [&](const float* src, int sk, int rows, int cols, int nrb, int kk) {
+        PackJob& j = T.j[T.n++];
+        j.src = src; j.sr = 1; j.sk = sk; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk; j.perm = 1;
+        j.dst_entry = dst; j.first_block = blocks;
+        blocks += nrb * kk;
+        dst += nrb * kk;
+    };
+    const int XV = PE_X_VALID, DV = PE_D_VALID;
+    for (int half = 0; half < 2; ++half) add(p->w_views + half * HR, HW + DV, HR, HV, NRBH, N::KKV);
+    add(p->w_views + HW, HW + DV, DV, HV, 1, N::KVB);
+    for (int half = 0; half < 2; ++half) add(p->w_feat + half * HR, HW, HR, HW, NRBH, N::KKH);
+    for (int l = NL - 1; l >= 1; --l) {
+        const int ld = l == SK ? XV + HW : HW;
+        if (l == SK) add(p->w[l], ld, XV, HW, 2, N::KKH);
+        for (int half = 0; half < 2; ++half) add(p->w[l] + (l == SK ? XV : 0) + half * HR, ld, HR, HW, NRBH, N::KKH);
+    }
+    add(p->w[0], XV, XV, HW, 2, N::KKH);
+}
+
 int dw_splits(long long Ppad, int /*tiles*/) {
     int s = 256;                                   // one 256x256-tile workgroup per CU
     // every workgroup ends a layer with 256 KB of atomics and starts it with a ring refill: give it at least 128
@@ -183,8 +210,11 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
     else return set_error("lush_mlp_pack: bad net");
     int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
     if (rc) return rc;
-    if (net == 0 && nplanes(planes) == 1) {      // the half-row stream is read by the one-plane forward only
+    if (net == 0 && nplanes(planes) == 1) {      // the half-row streams are read by the one-plane chain kernels only
         build_pack_table_half<NetNerf>(prm, T, blocks);
+        rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+        if (rc) return rc;
+        build_pack_table_half_bwd<NetNerf>(prm, T, blocks);
         rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
         if (rc) return rc;
     }

@@ -67,7 +67,10 @@ struct NetT {
     // chain_row() as in the second copy, but every full-width segment is cut into its two 128-row halves and the stream
     // runs [half 0 of the layer | half 1 of the layer] (skip layer: [a0 | b0 | a1 | b1]); narrow segments unchanged.
     static constexpr int fwd3_base = bwd2_base + (bwd_END - bwd_VAT);
-    static constexpr int total_entries = fwd3_base + fwd_END;
+    // ... and of the transposed segments for mlp_chain_bwd_half_kernel: [VAT h0 | VAT h1 | VBT | FEATT h0 | h1 |
+    // per layer NL-1..1: (skip: a) b h0 | b h1 | L0T], every full-width segment in 128-row halves
+    static constexpr int bwd3_base = fwd3_base + fwd_END;
+    static constexpr int total_entries = bwd3_base + (bwd_END - bwd_VAT);
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
 

@@ -1093,6 +1093,253 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
 }
 
 // ----------------------------------------------------------------------------
+// one-plane backward chain in 256 registers: TWO workgroups per CU (see mlp_chain_fwd_half_kernel)
+// ----------------------------------------------------------------------------
+// Same half-row scheme on the transposed weights (NetT::bwd3 stream): 64 accumulators, the first half of dZ_{l-1} is
+// masked and converted while the second half runs.  LDS per workgroup <= 80 KiB: ring 4 x 8 KiB, the per-wave stash
+// tiles (also the scratch of the final reduction), the d(gamma) image in the chain's 16-bit type (fp32 would be
+// 51 KiB), the two K<=3 head matrices.  The d(gamma) partial sums are parked in that image between their phases
+// (one extra 16-bit rounding of the skip layer's share) because the accumulators are needed for the trunk.
+constexpr int BH_DPE_LD = 104;      // 16-bit elements per point in the d(gamma) image (96 used; rows stay 16-byte aligned)
+
+template <class N>
+struct HbSched {
+    static constexpr int NS = 1, GT = 2, NRBH = N::NRB / 2;
+    static constexpr int S = 4;
+    static constexpr int TRUNK_PIECES = NRBH * NS * GT;                    // 8 KiB per position
+    static constexpr int SLOT = TRUNK_PIECES * 1024;
+    static constexpr int trunk_wait = (S - 2) * TRUNK_PIECES / 4;
+    static constexpr int G_X = TRUNK_PIECES / 2, G_D = TRUNK_PIECES;       // k-blocks per position of the 2- and 1-row-block segments
+    static constexpr int NP_VA = N::KKV / GT, NP_VB = N::KVB / G_D, NP_H = N::KKH / GT, NP_X = N::KKH / G_X;
+    static constexpr int WRAP = 2 * NP_VA + NP_VB + 2 * NP_H * N::NL + (N::SKIP > 0 ? NP_X : 0) + NP_X;
+    static_assert(N::KKV % GT == 0 && N::KVB % G_D == 0 && N::KKH % G_X == 0 && N::KKH % GT == 0, "backward stream positions must be uniform");
+    static_assert((N::bwd_END - N::bwd_VAT) == WRAP * TRUNK_PIECES, "backward segments must tile into whole positions");
+    static constexpr int tail_pieces(int) { return TRUNK_PIECES; }
+    static constexpr unsigned tail_off(int) { return 0; }
+    static constexpr int tail_wait(int) { return trunk_wait; }
+};
+
+template <class N, bool HAS_ALPHA, int DT>
+__global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpBwdArgs A) {
+    using SC = HbSched<N>;
+    constexpr int NS = 1;
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, NRB = N::NRB, NRBH = N::NRB / 2, NRBV = N::NRBV, KKH = N::KKH;
+    constexpr int PARTS = CH_NT / CH_MT;
+    static_assert(NRBV == NRBH, "the views layer is one half wide");
+    float gscale = 1.f, ginv = 1.f;
+    if constexpr (DT == DT_F16) { gscale = A.scale[0]; ginv = A.scale[1]; }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                              // [S][SLOT]
+    char* stage = smem + SC::S * SC::SLOT;                          // [4 waves][4 KiB]; reused as dxbuf [PARTS][128][6] fp32
+    __bf16* dpe = reinterpret_cast<__bf16*>(stage + CH_NW * 4096);  // [128][BH_DPE_LD] in the chain's 16-bit type
+    float* wtab = reinterpret_cast<float*>(dpe + CH_MT * BH_DPE_LD);   // w_rgb [3][HV] | w_alpha [HW]
+    float* dxbuf = reinterpret_cast<float*>(stage);
+    static_assert(PARTS * CH_MT * 6 * 4 <= CH_NW * 4096, "the reduction scratch must fit the stash tiles");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const char* wbase = reinterpret_cast<const char*>(A.wpk);
+    {
+        const float* f32 = reinterpret_cast<const float*>(wbase + (long long)N::total_entries * NS * 1024);
+        for (int i = tid; i < 3 * HV + HW; i += CH_NT) wtab[i] = f32[N::f32_w_rgb + i];
+    }
+    const float* w_rgb = wtab;
+    const float* w_alpha = wtab + 3 * HV;
+    ChCtx cx;
+    cx.ring = ring;
+    cx.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    cx.gbase = wbase + (long long)N::bwd3_base * NS * 1024;
+    cx.cslot = 0;
+    cx.trunk_pos = 0;
+    cx.w = w;
+    cx.lane = lane;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cx.voff[d] = (unsigned)lane * 16u + (unsigned)d * 4096u + (unsigned)w * 1024u;
+#pragma unroll
+    for (int j = 0; j < SC::S; ++j) ch_issue<SC::TRUNK_PIECES, SC::SLOT>(cx, (unsigned)j * SC::SLOT, j);
+    char* tile_w = stage + w * 4096;
+    const int row = w * 32 + n;
+    bf16x8 xin[KKH][NS], xnx[KKH][NS];
+    typedef bf16x8 (&half_ref)[KKH / 2][NS];
+#pragma unroll
+    for (int kb = 0; kb < KKH; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xin[kb][0][j] = (__bf16)0.f; xnx[kb][0][j] = (__bf16)0.f; }
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * CH_MT;
+        const long long gpt = pt0 + row;
+        const long long wpt = pt0 + w * 32;
+        const long long blk = pt0 / 32 + w;
+        cx.trunk_pos = 0;
+        {
+            unsigned long long gb = (unsigned long long)cx.gbase;
+            asm volatile("" : "+s"(gb));
+            cx.gbase = (const char*)gb;
+        }
+        // ReLU decisions of (layer ml, row half): this lane's 16-bit words of the 4 row blocks
+        auto mask_words = [&](unsigned (&mw)[NRBH], int ml, int half) {
+            const unsigned short* m = reinterpret_cast<const unsigned short*>(A.mask + ((blk * N::n_mask_layers + ml) * NRB + half * NRBH) * 16) + lane;
+#pragma unroll
+            for (int rb = 0; rb < NRBH; ++rb) mw[rb] = (unsigned)m[rb * 64];
+        };
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gpt < A.P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
+        if constexpr (DT == DT_F16) { dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale; }
+        wait_vm<0>();
+        lds_barrier();         // also orders wtab and the previous tile's dpe / dxbuf traffic
+
+        f32x16 acc[NRBH];
+        unsigned mw[NRBH];
+        // d(gamma) columns 32b..32b+31 of this lane's point, 16-bit: rows are wave-private until the barrier below
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        __bf16* const grow = dpe + row * BH_DPE_LD + 8 * h;       // this lane's columns: 32b + 16t + 8h + (0..7)
+        auto dpe_put = [&](const f32x16& a, int b) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 pk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned o[1];
+                    split_pair<1, DT>(a[8 * t + 2 * i], a[8 * t + 2 * i + 1], o);
+                    pk[i] = o[0];
+                }
+                *reinterpret_cast<u32x4*>(grow + 32 * b + 16 * t) = pk;
+            }
+        };
+        auto dpe_add = [&](f32x16& a, int b) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(grow + 32 * b + 16 * t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[8 * t + i] += elem_to_f32<DT>(v[i]);
+            }
+        };
+        // ---- dZv = (Wrgb^T d_rgb) * relu'(hv)   (K = 3: rank-3 update on the VALU) ----
+        mask_words(mw, NL, 0);
+#pragma unroll
+        for (int rb = 0; rb < NRBV; ++rb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int f = 32 * rb + 16 * (q >> 3) + 8 * h + (q & 7);
+                acc[rb][q] = w_rgb[f] * dr.x + w_rgb[HV + f] * dr.y + w_rgb[2 * HV + f] * dr.z;
+            }
+        bw_convert<NS, true, NRBV, KKH, DT>(acc, xin, mw);
+        // ---- d_feature = Wva^T dZv (two row halves); d gamma(d) = Wvb^T dZv ----
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bw_zero<NRBH>(acc);
+            if (half == 0)
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, HV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * HV, A.plane_hv);
+            else
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
+            unsigned none[NRBH];
+            bw_convert<NS, false, NRBH, KKH / 2, DT>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), none);
+        }
+        {
+            f32x16 apd[1];
+            bw_zero<1>(apd);
+            ChPhase<SC, NS, DT, 1, SC::G_D, SC::NP_VB, B_REG, true, 0, KKH, 0, 1>::run(cx, apd, xin, nullptr, row, nullptr, nullptr, 0);
+            dpe_put(apd[0], 2);
+        }
+#pragma unroll
+        for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
+        // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            mask_words(mw, NL - 1, half);
+            bw_zero<NRBH>(acc);
+            if (half == 0)
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, NS, HW>::run(cx, acc, xin, nullptr, row, tile_w, A.dfeat + wpt * HW, A.plane_h);
+            else
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
+            if constexpr (HAS_ALPHA) {
+#pragma unroll
+                for (int rb = 0; rb < NRBH; ++rb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[rb][q] += w_alpha[half * (HW / 2) + 32 * rb + 16 * (q >> 3) + 8 * h + (q & 7)] * dr.w;
+            }
+            bw_convert<NS, true, NRBH, KKH / 2, DT>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mw);
+        }
+#pragma unroll
+        for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
+        // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}) ----
+#pragma unroll 1
+        for (int l = NL - 1; l >= 1; --l) {
+            if (l == N::SKIP) {   // gamma(x) rows of the skip layer's input, parked in the image until layer 0 adds its share
+                f32x16 apx[2];
+                bw_zero<2>(apx);
+                ChPhase<SC, NS, DT, 2, SC::G_X, SC::NP_X, B_REG, true, 0, KKH, 0, 1>::run(cx, apx, xin, nullptr, row, nullptr, nullptr, 0);
+                dpe_put(apx[0], 0);
+                dpe_put(apx[1], 1);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                mask_words(mw, l - 1, half);
+                bw_zero<NRBH>(acc);
+                if (half == 0)
+                    ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, NS, HW>::run(cx, acc, xin, nullptr, row, tile_w,
+                                                                                              A.dz0 + l * A.dz_stride + wpt * HW, A.plane_h);
+                else
+                    ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
+                bw_convert<NS, true, NRBH, KKH / 2, DT>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mw);
+            }
+#pragma unroll
+            for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
+        }
+        // ---- layer 0: d gamma(x) += W_0^T dZ_0 ----
+        {
+            f32x16 apx[2];
+            bw_zero<2>(apx);
+            ChPhase<SC, NS, DT, 2, SC::G_X, SC::NP_X, B_REG, true, 0, KKH, 0, 1>::run(cx, apx, xin, nullptr, row, nullptr, nullptr, 0);
+            bw_stash_all<NS, KKH, KKH, HW>(xin, tile_w, A.dz0 + wpt * HW, A.plane_h, lane);
+            if constexpr (N::SKIP > 0) { dpe_add(apx[0], 0); dpe_add(apx[1], 1); }
+            dpe_put(apx[0], 0);
+            dpe_put(apx[1], 1);
+        }
+        // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos) ----
+        lds_barrier();         // d(gamma) image complete; every wave has left its stash tile (dxbuf aliases them)
+        {
+            const int pt = tid % CH_MT, part = tid / CH_MT;
+            const long long gp = pt0 + pt;
+            float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+            if (gp < A.P) point_of(A.rays, A.z, A.S, gp, x, d);
+            float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+            const __bf16* g = dpe + pt * BH_DPE_LD;
+            auto gv = [&](int c) { return elem_to_f32<DT>(g[c]); };
+            for (int u = part; u < L_X + L_D; u += PARTS) {
+                const bool isd = u >= L_X;
+                const int k = isd ? u - L_X : u;
+                const int base = isd ? PE_X : 0;
+                const float f = (float)(1 << k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float v = isd ? d[i] : x[i];
+                    float sn, cs;
+                    lush_sincos(v * f, &sn, &cs);
+                    float t = f * (cs * gv(base + 3 + 6 * k + i) - sn * gv(base + 3 + 6 * k + 3 + i));
+                    if (k == 0) t += gv(base + i);
+                    if (isd) gd[i] += t; else gx[i] += t;
+                }
+            }
+            float* o = dxbuf + (part * CH_MT + pt) * 6;
+            o[0] = gx[0]; o[1] = gx[1]; o[2] = gx[2]; o[3] = gd[0]; o[4] = gd[1]; o[5] = gd[2];
+        }
+        lds_barrier();
+        for (int i = tid; i < CH_MT * 6; i += CH_NT) {
+            const int pt = i / 6, c = i % 6;
+            float sum = 0.f;
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) sum += dxbuf[(p * CH_MT + pt) * 6 + c];
+            const long long gp = pt0 + pt;
+            if (gp < A.P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum * ginv;
+        }
+    }
+    wait_vm<0>();
+}
+
+// ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
 template <class N, int NS, bool HAS_ALPHA>
@@ -1231,13 +1478,42 @@ bool mlp_bwd_chain_enabled(int planes) {
     return !old && (planes == 1 || planes == 2 || planes == PLANES_F16);
 }
 
+template <class N, bool HAS_ALPHA, int DT>
+static int launch_chain_bwd_half(const MlpBwdArgs& a, hipStream_t s) {
+    auto k = mlp_chain_bwd_half_kernel<N, HAS_ALPHA, DT>;
+    const size_t lds = (size_t)HbSched<N>::S * HbSched<N>::SLOT + (size_t)CH_NW * 4096 + (size_t)CH_MT * BH_DPE_LD * 2 +
+                       (size_t)(3 * N::HV + N::HW) * 4;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        LUSH_HIP(hipGetDevice(&dev));
+        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+    }
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = a.n_tiles < 2 * n_cu ? a.n_tiles : 2 * n_cu;     // two workgroups per CU
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+static bool bwd_half_enabled() {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("LUSH_BWD_512");       // A/B switch: 1 = the one-wave-per-SIMD backward chain for one plane too
+        off = (e && e[0] == '1') ? 1 : 0;
+    }
+    return !off;
+}
+
 int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s) {
     if (planes == PLANES_F16) {
         if (a.scale == nullptr) return set_error("launch_mlp_chain_bwd: the fp16 chain needs its loss scale");
-        if (net == 0) return launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
+        if (net == 0) return bwd_half_enabled() ? launch_chain_bwd_half<NetNerf, true, DT_F16>(a, s) : launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
         return launch_chain_bwd_k<NetNoise, 1, false, DT_F16>(a, s);
     }
     if (net == 0) {
+        if (planes == 1 && bwd_half_enabled()) return launch_chain_bwd_half<NetNerf, true, DT_BF16>(a, s);
         if (planes == 1) return launch_chain_bwd_k<NetNerf, 1, true>(a, s);
         if (planes == 2) return launch_chain_bwd_k<NetNerf, 2, true>(a, s);
     } else {
