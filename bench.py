@@ -30,8 +30,14 @@ MACS_PER_EVAL = 593_408            # NeRF D=8 W=256 MLP, verified layer shapes (
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 # stash bytes per MLP evaluation and bf16 plane ([point][feature] rows)
-BYTES_X_STASH = 2 * (128 + 8 * 256 + 256 + 128)    # gamma row, h_0..h_7, feature, views hidden
-BYTES_DZ_STASH = 2 * (8 * 256 + 256 + 128)         # dZ_0..dZ_7, d feature, dZ views
+# A one-plane backward keeps neither the feature activations nor their gradients (the feature layer is linear: its
+# weight gradients follow from dZv^T h_7, FeatFactorArgs in csrc/lush_mlp.h); with 2+ planes both are stashed.
+def BYTES_X_STASH(planes):
+    return 2 * (128 + 8 * 256 + (256 if planes >= 2 else 0) + 128)    # gamma row, h_0..h_7, [feature], views hidden
+
+
+def BYTES_DZ_STASH(planes):
+    return 2 * (8 * 256 + (256 if planes >= 2 else 0) + 128)          # dZ_0..dZ_7, [d feature], dZ views
 
 
 def make_model(args_ns, device, precision, seed=0, num_img=30):
@@ -330,8 +336,9 @@ def main():
         FLOP/s and algorithmic HBM bytes/s per launch (DESIGN.md section 5 gives the per-evaluation figures)."""
         sp = ops.nplanes(ops.stash_code(pf, pb))
         pbn = ops.nplanes(pb)
-        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH + 16 + 44 / 64, "mlp_bwd_chain": pbn * BYTES_DZ_STASH + 288 + 16 + 32,
-                      "mlp_bwd_weights": pbn * (BYTES_X_STASH + BYTES_DZ_STASH)}
+        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH(sp) + 16 + 44 / 64,
+                      "mlp_bwd_chain": pbn * BYTES_DZ_STASH(pbn) + 288 + 16 + 32,
+                      "mlp_bwd_weights": pbn * (BYTES_X_STASH(pbn) + BYTES_DZ_STASH(pbn))}
         per_prod = lambda c: {1: 1, 2: 3, 3: 6}[ops.nplanes(c)]
         mfma_mult = {"mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
         kern = {}

@@ -235,12 +235,16 @@ int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const f
                  lush_stream_t stream);
 /* The same in two halves (so each kernel group can be timed / overlapped separately):
  * _chain runs the fused dX chain (writes dstash + dpts); _weights runs the weight-gradient
- * GEMMs over stash x dstash.  lush_mlp_bwd == _chain followed by _weights. */
+ * GEMMs over stash x dstash.  lush_mlp_bwd == _chain followed by _weights.
+ * With a one-plane backward the feature layer (feature_linear, models/lushnerf.py:259-263: no activation) is
+ * not stashed at all: _weights accumulates G = dZv^T h_7 and s = sum dZv and derives
+ * dW_feature = Wva^T G, db_feature = Wva^T s, dW_views[:, :W] = G Wf^T + s b_f^T, db_views = s from the fp32
+ * parameters in `prm` (which it therefore needs). */
 int lush_mlp_bwd_chain(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                        const void* packed_b, const lush_mlp_params* prm, const float* draw,
                        const void* stash, void* dstash, float* dpts, lush_stream_t stream);
-int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const float* draw,
-                         const void* stash, void* dstash, const lush_mlp_grads* grads,
+int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const lush_mlp_params* prm,
+                         const float* draw, const void* stash, void* dstash, const lush_mlp_grads* grads,
                          lush_stream_t stream);
 /* d rays from d points: pts = o + d*z (models/lushnerf.py:414, 525).  dpts [R*S][8]
  * -> drays [R][11] accumulate (o: 0..2, d: 3..5, viewdir: 8..10). */

@@ -37,20 +37,23 @@ StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
     size_t off = 0;
     L.mask = off; off += sp ? al256((size_t)(L.Ppad / 32) * (n.NL + 1) * n.NRB * 16 * 8) : 0;
     for (int l = 0; l < n.NL; ++l) { L.h[l] = off; off += al256((size_t)sp * L.Ppad * n.HW * 2); }
-    L.feat = off; off += al256((size_t)sp * L.Ppad * n.HW * 2);
+    // a one-plane backward takes the feature layer's gradients from dZv^T h_{NL-1} (FeatFactorArgs): nothing kept
+    L.feat = off; off += sp >= 2 ? al256((size_t)sp * L.Ppad * n.HW * 2) : 0;
     L.hv = off;   off += al256((size_t)sp * L.Ppad * n.HV * 2);
     L.pe = off;   off += al256((size_t)pf * L.Ppad * PE_ROW * 2);
     L.total = off;
     return L;
 }
-struct DStashLayout { size_t scale, dz[NET_MAX_LAYERS], dfeat, dzv, total; };
+struct DStashLayout { size_t scale, fac, dz[NET_MAX_LAYERS], dfeat, dzv, total; };
 DStashLayout dstash_layout(const NetInfo& n, int ns, long long P) {
     DStashLayout L{};
     const long long Ppad = pad_pts(P);
     size_t off = 0;
     L.scale = off; off += 256;      // {loss scale, 1/scale, 2 work words} of the fp16 gradient chain
+    // one plane: fp32 scratch G = dZv^T h_{NL-1} [HV][HW] then s = sum dZv [HV] (FeatFactorArgs), no d_feature array
+    L.fac = off; off += ns == 1 ? al256((size_t)(n.HV * n.HW + n.HV) * 4) : 0;
     for (int l = 0; l < n.NL; ++l) { L.dz[l] = off; off += al256((size_t)ns * Ppad * n.HW * 2); }
-    L.dfeat = off; off += al256((size_t)ns * Ppad * n.HW * 2);
+    L.dfeat = off; off += ns >= 2 ? al256((size_t)ns * Ppad * n.HW * 2) : 0;
     L.dzv = off;   off += al256((size_t)ns * Ppad * n.HV * 2);
     L.total = off;
     return L;
@@ -307,7 +310,6 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.scale = gscale;
     a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / (chain ? 128 : mlp_bwd_tile(planes_b)));
     a.wpk = (const uint4*)packed_b;
-    (void)prm;
     a.draw = draw;
     a.mask = (const unsigned long long*)(sb + L.mask);
     __bf16* dzp[NET_MAX_LAYERS];
@@ -352,8 +354,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     };
     const __bf16* feat = (const __bf16*)(sb + L.feat);
     const __bf16* hv = (const __bf16*)(sb + L.hv);
-    static const bool per_layer = getenv("LUSH_DW_OLD") != nullptr;        // A/B switch: one launch per layer
-    if (planes_b == 1 && !per_layer) {
+    if (planes_b == 1) {
         // one grouped launch: every layer of the pass, the two pairs that share a dZ merged (DwJob::X2)
         DwGroup G{};
         auto job = [&](const __bf16* Z, int ldz, int n_out, const __bf16* X, int ldx, int xcol0, int k_in, float* dW,
@@ -361,7 +362,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
             DwJob& j = G.j[G.n++];
             j.Z = Z; j.ldz = ldz; j.n_out = n_out; j.X = X; j.ldx = ldx; j.xcol0 = xcol0; j.k_in = k_in;
             j.X2 = nullptr; j.ldx2 = 0; j.x2col0 = 0; j.k2_in = 0;
-            j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.wcol2 = 0; j.db = dbias;
+            j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.dW2 = dW; j.ldw2 = ldw; j.wcol2 = 0; j.db = dbias;
             return j;
         };
         for (int l = 0; l < n.NL; ++l) {
@@ -374,10 +375,15 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
                 job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], n.HW, 0, g->b[l]);
             }
         }
-        job(a.dfeat, n.HW, n.HW, H(n.NL - 1), n.HW, 0, n.HW, g->w_feat, n.HW, 0, g->b_feat);
+        // feature + views layers: G = dZv^T h_{NL-1} and s = sum dZv into scratch (launch_feat_factor below turns them
+        // into dW_feat, db_feat, dW_views[:, :HW], db_views); the gamma(d) columns of dW_views directly
+        if (!prm || !prm->w_views || !prm->w_feat || !prm->b_feat) return set_error("lush_mlp_bwd: the one-plane weight gradients need the fp32 parameters");
+        float* facG = (float*)(db + D.fac);
+        float* facS = facG + (size_t)n.HV * n.HW;
+        LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(n.HV * n.HW + n.HV) * 4, st));
         {
-            DwJob& j = job(a.dzv, n.HV, n.HV, feat, n.HW, 0, n.HW, g->w_views, n.HW + DV, 0, g->b_views);
-            j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = PE_X; j.k2_in = DV; j.wcol2 = n.HW;
+            DwJob& j = job(a.dzv, n.HV, n.HV, H(n.NL - 1), n.HW, 0, n.HW, facG, n.HW, 0, facS);
+            j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = PE_X; j.k2_in = DV; j.dW2 = g->w_views; j.ldw2 = n.HW + DV; j.wcol2 = n.HW;
         }
         const int splits = dw_splits(L.Ppad, 0);
         long long pps = (L.Ppad + splits - 1) / splits;
@@ -386,6 +392,12 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         G.pts_per_split = (int)pps;
         G.scale = gscale;
         rc = launch_dw_group(G, (int)((L.Ppad + pps - 1) / pps), x_f16, z_f16, st);
+        if (rc) return rc;
+        FeatFactorArgs F{};
+        F.G = facG; F.s = facS; F.w_views = prm->w_views; F.w_feat = prm->w_feat; F.b_feat = prm->b_feat;
+        F.g_w_feat = g->w_feat; F.g_b_feat = g->b_feat; F.g_w_views = g->w_views; F.g_b_views = g->b_views;
+        F.HW = n.HW; F.HV = n.HV; F.ldv = n.HW + DV;
+        rc = launch_feat_factor(F, st);
         if (rc) return rc;
         return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
                               net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
@@ -422,10 +434,9 @@ int lush_mlp_bwd_chain(int net, int planes_f, int planes_b, const float* rays, c
                        void* dstash, float* dpts, lush_stream_t stream) {
     return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, nullptr, dpts, stream, 1, 0);
 }
-int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const float* draw, const void* stash,
-                         void* dstash, const lush_mlp_grads* g, lush_stream_t stream) {
-    lush_mlp_params dummy{};
-    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, &dummy, draw, stash, dstash, g, nullptr, stream, 0, 1);
+int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const lush_mlp_params* prm, const float* draw,
+                         const void* stash, void* dstash, const lush_mlp_grads* g, lush_stream_t stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, prm, draw, stash, dstash, g, nullptr, stream, 0, 1);
 }
 
 }  // extern "C"

@@ -182,10 +182,20 @@ struct DwJob {
     const __bf16* Z; int ldz; int n_out;
     const __bf16* X; int ldx; int xcol0; int k_in;
     const __bf16* X2; int ldx2; int x2col0; int k2_in;     // X2 == null: none; k2_in <= 64
-    float* dW; int ldw; int wcol0; int wcol2;
+    float* dW; int ldw; int wcol0;
+    float* dW2; int ldw2; int wcol2;                        // where the X2 columns go (usually dW / ldw again)
     float* db;                                              // may be null
 };
 enum { DW_MAX_JOBS = 14 };
+// The feature layer has no activation, so with G = dZv^T h_{NL-1} [HV][HW] and s = sum dZv (what the grouped launch
+// accumulates for the one-plane backward):  dW_feat = Wva^T G,  db_feat = Wva^T s,  dW_views[:, :HW] = G Wf^T + s b_f^T,
+// db_views = s  -- neither the feature activations nor their gradients travel through HBM.
+struct FeatFactorArgs {
+    const float* G; const float* s;               // scratch of this launch (fp32, already unscaled)
+    const float* w_views; const float* w_feat; const float* b_feat;
+    float* g_w_feat; float* g_b_feat; float* g_w_views; float* g_b_views;   // accumulated into
+    int HW, HV, ldv;                              // ldv = row length of w_views (HW + gamma(d) columns)
+};
 struct DwGroup {
     DwJob j[DW_MAX_JOBS];
     int n;

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             seg_gemm<NS, RBV, CB, N::KKD, DT>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
-        if (stash_on) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.feat, A.plane_h, pt0, tid, A.stash_planes);
+        // (a one-plane backward derives the feature layer's gradients from dZv^T h_{NL-1}: FeatFactorArgs)
+        if (stash_on && A.stash_planes >= 2) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.feat, A.plane_h, pt0, tid, A.stash_planes);
         lds_barrier();
         if (views_active) {
 #pragma unroll
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                         const int o = wo * 128 + wi * 32 + acc_row(q, h);
                         const int i = v * 32 + r;
                         if (o < A.n_out) {
-                            if (v < nv2 && i < A.k2_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol2 + i, accs[v][q] * unscale);
+                            if (v < nv2 && i < A.k2_in) atomicAdd(A.dW2 + (long long)o * A.ldw2 + A.wcol2 + i, accs[v][q] * unscale);
                             if (do_bias && v == bias_blk && r == 31) atomicAdd(A.db + o, accs[v][q] * unscale);
                         }
                     }
@@ -1296,26 +1297,9 @@ size_t mlp_fwd_lds_bytes(int hw, int ns, int mt) {
 size_t mlp_bwd_lds_bytes(int hw, int ns, int mt, int nthreads) {
     return (size_t)ns * mt * hw * 2 + (size_t)mt * DPE_LD * 4 + (size_t)mt * 16 + (size_t)(nthreads / mt) * mt * 24;
 }
-// tile / wave configuration per plane count (env LUSH_FWD_CFG / LUSH_BWD_CFG = "MT,NW" override for tuning)
-struct TileCfg { int mt, nw; };
-static TileCfg cfg_from_env(const char* name, TileCfg def) {
-    const char* e = getenv(name);
-    int a = 0, b = 0;
-    if (e && sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 4 || b == 8)) return {a, b};
-    return def;
-}
-static TileCfg fwd_cfg(int ns) {
-    TileCfg c = cfg_from_env("LUSH_FWD_CFG", TileCfg{64, 8});
-    if (ns >= 2) c.mt = 64;              // activation + gamma images: 96 KB per 64 points at 2 planes
-    return c;
-}
-static TileCfg bwd_cfg(int ns) {
-    TileCfg c = cfg_from_env("LUSH_BWD_CFG", ns == 1 ? TileCfg{128, 8} : TileCfg{64, 8});
-    if (ns >= 2) c.mt = 64;              // + 51 KB fp32 d(gamma) image
-    return c;
-}
-int mlp_fwd_tile(int ns) { return fwd_cfg(ns).mt; }
-int mlp_bwd_tile(int ns) { return bwd_cfg(ns).mt; }
+// tile of the tiled kernels: 64 points, 8 waves (activation + gamma images of 3 planes fill the LDS)
+int mlp_fwd_tile(int) { return 64; }
+int mlp_bwd_tile(int) { return 64; }
 
 template <class N, int NS, int MT, int NW, bool HAS_ALPHA, int DT = DT_BF16>
 static int launch_fwd_k(const MlpFwdArgs& a, int grid, hipStream_t s) {
@@ -1326,15 +1310,6 @@ static int launch_fwd_k(const MlpFwdArgs& a, int grid, hipStream_t s) {
     LUSH_HIP(hipGetLastError());
     return 0;
 }
-template <class N, int NS, bool HAS_ALPHA>
-static int launch_fwd_t(const MlpFwdArgs& a, int grid, hipStream_t s) {
-    const TileCfg c = fwd_cfg(NS);
-    if constexpr (NS == 1) {
-        if (c.mt == 128) return launch_fwd_k<N, NS, 128, 8, HAS_ALPHA>(a, grid, s);
-    }
-    if (c.nw == 4) return launch_fwd_k<N, NS, 64, 4, HAS_ALPHA>(a, grid, s);
-    return launch_fwd_k<N, NS, 64, 8, HAS_ALPHA>(a, grid, s);
-}
 template <class N, int NS, int MT, int NW, bool HAS_ALPHA>
 static int launch_bwd_k(const MlpBwdArgs& a, int grid, hipStream_t s) {
     auto k = mlp_bwd_kernel<N, NS, MT, NW, HAS_ALPHA>;
@@ -1344,42 +1319,65 @@ static int launch_bwd_k(const MlpBwdArgs& a, int grid, hipStream_t s) {
     LUSH_HIP(hipGetLastError());
     return 0;
 }
-template <class N, int NS, bool HAS_ALPHA>
-static int launch_bwd_t(const MlpBwdArgs& a, int grid, hipStream_t s) {
-    const TileCfg c = bwd_cfg(NS);
-    if constexpr (NS == 1) {
-        if (c.mt == 128) return launch_bwd_k<N, NS, 128, 8, HAS_ALPHA>(a, grid, s);
-    }
-    return launch_bwd_k<N, NS, 64, 8, HAS_ALPHA>(a, grid, s);
-}
 
+// Only the three-plane mode (fp32-grade test mode) still runs on these tiled kernels; 1, 2 planes and fp16 run on
+// the chain kernels (lush_mlp_chain.hip).
 int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s) {
-    if (ns == PLANES_F16) {   // one fp16 plane
-        if (net == 0) return launch_fwd_k<NetNerf, 1, 64, 8, true, DT_F16>(a, grid, s);
-        return launch_fwd_k<NetNoise, 1, 64, 8, false, DT_F16>(a, grid, s);
-    }
-    if (net == 0) {
-        if (ns == 1) return launch_fwd_t<NetNerf, 1, true>(a, grid, s);
-        if (ns == 2) return launch_fwd_t<NetNerf, 2, true>(a, grid, s);
-        if (ns == 3) return launch_fwd_t<NetNerf, 3, true>(a, grid, s);
-    } else {
-        if (ns == 1) return launch_fwd_t<NetNoise, 1, false>(a, grid, s);
-        if (ns == 2) return launch_fwd_t<NetNoise, 2, false>(a, grid, s);
-        if (ns == 3) return launch_fwd_t<NetNoise, 3, false>(a, grid, s);
-    }
-    return set_error("launch_mlp_fwd: bad net/planes");
+    if (ns != 3) return set_error("launch_mlp_fwd: the tiled kernel serves 3 planes only");
+    if (net == 0) return launch_fwd_k<NetNerf, 3, 64, 8, true>(a, grid, s);
+    return launch_fwd_k<NetNoise, 3, 64, 8, false>(a, grid, s);
 }
 int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s) {
-    if (net == 0) {
-        if (ns == 1) return launch_bwd_t<NetNerf, 1, true>(a, grid, s);
-        if (ns == 2) return launch_bwd_t<NetNerf, 2, true>(a, grid, s);
-        if (ns == 3) return launch_bwd_t<NetNerf, 3, true>(a, grid, s);
-    } else {
-        if (ns == 1) return launch_bwd_t<NetNoise, 1, false>(a, grid, s);
-        if (ns == 2) return launch_bwd_t<NetNoise, 2, false>(a, grid, s);
-        if (ns == 3) return launch_bwd_t<NetNoise, 3, false>(a, grid, s);
+    if (ns != 3) return set_error("launch_mlp_bwd: the tiled kernel serves 3 planes only");
+    if (net == 0) return launch_bwd_k<NetNerf, 3, 64, 8, true>(a, grid, s);
+    return launch_bwd_k<NetNoise, 3, 64, 8, false>(a, grid, s);
+}
+
+// ---- feature-layer gradients from G = dZv^T h_{NL-1} (FeatFactorArgs) ----
+// part 0: dW_feat[i][k] += sum_v Wva[v][i] G[v][k]   (thread per (i, k), k fastest: G coalesced, Wva broadcast)
+// part 1: dW_views[v][i] += sum_k G[v][k] Wf[i][k] + s[v] b_f[i]   (thread per (v, i))
+// part 2: db_feat[i] += sum_v Wva[v][i] s[v];  db_views[v] += s[v]
+// Each output has one owner and the launch is ordered after the grouped dW launch on the same stream: plain adds.
+__global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a) {
+    const int HW = a.HW, HV = a.HV;
+    const int n0 = HW * HW, n1 = HV * HW, n2 = HW + HV;
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n0) {
+        const int i = t / HW, k = t % HW;
+        float acc = 0.f;
+        for (int v = 0; v < HV; ++v) acc += a.w_views[(long long)v * a.ldv + i] * a.G[v * HW + k];
+        a.g_w_feat[t] += acc;
+        return;
     }
-    return set_error("launch_mlp_bwd: bad net/planes");
+    t -= n0;
+    if (t < n1) {
+        const int v = t / HW, i = t % HW;
+        const float4* g4 = reinterpret_cast<const float4*>(a.G + v * HW);
+        const float4* w4 = reinterpret_cast<const float4*>(a.w_feat + (long long)i * HW);
+        float acc = 0.f;
+        for (int k = 0; k < HW / 4; ++k) {
+            const float4 g = g4[k], w = w4[k];
+            acc += g.x * w.x + g.y * w.y + g.z * w.z + g.w * w.w;
+        }
+        a.g_w_views[(long long)v * a.ldv + i] += acc + a.s[v] * a.b_feat[i];
+        return;
+    }
+    t -= n1;
+    if (t < n2) {
+        if (t < HW) {
+            float acc = 0.f;
+            for (int v = 0; v < HV; ++v) acc += a.w_views[(long long)v * a.ldv + t] * a.s[v];
+            a.g_b_feat[t] += acc;
+        } else {
+            a.g_b_views[t - HW] += a.s[t - HW];
+        }
+    }
+}
+int launch_feat_factor(const FeatFactorArgs& a, hipStream_t s) {
+    const int n = a.HW * a.HW + a.HV * a.HW + a.HW + a.HV;
+    hipLaunchKernelGGL(feat_factor_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    LUSH_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s) {

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
         f32x16 av[NRBV];
         ch_bias<NRBV>(av, biasl + N::f32_b_views, h);
-        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VA, SC::NP_VA, B_REG, false, SC::T_VA, KKH, SPK, HW>(cx, av, xin, peimg, row, tile_w,
+        // the feature activations are stashed for a multi-plane backward only (one plane: FeatFactorArgs, lush_mlp.h)
+        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VA, SC::NP_VA, B_REG, false, SC::T_VA, KKH, (SPK >= 2 ? SPK : 0), HW>(cx, av, xin, peimg, row, tile_w,
                                                                                                 A.feat + wpt * HW, A.plane_h);
         ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VB, SC::NP_VB, B_PED, false, SC::T_VB, KKH>(cx, av, xin, peimg, row);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(av, xin, mrow(NL), lane);
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
         ch_bias_g<NRBV>(acc, f32b + N::f32_b_views, h);
-        ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VA, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w, A.feat + wpt * HW, A.plane_h);
+        ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VA, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VB, B_PED, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(acc, xin, mrow(NL, 0), lane);
         // ---- rgb head ----
@@ -1004,7 +1005,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
         // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
         mask_words(mw, NL - 1, NRB);
         bw_zero<NRB>(acc);
-        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_H, B_REG, true, 0, KKH, NS, HW>::run(cx, acc, xin, nullptr, row, tile_w, A.dfeat + wpt * HW, A.plane_h);
+        // (d_feature is stashed for a multi-plane weight-gradient pass only: FeatFactorArgs, lush_mlp.h)
+        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_H, B_REG, true, 0, KKH, (NS >= 2 ? NS : 0), HW>::run(cx, acc, xin, nullptr, row, tile_w, A.dfeat + wpt * HW, A.plane_h);
         if constexpr (HAS_ALPHA) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
@@ -1250,10 +1252,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
         for (int half = 0; half < 2; ++half) {
             mask_words(mw, NL - 1, half);
             bw_zero<NRBH>(acc);
-            if (half == 0)
-                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, NS, HW>::run(cx, acc, xin, nullptr, row, tile_w, A.dfeat + wpt * HW, A.plane_h);
-            else
-                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
+            ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
             if constexpr (HAS_ALPHA) {
 #pragma unroll
                 for (int rb = 0; rb < NRBH; ++rb)
@@ -1424,15 +1423,7 @@ extern "C" int lush_debug_prof(unsigned long long* out) {
 #endif
 
 // planes 1, 2 and the fp16 code run on the chain kernel (128-point tiles); 3 planes keep mlp_fwd_kernel.
-// LUSH_FWD_OLD=1 forces the old kernel (A/B measurements).
-bool mlp_fwd_chain_enabled(int planes) {
-    static int old = -1;
-    if (old < 0) {
-        const char* e = getenv("LUSH_FWD_OLD");
-        old = (e && e[0] == '1') ? 1 : 0;
-    }
-    return !old && (planes == 1 || planes == 2 || planes == PLANES_F16);
-}
+bool mlp_fwd_chain_enabled(int planes) { return planes == 1 || planes == 2 || planes == PLANES_F16; }
 
 int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, hipStream_t s) {
     if (planes == PLANES_F16) {
@@ -1468,15 +1459,8 @@ static int launch_chain_bwd_k(const MlpBwdArgs& a, hipStream_t s) {
     return 0;
 }
 
-// 1 and 2 planes run on the chain kernel (128-point tiles); 3 planes keep mlp_bwd_kernel.  LUSH_BWD_OLD=1 forces the old kernel.
-bool mlp_bwd_chain_enabled(int planes) {
-    static int old = -1;
-    if (old < 0) {
-        const char* e = getenv("LUSH_BWD_OLD");
-        old = (e && e[0] == '1') ? 1 : 0;
-    }
-    return !old && (planes == 1 || planes == 2 || planes == PLANES_F16);
-}
+// 1 and 2 planes run on the chain kernel (128-point tiles); 3 planes keep mlp_bwd_kernel.
+bool mlp_bwd_chain_enabled(int planes) { return planes == 1 || planes == 2 || planes == PLANES_F16; }
 
 template <class N, bool HAS_ALPHA, int DT>
 static int launch_chain_bwd_half(const MlpBwdArgs& a, hipStream_t s) {

@@ -112,13 +112,13 @@ _SIGS = {
     "lush_mlp_bwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p,
                       C.POINTER(MlpParams), _p, _p], _i),
     "lush_mlp_bwd_chain": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _p], _i),
-    "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, _p, _p, _p, C.POINTER(MlpParams), _p], _i),
+    "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(MlpParams), _p], _i),
     "lush_ray_grad_reduce": ([_p, _p, _i, _i, _p, _p], _i),
     "lush_adam": ([_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p], _i),
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 3
+ABI_VERSION = 4
 # include/lush_march.h: LUSH_FAULT_*
 FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
                128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}

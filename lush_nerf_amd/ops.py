@@ -161,8 +161,8 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
     ev = TIMER.span("mlp_bwd_weights", R * S) if timed else None
     if ev:
         ev[0].record()
-    lib.call("lush_mlp_bwd_weights", net, planes_f, planes_b, R, S, lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash),
-             C.byref(gs), _stream())
+    lib.call("lush_mlp_bwd_weights", net, planes_f, planes_b, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash),
+             lib.ptr(dstash), C.byref(gs), _stream())
     if ev:
         ev[1].record()
     return ([None] * len(tensors) if sink is not None else grads), dpts

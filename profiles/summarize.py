@@ -19,7 +19,8 @@ steps = bench.get("steps", 4) + bench.get("warmup", 2)
 
 GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
-         "mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_fwd", "dw_group_kernel": "mlp_bwd_weights",
+         "mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_half_kernel<lush::NetT<256": "mlp_bwd_chain",
+         "dw_group_kernel": "mlp_bwd_weights", "feat_factor_kernel": "mlp_bwd_weights",
          "dw_gemm_kernel": "mlp_bwd_weights", "dw_gemm_dma_kernel": "mlp_bwd_weights", "head_dw_kernel": "mlp_bwd_weights"}
 
 
@@ -68,8 +69,13 @@ if per:
     evals = bench.get("config", {}).get("mlp_evals_per_step", 3932160)
     _n = lambda x: 1 if x == "h" else int(x)
     pf, pb = (_n(planes.split(",")[0]), _n(planes.split(",")[1])) if "?" not in planes else (2, 1)
-    alg = {"mlp_fwd": evals * (min(pf, pb) * 5120 + 16), "mlp_bwd_chain": evals * (pb * 4864 + 336),
-           "mlp_bwd_weights": evals * pb * 9984}
+    # bytes per MLP evaluation and plane (bench.py BYTES_X_STASH / BYTES_DZ_STASH): a one-plane backward keeps neither
+    # the feature activations nor their gradients
+    xs = lambda n: 2 * (128 + 8 * 256 + (256 if n >= 2 else 0) + 128)
+    zs = lambda n: 2 * (8 * 256 + (256 if n >= 2 else 0) + 128)
+    sp = min(pf, pb)
+    alg = {"mlp_fwd": evals * (sp * xs(sp) + 16), "mlp_bwd_chain": evals * (pb * zs(pb) + 336),
+           "mlp_bwd_weights": evals * pb * (xs(pb) + zs(pb))}
     lps = {k: v["launches_per_step"] for k, v in bench.get("kernels", {}).items()}
     for g in ("mlp_fwd", "mlp_bwd_chain", "mlp_bwd_weights"):
         fe, wr = per.get("FETCH_SIZE", {}).get(g, 0.0) / steps, per.get("WRITE_SIZE", {}).get(g, 0.0) / steps

@@ -9,7 +9,8 @@ src = os.path.join(root, "gpurun_out", f"sq_{tag}")
 KEEP = {"mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_chain_fwd_half_kernel (one fp16 plane, stash on, 2 workgroups per CU)",
         "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_chain_fwd_kernel",
         "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_chain_bwd_kernel (one loss-scaled fp16 plane)",
-        "dw_group_kernel": "dw_group_kernel (12 weight-gradient GEMMs of the fine pass in one launch)"}
+        "mlp_chain_bwd_half_kernel<lush::NetT<256": "mlp_chain_bwd_half_kernel (one loss-scaled fp16 plane, 2 workgroups per CU)",
+        "dw_group_kernel": "dw_group_kernel (the weight-gradient GEMMs of the fine pass in one launch)"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "p*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):

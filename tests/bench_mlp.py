@@ -49,7 +49,7 @@ for nf, nb in modes:
         lib.call("lush_mlp_bwd_chain", 0, nf_s, nb, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pkb), C.byref(st),
                  lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), ops._stream())
     def weights():
-        lib.call("lush_mlp_bwd_weights", 0, nf_s, nb, R, S, lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), ops._stream())
+        lib.call("lush_mlp_bwd_weights", 0, nf_s, nb, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), ops._stream())
     if "chain" in what:
         res["chain"] = timeit(chain)
     else:
