@@ -217,9 +217,11 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
         build_pack_table_half<NetNerf>(prm, T, blocks);
         rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
         if (rc) return rc;
-        build_pack_table_half_bwd<NetNerf>(prm, T, blocks);
-        rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
-        if (rc) return rc;
+        if (planes == PLANES_F16) {              // ... and the half-row backward by the fp16 chain only
+            build_pack_table_half_bwd<NetNerf>(prm, T, blocks);
+            rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+            if (rc) return rc;
+        }
     }
     return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
 }

@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
 // Same half-row scheme on the transposed weights (NetT::bwd3 stream): 64 accumulators, the first half of dZ_{l-1} is
 // masked and converted while the second half runs.  LDS per workgroup <= 80 KiB: ring 4 x 8 KiB, the per-wave stash
 // tiles (also the scratch of the final reduction), the d(gamma) image in the chain's 16-bit type (fp32 would be
-// 51 KiB), the two K<=3 head matrices.  The d(gamma) partial sums are parked in that image between their phases
+// 51 KiB; used for the loss-scaled fp16 chain only, where 11 bits match the chain's own operands), the two K<=3 head matrices.  The d(gamma) partial sums are parked in that image between their phases
 // (one extra 16-bit rounding of the skip layer's share) because the accumulators are needed for the trunk.
 constexpr int BH_DPE_LD = 104;      // 16-bit elements per point in the d(gamma) image (96 used; rows stay 16-byte aligned)
 
@@ -1497,7 +1497,8 @@ int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s
         return launch_chain_bwd_k<NetNoise, 1, false, DT_F16>(a, s);
     }
     if (net == 0) {
-        if (planes == 1 && bwd_half_enabled()) return launch_chain_bwd_half<NetNerf, true, DT_BF16>(a, s);
+        // (plain bf16 keeps the one-workgroup kernel: its d(gamma) image is fp32, the half-row kernel's is 16-bit, and
+        // 8 mantissa bits there moved the 40-step training trajectory of the (h,1) mode from 6e-4 to 1.2e-3..2.2e-3)
         if (planes == 1) return launch_chain_bwd_k<NetNerf, 1, true>(a, s);
         if (planes == 2) return launch_chain_bwd_k<NetNerf, 2, true>(a, s);
     } else {
