@@ -30,14 +30,14 @@ MACS_PER_EVAL = 593_408            # NeRF D=8 W=256 MLP, verified layer shapes (
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 # stash bytes per MLP evaluation and bf16 plane ([point][feature] rows)
-# A one-plane backward keeps neither the feature activations nor their gradients (the feature layer is linear: its
-# weight gradients follow from dZv^T h_7, FeatFactorArgs in csrc/lush_mlp.h); with 2+ planes both are stashed.
+# A 1- or 2-plane backward keeps neither the feature activations nor their gradients (the feature layer is linear: its
+# weight gradients follow from dZv^T h_7, FeatFactorArgs in csrc/lush_mlp.h); the 3-plane reference mode stashes both.
 def BYTES_X_STASH(planes):
-    return 2 * (128 + 8 * 256 + (256 if planes >= 2 else 0) + 128)    # gamma row, h_0..h_7, [feature], views hidden
+    return 2 * (128 + 8 * 256 + (256 if planes >= 3 else 0) + 128)    # gamma row, h_0..h_7, [feature], views hidden
 
 
 def BYTES_DZ_STASH(planes):
-    return 2 * (8 * 256 + (256 if planes >= 2 else 0) + 128)          # dZ_0..dZ_7, [d feature], dZ views
+    return 2 * (8 * 256 + (256 if planes >= 3 else 0) + 128)          # dZ_0..dZ_7, [d feature], dZ views
 
 
 def make_model(args_ns, device, precision, seed=0, num_img=30):

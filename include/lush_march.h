@@ -236,7 +236,7 @@ int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const f
 /* The same in two halves (so each kernel group can be timed / overlapped separately):
  * _chain runs the fused dX chain (writes dstash + dpts); _weights runs the weight-gradient
  * GEMMs over stash x dstash.  lush_mlp_bwd == _chain followed by _weights.
- * With a one-plane backward the feature layer (feature_linear, models/lushnerf.py:259-263: no activation) is
+ * With a 1- or 2-plane backward the feature layer (feature_linear, models/lushnerf.py:259-263: no activation) is
  * not stashed at all: _weights accumulates G = dZv^T h_7 and s = sum dZv and derives
  * dW_feature = Wva^T G, db_feature = Wva^T s, dW_views[:, :W] = G Wf^T + s b_f^T, db_views = s from the fp32
  * parameters in `prm` (which it therefore needs). */

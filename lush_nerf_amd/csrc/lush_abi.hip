@@ -37,8 +37,9 @@ StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
     size_t off = 0;
     L.mask = off; off += sp ? al256((size_t)(L.Ppad / 32) * (n.NL + 1) * n.NRB * 16 * 8) : 0;
     for (int l = 0; l < n.NL; ++l) { L.h[l] = off; off += al256((size_t)sp * L.Ppad * n.HW * 2); }
-    // a one-plane backward takes the feature layer's gradients from dZv^T h_{NL-1} (FeatFactorArgs): nothing kept
-    L.feat = off; off += sp >= 2 ? al256((size_t)sp * L.Ppad * n.HW * 2) : 0;
+    // the grouped weight-gradient launch (1 and 2 planes) takes the feature layer's gradients from dZv^T h_{NL-1}
+    // (FeatFactorArgs): the feature activations are kept for the three-plane reference mode only
+    L.feat = off; off += sp >= 3 ? al256((size_t)sp * L.Ppad * n.HW * 2) : 0;
     L.hv = off;   off += al256((size_t)sp * L.Ppad * n.HV * 2);
     L.pe = off;   off += al256((size_t)pf * L.Ppad * PE_ROW * 2);
     L.total = off;
@@ -50,10 +51,10 @@ DStashLayout dstash_layout(const NetInfo& n, int ns, long long P) {
     const long long Ppad = pad_pts(P);
     size_t off = 0;
     L.scale = off; off += 256;      // {loss scale, 1/scale, 2 work words} of the fp16 gradient chain
-    // one plane: fp32 scratch G = dZv^T h_{NL-1} [HV][HW] then s = sum dZv [HV] (FeatFactorArgs), no d_feature array
-    L.fac = off; off += ns == 1 ? al256((size_t)(n.HV * n.HW + n.HV) * 4) : 0;
+    // 1 and 2 planes: fp32 scratch G = dZv^T h_{NL-1} [HV][HW] then s = sum dZv [HV] (FeatFactorArgs), no d_feature array
+    L.fac = off; off += ns <= 2 ? al256((size_t)(n.HV * n.HW + n.HV) * 4) : 0;
     for (int l = 0; l < n.NL; ++l) { L.dz[l] = off; off += al256((size_t)ns * Ppad * n.HW * 2); }
-    L.dfeat = off; off += ns >= 2 ? al256((size_t)ns * Ppad * n.HW * 2) : 0;
+    L.dfeat = off; off += ns >= 3 ? al256((size_t)ns * Ppad * n.HW * 2) : 0;
     L.dzv = off;   off += al256((size_t)ns * Ppad * n.HV * 2);
     L.total = off;
     return L;
@@ -356,7 +357,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     };
     const __bf16* feat = (const __bf16*)(sb + L.feat);
     const __bf16* hv = (const __bf16*)(sb + L.hv);
-    if (planes_b == 1) {
+    if (planes_b <= 2) {
         // one grouped launch: every layer of the pass, the two pairs that share a dZ merged (DwJob::X2)
         DwGroup G{};
         auto job = [&](const __bf16* Z, int ldz, int n_out, const __bf16* X, int ldx, int xcol0, int k_in, float* dW,
@@ -364,28 +365,33 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
             DwJob& j = G.j[G.n++];
             j.Z = Z; j.ldz = ldz; j.n_out = n_out; j.X = X; j.ldx = ldx; j.xcol0 = xcol0; j.k_in = k_in;
             j.X2 = nullptr; j.ldx2 = 0; j.x2col0 = 0; j.k2_in = 0;
+            j.z_plane = (long long)L.Ppad * ldz; j.x_plane = (long long)L.Ppad * ldx; j.x2_plane = 0;
             j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.dW2 = dW; j.ldw2 = ldw; j.wcol2 = 0; j.db = dbias;
             return j;
+        };
+        auto with_pe = [&](DwJob& j, int col0, int k2, float* dW2, int ldw2, int wcol2) {
+            j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = col0; j.k2_in = k2; j.x2_plane = plane_pe;
+            j.dW2 = dW2; j.ldw2 = ldw2; j.wcol2 = wcol2;
         };
         for (int l = 0; l < n.NL; ++l) {
             if (l == 0) {
                 job(dzp[0], n.HW, n.HW, pe, PE_ROW, 0, XV, g->w[0], XV, 0, g->b[0]);
             } else if (l == n.SKIP) {
                 DwJob& j = job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], XV + n.HW, XV, g->b[l]);
-                j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = 0; j.k2_in = XV; j.wcol2 = 0;
+                with_pe(j, 0, XV, g->w[l], XV + n.HW, 0);
             } else {
                 job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], n.HW, 0, g->b[l]);
             }
         }
         // feature + views layers: G = dZv^T h_{NL-1} and s = sum dZv into scratch (launch_feat_factor below turns them
         // into dW_feat, db_feat, dW_views[:, :HW], db_views); the gamma(d) columns of dW_views directly
-        if (!prm || !prm->w_views || !prm->w_feat || !prm->b_feat) return set_error("lush_mlp_bwd: the one-plane weight gradients need the fp32 parameters");
+        if (!prm || !prm->w_views || !prm->w_feat || !prm->b_feat) return set_error("lush_mlp_bwd: the grouped weight gradients need the fp32 parameters");
         float* facG = (float*)(db + D.fac);
         float* facS = facG + (size_t)n.HV * n.HW;
         LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(n.HV * n.HW + n.HV) * 4, st));
         {
             DwJob& j = job(a.dzv, n.HV, n.HV, H(n.NL - 1), n.HW, 0, n.HW, facG, n.HW, 0, facS);
-            j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = PE_X; j.k2_in = DV; j.dW2 = g->w_views; j.ldw2 = n.HW + DV; j.wcol2 = n.HW;
+            with_pe(j, PE_X, DV, g->w_views, n.HW + DV, n.HW);
         }
         const int splits = dw_splits(L.Ppad, 0);
         long long pps = (L.Ppad + splits - 1) / splits;
@@ -393,7 +399,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         G.Ppad = (int)L.Ppad;
         G.pts_per_split = (int)pps;
         G.scale = gscale;
-        rc = launch_dw_group(G, (int)((L.Ppad + pps - 1) / pps), x_f16, z_f16, st);
+        rc = launch_dw_group(G, (int)((L.Ppad + pps - 1) / pps), planes_b, x_f16, z_f16, st);
         if (rc) return rc;
         FeatFactorArgs F{};
         F.G = facG; F.s = facS; F.w_views = prm->w_views; F.w_feat = prm->w_feat; F.b_feat = prm->b_feat;
@@ -404,6 +410,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
                               net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
     }
+    // three planes (test reference): one launch per layer
     for (int l = 0; l < n.NL && !rc; ++l) {
         const __bf16* Z = dzp[l];
         if (l == 0) {

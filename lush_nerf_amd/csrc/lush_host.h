@@ -29,7 +29,7 @@ int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
 int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s);
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);
-int launch_dw_group(const DwGroup& g, int splits, bool x_f16, bool z_f16, hipStream_t s);
+int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16, hipStream_t s);
 int launch_feat_factor(const FeatFactorArgs& a, hipStream_t s);
 int launch_grad_scale(const float* draw, long long n, float* scale, hipStream_t s);
 int launch_head_dw(int ns, bool x_f16, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,

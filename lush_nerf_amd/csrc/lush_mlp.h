@@ -182,11 +182,12 @@ struct DwJob {
     const __bf16* Z; int ldz; int n_out;
     const __bf16* X; int ldx; int xcol0; int k_in;
     const __bf16* X2; int ldx2; int x2col0; int k2_in;     // X2 == null: none; k2_in <= 64
+    long long z_plane, x_plane, x2_plane;                   // plane strides in elements (two-plane launches)
     float* dW; int ldw; int wcol0;
     float* dW2; int ldw2; int wcol2;                        // where the X2 columns go (usually dW / ldw again)
     float* db;                                              // may be null
 };
-enum { DW_MAX_JOBS = 14 };
+enum { DW_MAX_JOBS = 12 };
 // The feature layer has no activation, so with G = dZv^T h_{NL-1} [HV][HW] and s = sum dZv (what the grouped launch
 // accumulates for the one-plane backward):  dW_feat = Wva^T G,  db_feat = Wva^T s,  dW_views[:, :HW] = G Wf^T + s b_f^T,
 // db_views = s  -- neither the feature activations nor their gradients travel through HBM.

@@ -412,8 +412,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpFwdArgs A) {
             seg_gemm<NS, RBV, CB, N::KKD, DT>(av, seg(N::fwd_VB), N::NRBV, rbv0, peimg, PE_PLANE, PE_ROW * 2, PE_X / 8,
                                           lane);
         }
-        // (a one-plane backward derives the feature layer's gradients from dZv^T h_{NL-1}: FeatFactorArgs)
-        if (stash_on && A.stash_planes >= 2) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.feat, A.plane_h, pt0, tid, A.stash_planes);
+        // (a 1- or 2-plane backward derives the feature layer's gradients from dZv^T h_{NL-1}: FeatFactorArgs)
+        if (stash_on && A.stash_planes >= 3) copy_out_fast<MT, HW, NTHREADS>(actimg, ACT_PLANE, ACT_ROW, A.feat, A.plane_h, pt0, tid, A.stash_planes);
         lds_barrier();
         if (views_active) {
 #pragma unroll
@@ -852,33 +852,18 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1-plane variant with an LDS-DMA ring.  Ablation of the register-staged kernel above (MFMAs
-// removed: 6.41 vs 6.54 ms) showed it is paced by the global -> VGPR -> LDS path at ~4.1 TB/s with
-// 64 KB in flight per CU.  Here tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPRs, no
-// ds_write) into a 4-stage ring, so 3 tiles (96 KB) are in flight while one is consumed.
+// LDS-DMA ring of the grouped kernel below.  Round 1's register-staged kernel (MFMAs removed: 6.41 vs 6.54 ms) was
+// paced by the global -> VGPR -> LDS path at ~4.1 TB/s with 64 KB in flight per CU.  Here tiles go HBM -> LDS directly
+// (global_load_lds_dwordx4, no VGPRs, no ds_write) into a 4-stage ring, so 3 tiles are in flight while one is consumed.
 //  * DMA writes LDS linearly (M0 base + lane*16), so rows cannot be padded; the bank-conflict fix for
 //    the transposing reads is an XOR swizzle of the 16-byte chunk index with (row & 3) << 2, applied
 //    to the per-lane SOURCE address and again on the read (cdna_hip_programming.md rule 21).
-//  * Columns beyond the valid width are never written (lanes masked): the ring is zeroed once, and a
+//  * Columns beyond the valid width are never written (lanes masked): the ring is zeroed per job, and a
 //    given (row, position) is either always or never written, so it stays zero.
 //  * Completion: each wave waits its own DMAs with a counted s_waitcnt vmcnt(4 * younger stages),
 //    then ONE raw s_barrier per tile makes every wave's rows visible; the slot refilled after that
 //    barrier was last read in the previous iteration, which every wave has left.
-constexpr int DMA_STAGES = 4, DMA_KT = 32, DMA_ROWB = 512, DMA_OPER = DMA_KT * DMA_ROWB, DMA_STAGE = 2 * DMA_OPER;
-
-__device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int k0, int col0, int lane) {
-    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int row = k0 + 8 * (G >> 1) + q;                 // (row + 4) & 3 == row & 3: same swizzle for both reads
-    const int col = col0 + 16 * (G & 1) + 4 * p;
-    const char* a0 = tile + row * DMA_ROWB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * DMA_ROWB));
-    union { s16x4 s[2]; bf16x8 v; } u;
-    u.s[0] = lo;
-    u.s[1] = hi;
-    return u.v;
-}
+constexpr int DMA_STAGES = 4, DMA_KT = 32, DMA_ROWB = 512, DMA_OPER = DMA_KT * DMA_ROWB;
 
 // bf16 X stash (the hi plane of a 2-plane forward) -> fp16 fragment for the fp16 gradient GEMM: exact (8-bit
 // mantissa into 11 bits) unless |x| < 2^-24 (flushed; such an activation contributes nothing) or > 65504 (no
@@ -889,114 +874,6 @@ __device__ __forceinline__ bf16x8 bf16_frag_to_f16(bf16x8 v) {
     for (int e = 0; e < 8; ++e) o[e] = (_Float16)(float)v[e];
     return __builtin_bit_cast(bf16x8, o);
 }
-
-// ZF16: dZ holds loss-scaled fp16 (mlp_chain_bwd_kernel<..., DT_F16>): fp16 MFMAs, the epilogue un-scales.
-template <bool XF16, bool ZF16 = false>
-__global__ __launch_bounds__(DW_THREADS2) void dw_gemm_dma_kernel(const DwArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char tiles[];   // [4 stages][Z 32x512 B | X 32x512 B]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = w >> 2, wi = w & 3;
-    const long long p_begin = (long long)blockIdx.x * A.pts_per_split;
-    long long p_end = p_begin + A.pts_per_split;
-    if (p_end > A.Ppad) p_end = A.Ppad;
-    const int n_tiles = (int)((p_end - p_begin) / DMA_KT);
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-    const bool do_bias = A.db != nullptr;
-    f32x16 accb;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) accb[q] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = ZF16 ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
-    auto mm = [](bf16x8 a, bf16x8 b, f32x16 c) { return ZF16 ? mfma_f16(a, b, c) : mfma_bf16(a, b, c); };
-    const float unscale = ZF16 ? A.scale[1] : 1.f;
-    const bool wave_live = (wo * 128 < A.n_out) && (wi * 64 < A.k_in);
-    const bool bias_only = !wave_live && do_bias && (wo * 128 < A.n_out);
-    for (int i = tid; i < DMA_STAGES * DMA_STAGE / 16; i += DW_THREADS2)
-        reinterpret_cast<uint4*>(tiles)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)tiles;
-    // this wave's 4 DMA instructions per stage: j = 4w + i; j < 16 -> Z rows (2j, 2j+1), else X rows
-    auto issue = [&](int t) {
-        const long long p0 = p_begin + (long long)t * DMA_KT;
-        const unsigned stage = lds0 + (unsigned)((t % DMA_STAGES) * DMA_STAGE);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = w * 4 + i;
-            const int op = j >> 4, rp = j & 15;
-            const int row = 2 * rp + (lane >> 5);
-            const int gch = (lane & 31) ^ ((row & 3) << 2);            // source chunk that belongs at this position
-            const int ncols = op ? A.k_in : A.n_out;
-            const __bf16* src = op ? A.X + (p0 + row) * A.ldx + A.xcol0 + gch * 8 : A.Z + (p0 + row) * A.ldz + gch * 8;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(stage + (unsigned)(op * DMA_OPER + 2 * rp * DMA_ROWB));
-            if (gch * 8 < ncols) dma16(src, dst);
-        }
-    };
-    for (int t = 0; t < DMA_STAGES - 1 && t < n_tiles; ++t) issue(t);
-    for (int t = 0; t < n_tiles; ++t) {
-        const int younger = n_tiles - 1 - t < DMA_STAGES - 2 ? n_tiles - 1 - t : DMA_STAGES - 2;   // stages issued after tile t
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + DMA_STAGES - 1 < n_tiles) issue(t + DMA_STAGES - 1);
-        const char* zt = tiles + (t % DMA_STAGES) * DMA_STAGE;
-        const char* xt = zt + DMA_OPER;
-        if (wave_live) {
-#pragma unroll
-            for (int ks = 0; ks < DMA_KT / 16; ++ks) {
-                bf16x8 a[4][1], b[2][1];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a[u][0] = tr_frag_sw(zt, ks * 16, wo * 128 + u * 32, lane);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    b[u][0] = tr_frag_sw(xt, ks * 16, wi * 64 + u * 32, lane);
-                    if constexpr (XF16 && !ZF16) b[u][0] = f16_frag_to_bf16(b[u][0]);
-                    if constexpr (!XF16 && ZF16) b[u][0] = bf16_frag_to_f16(b[u][0]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) acc[u][v] = mm(a[u][0], b[v][0], acc[u][v]);
-                if (do_bias) {
-                    const bf16x8 sel = wi == 0 ? a[0][0] : (wi == 1 ? a[1][0] : (wi == 2 ? a[2][0] : a[3][0]));
-                    accb = mm(sel, ones, accb);
-                }
-            }
-        } else if (bias_only) {
-#pragma unroll
-            for (int ks = 0; ks < DMA_KT / 16; ++ks)
-                accb = mm(tr_frag_sw(zt, ks * 16, wo * 128 + wi * 32, lane), ones, accb);
-        }
-    }
-    const int r = lane & 31, h = lane >> 5;
-    if (do_bias && r == 0 && (wave_live || bias_only)) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int o = wo * 128 + wi * 32 + acc_row(q, h);
-            if (o < A.n_out) atomicAdd(A.db + o, accb[q] * unscale);
-        }
-    }
-    if (!wave_live) return;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int o = wo * 128 + u * 32 + acc_row(q, h);
-                const int i = wi * 64 + v * 32 + r;
-                if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[u][v][q] * unscale);
-            }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Grouped weight-gradient launch: ONE launch per network pass instead of one per layer.
@@ -1010,23 +887,12 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_dma_kernel(const DwArgs A
 // gamma(d)): the per-layer launches read that dZ twice (7 GB per step).
 //   stage = [Z 32 x 512 B | X 32 x 512 B | X2 32 x 128 B]; X2 is swizzled chunk ^= ((row >> 1) & 1) << 2 (rows of 128 B:
 //   the four rows of a transposing read then sit on four different 16-bank groups).
+// Two bf16 planes per operand (NS = 2, the strict mode): the 32 rows of a tile are [plane 0: 16 points | plane 1: the
+// same 16 points], i.e. one k-step per stage with the three plane products hi*hi + hi*lo + lo*hi; a wave's DMA rows lie
+// in one plane, so the plane offset is part of its scalar base and nothing else changes.
 constexpr int GRP_X2_ROWB = 128, GRP_X2 = DMA_KT * GRP_X2_ROWB, GRP_STAGE = 2 * DMA_OPER + GRP_X2;
 
-__device__ __forceinline__ bf16x8 tr_frag_x2(const char* tile, int k0, int col0, int lane) {
-    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int row = k0 + 8 * (G >> 1) + q;                 // ((row + 4) >> 1) & 1 == (row >> 1) & 1: same swizzle for both reads
-    const int col = col0 + 16 * (G & 1) + 4 * p;
-    const char* a0 = tile + row * GRP_X2_ROWB + ((((col >> 3) ^ (((row >> 1) & 1) << 2))) << 4) + (col & 7) * 2;
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * GRP_X2_ROWB));
-    union { s16x4 s[2]; bf16x8 v; } u;
-    u.s[0] = lo;
-    u.s[1] = hi;
-    return u.v;
-}
-
-// Byte offset (inside an operand tile) of the first of the two transposing reads of tr_frag_sw(tile, 0, col0, lane); the
+// Byte offset (inside an operand tile) of the first of the two transposing reads of a fragment at column col0; the
 // second sits 4 rows below, k-step ks 16 rows below: both plain immediates.
 __device__ __forceinline__ unsigned tr_off_sw(int col0, int lane) {
     const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -1063,7 +929,7 @@ struct GrpStream {
 
 // The streaming loop of one job, specialised on the number of 32-column X2 blocks (0: none, the side accumulator is the
 // bias alone).  Nothing in it depends on the job except through `st` (registers) and three wave-uniform flags.
-template <bool XF16, bool ZF16, int NV2>
+template <bool XF16, bool ZF16, int NV2, int NS>
 __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tiles, unsigned lds0, int n_tiles, int w, int lane,
                                            bool wave_live, bool row_live, bool x2_wave, const unsigned (&a_off)[4],
                                            const unsigned (&b_off)[2], unsigned sel_off, const unsigned (&x2_off)[2],
@@ -1097,29 +963,49 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
         const char* zt = tiles + slot * GRP_STAGE;
         const char* xt = zt + DMA_OPER;
         const char* x2t = zt + 2 * DMA_OPER;
+        // NS = 1: two k-steps of 16 points; NS = 2: one k-step, plane p of the 16 points at rows 16p..16p+15
 #pragma unroll
-        for (int ks = 0; ks < DMA_KT / 16; ++ks) {
+        for (int ks = 0; ks < (NS == 1 ? DMA_KT / 16 : 1); ++ks) {
             if (wave_live) {
-                bf16x8 a[4], b[2];
+                bf16x8 a[NS][4], b[NS][2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = tr_read<DMA_ROWB>(zt + a_off[u] + ks * 16 * DMA_ROWB);
+                for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
-                for (int v = 0; v < 2; ++v) b[v] = xcv(tr_read<DMA_ROWB>(xt + b_off[v] + ks * 16 * DMA_ROWB));
+                    for (int u = 0; u < 4; ++u) a[pl][u] = tr_read<DMA_ROWB>(zt + a_off[u] + (ks + pl) * 16 * DMA_ROWB);
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) b[pl][v] = xcv(tr_read<DMA_ROWB>(xt + b_off[v] + (ks + pl) * 16 * DMA_ROWB));
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int v = 0; v < 2; ++v) acc[u][v] = mm(a[u], b[v], acc[u][v]);
+                    for (int v = 0; v < 2; ++v) {
+                        if constexpr (NS == 2) {
+                            acc[u][v] = mm(a[1][u], b[0][v], acc[u][v]);
+                            acc[u][v] = mm(a[0][u], b[1][v], acc[u][v]);
+                        }
+                        acc[u][v] = mm(a[0][u], b[0][v], acc[u][v]);
+                    }
             }
             if (row_live) {      // (re-reads this wave's row block of Z: 2 LDS reads against keeping a copy of a[wi] alive)
-                const bf16x8 sel = tr_read<DMA_ROWB>(zt + sel_off + ks * 16 * DMA_ROWB);
+                bf16x8 sel[NS];
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) sel[pl] = tr_read<DMA_ROWB>(zt + sel_off + (ks + pl) * 16 * DMA_ROWB);
                 if constexpr (NV2 == 0) {
-                    accs[0] = mm(sel, ones, accs[0]);
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl) accs[0] = mm(sel[pl], ones, accs[0]);
                 } else {
 #pragma unroll
                     for (int v = 0; v < NV2; ++v) {
-                        bf16x8 bb = xcv(tr_read<GRP_X2_ROWB>(x2t + x2_off[v] + ks * 16 * GRP_X2_ROWB));
-                        if (v == NV2 - 1 && bias_lane) bb = ones;       // the bias rides in the block's last (padding) column
-                        accs[v] = mm(sel, bb, accs[v]);
+                        bf16x8 bb[NS];
+#pragma unroll
+                        for (int pl = 0; pl < NS; ++pl) bb[pl] = xcv(tr_read<GRP_X2_ROWB>(x2t + x2_off[v] + (ks + pl) * 16 * GRP_X2_ROWB));
+                        // the bias rides in the block's last (padding) column: ones there in plane 0, the padding's zeros in plane 1
+                        if (v == NV2 - 1 && bias_lane) bb[0] = ones;
+                        if constexpr (NS == 2) {
+                            accs[v] = mm(sel[1], bb[0], accs[v]);
+                            accs[v] = mm(sel[0], bb[1], accs[v]);
+                        }
+                        accs[v] = mm(sel[0], bb[0], accs[v]);
                     }
                 }
             }
@@ -1148,9 +1034,11 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
     }
 }
 
-template <bool XF16, bool ZF16>
+template <bool XF16, bool ZF16, int NS>
 __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) {
     static_assert((DMA_STAGES & (DMA_STAGES - 1)) == 0, "slot arithmetic uses a mask");
+    static_assert(NS == 1 || (NS == 2 && !XF16 && !ZF16), "two planes are bf16 planes");
+    constexpr int KT = DMA_KT / NS;                 // points per stage
     extern __shared__ __attribute__((aligned(16))) char tiles[];   // [4 stages][GRP_STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1158,7 +1046,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
     const long long p_begin = (long long)blockIdx.x * G.pts_per_split;
     long long p_end = p_begin + G.pts_per_split;
     if (p_end > G.Ppad) p_end = G.Ppad;
-    const int n_tiles = (int)((p_end - p_begin) / DMA_KT);
+    const int n_tiles = (int)((p_end - p_begin) / KT);
     if (n_tiles <= 0) return;
     const float unscale = ZF16 ? G.scale[1] : 1.f;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)tiles;
@@ -1200,14 +1088,15 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
             const int op = w >> 2;                      // waves 0..3 stream Z, 4..7 stream X
             const int ld = op ? A.ldx : A.ldz, ncols = op ? A.k_in : A.n_out, c0 = op ? A.xcol0 : 0;
             const __bf16* base = op ? A.X : A.Z;
-            st.src = reinterpret_cast<const char*>(base + p_begin * ld + c0);
-            st.stride = (unsigned)(DMA_KT * ld * 2);
+            const int plane = ((w & 3) * 8) / KT;       // the tile rows this wave moves, 8 (w & 3) .. + 7, lie in one plane
+            st.src = reinterpret_cast<const char*>(base + plane * (op ? A.x_plane : A.z_plane) + p_begin * ld + c0);
+            st.stride = (unsigned)(KT * ld * 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rp = (w * 4 + i) & 15;
-                const int row = 2 * rp + (lane >> 5);
+                const int row = 2 * rp + (lane >> 5);                      // tile row: plane row / KT, point row % KT
                 const int gch = (lane & 31) ^ ((row & 3) << 2);            // source chunk that belongs at this position
-                st.voff[i] = (unsigned)((row * ld + gch * 8) * 2);
+                st.voff[i] = (unsigned)(((row % KT) * ld + gch * 8) * 2);
                 st.dst[i] = (unsigned)(op * DMA_OPER + 2 * rp * DMA_ROWB);
                 st.on[i] = gch * 8 < ncols;
             }
@@ -1215,16 +1104,16 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
             if (x2_wave) {
                 const int row = 8 * w + (lane >> 3);
                 const int gch = (lane & 7) ^ (((row >> 1) & 1) << 2);
-                st.src2 = reinterpret_cast<const char*>(A.X2 + p_begin * A.ldx2 + A.x2col0);
-                st.stride2 = (unsigned)(DMA_KT * A.ldx2 * 2);
-                st.voff2 = (unsigned)((row * A.ldx2 + gch * 8) * 2);
+                st.src2 = reinterpret_cast<const char*>(A.X2 + ((8 * w) / KT) * A.x2_plane + p_begin * A.ldx2 + A.x2col0);
+                st.stride2 = (unsigned)(KT * A.ldx2 * 2);
+                st.voff2 = (unsigned)(((row % KT) * A.ldx2 + gch * 8) * 2);
                 st.dst2 = (unsigned)(2 * DMA_OPER + 8 * w * GRP_X2_ROWB);
                 st.on2 = gch * 8 < A.k2_in;
             }
         }
-        if (nv2 == 0) grp_stream<XF16, ZF16, 0>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
-        else if (nv2 == 1) grp_stream<XF16, ZF16, 1>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
-        else grp_stream<XF16, ZF16, 2>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
+        if (nv2 == 0) grp_stream<XF16, ZF16, 0, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
+        else if (nv2 == 1) grp_stream<XF16, ZF16, 1, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
+        else grp_stream<XF16, ZF16, 2, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
         if (row_live) {
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
@@ -1492,54 +1381,39 @@ static int launch_dw_t(const DwArgs& a, int splits, hipStream_t s) {
     LUSH_HIP(hipGetLastError());
     return 0;
 }
-template <bool XF16, bool ZF16 = false>
-static int launch_dw_dma(const DwArgs& a, int splits, hipStream_t s) {
-    const size_t lds = (size_t)DMA_STAGES * DMA_STAGE;
-    auto k = dw_gemm_dma_kernel<XF16, ZF16>;
-    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, a);
-    LUSH_HIP(hipGetLastError());
-    return 0;
-}
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
     if (a.n_out > DW_T || a.k_in > DW_T) return set_error("launch_dw: layer wider than 256");
-    static const bool no_dma = getenv("LUSH_DW_NODMA") != nullptr;
-    if (a.z_f16) {
-        if (ns != 1 || a.scale == nullptr) return set_error("launch_dw: the fp16 gradient GEMM is one plane and needs its loss scale");
-        return a.x_f16 ? launch_dw_dma<true, true>(a, splits, s) : launch_dw_dma<false, true>(a, splits, s);
-    }
-    if (ns == 1 && !no_dma) return a.x_f16 ? launch_dw_dma<true>(a, splits, s) : launch_dw_dma<false>(a, splits, s);
-    if (a.x_f16) {
-        if (ns != 1) return set_error("launch_dw: an fp16 stash has one plane");
-        return launch_dw_t<1, true>(a, splits, s);
-    }
-    if (ns == 1) return launch_dw_t<1>(a, splits, s);
-    if (ns == 2) return launch_dw_t<2>(a, splits, s);
-    if (ns == 3) return launch_dw_t<3>(a, splits, s);
-    return set_error("launch_dw: bad planes");
+    if (ns != 3 || a.x_f16 || a.z_f16) return set_error("launch_dw: the per-layer kernel serves 3 bf16 planes only (1 and 2 planes: launch_dw_group)");
+    return launch_dw_t<3>(a, splits, s);
 }
 
-template <bool XF16, bool ZF16>
+template <bool XF16, bool ZF16, int NS>
 static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
     const size_t lds = (size_t)DMA_STAGES * GRP_STAGE;
-    auto k = dw_group_kernel<XF16, ZF16>;
+    auto k = dw_group_kernel<XF16, ZF16, NS>;
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, g);
     LUSH_HIP(hipGetLastError());
     return 0;
 }
-// one launch for all the weight-gradient GEMMs of a network pass (one 16-bit plane per operand)
-int launch_dw_group(const DwGroup& g, int splits, bool x_f16, bool z_f16, hipStream_t s) {
+// one launch for all the weight-gradient GEMMs of a network pass (ns = 1: one 16-bit plane per operand; 2: two bf16 planes)
+int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16, hipStream_t s) {
     for (int i = 0; i < g.n; ++i) {
         const DwJob& j = g.j[i];
-        if (j.n_out > DW_T || j.k_in > DW_T || j.n_out < 8 || j.k_in < 8) return set_error("launch_dw_group: layer width out of range");
-        // the bias rides in column 31 of the last 32-column block of X2, which must therefore be a padding column
+        if (j.n_out > DW_T || j.k_in > DW_T || j.n_out < 1 || j.k_in < 8) return set_error("launch_dw_group: layer width out of range");
         if (j.db == nullptr) return set_error("launch_dw_group: every job carries its bias gradient");
+        // the bias rides in column 31 of the last 32-column block of X2, which must therefore be a padding column
         if (j.X2 && (j.k2_in < 8 || j.k2_in > 63 || j.k2_in % 32 == 0)) return set_error("launch_dw_group: second input block must leave its last column free");
     }
+    if (g.pts_per_split % DMA_KT != 0 || g.Ppad % DMA_KT != 0) return set_error("launch_dw_group: slices are whole 32-point tiles");
+    if (ns == 2) {
+        if (x_f16 || z_f16) return set_error("launch_dw_group: two planes are bf16 planes");
+        return launch_dw_group_t<false, false, 2>(g, splits, s);
+    }
+    if (ns != 1) return set_error("launch_dw_group: 1 or 2 planes");
     if (z_f16 && g.scale == nullptr) return set_error("launch_dw_group: the fp16 gradient GEMM needs its loss scale");
-    if (z_f16) return x_f16 ? launch_dw_group_t<true, true>(g, splits, s) : launch_dw_group_t<false, true>(g, splits, s);
-    return x_f16 ? launch_dw_group_t<true, false>(g, splits, s) : launch_dw_group_t<false, false>(g, splits, s);
+    if (z_f16) return x_f16 ? launch_dw_group_t<true, true, 1>(g, splits, s) : launch_dw_group_t<false, true, 1>(g, splits, s);
+    return x_f16 ? launch_dw_group_t<true, false, 1>(g, splits, s) : launch_dw_group_t<false, false, 1>(g, splits, s);
 }
 
 int launch_grad_scale(const float* draw, long long n, float* scale /* {scale, 1/scale, 2 work words} */, hipStream_t s) {

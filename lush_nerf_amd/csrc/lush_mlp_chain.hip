@@ -589,9 +589,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
         f32x16 av[NRBV];
         ch_bias<NRBV>(av, biasl + N::f32_b_views, h);
-        // the feature activations are stashed for a multi-plane backward only (one plane: FeatFactorArgs, lush_mlp.h)
-        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VA, SC::NP_VA, B_REG, false, SC::T_VA, KKH, (SPK >= 2 ? SPK : 0), HW>(cx, av, xin, peimg, row, tile_w,
-                                                                                                A.feat + wpt * HW, A.plane_h);
+        // (the feature activations are not stashed: FeatFactorArgs, lush_mlp.h)
+        ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VA, SC::NP_VA, B_REG, false, SC::T_VA, KKH>(cx, av, xin, peimg, row);
         ch_phase<N, NS, DT, HAS_ALPHA, NRBV, SC::G_VB, SC::NP_VB, B_PED, false, SC::T_VB, KKH>(cx, av, xin, peimg, row);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(av, xin, mrow(NL), lane);
         // ---- rgb head ----
@@ -1005,8 +1004,8 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
         // ---- dZ_{NL-1} = (Wfeat^T d_feature + Walpha^T d_alpha) * relu'(h_{NL-1}) ----
         mask_words(mw, NL - 1, NRB);
         bw_zero<NRB>(acc);
-        // (d_feature is stashed for a multi-plane weight-gradient pass only: FeatFactorArgs, lush_mlp.h)
-        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_H, B_REG, true, 0, KKH, (NS >= 2 ? NS : 0), HW>::run(cx, acc, xin, nullptr, row, tile_w, A.dfeat + wpt * HW, A.plane_h);
+        // (d_feature is not stashed: FeatFactorArgs, lush_mlp.h)
+        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
         if constexpr (HAS_ALPHA) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)

@@ -69,10 +69,10 @@ if per:
     evals = bench.get("config", {}).get("mlp_evals_per_step", 3932160)
     _n = lambda x: 1 if x == "h" else int(x)
     pf, pb = (_n(planes.split(",")[0]), _n(planes.split(",")[1])) if "?" not in planes else (2, 1)
-    # bytes per MLP evaluation and plane (bench.py BYTES_X_STASH / BYTES_DZ_STASH): a one-plane backward keeps neither
+    # bytes per MLP evaluation and plane (bench.py BYTES_X_STASH / BYTES_DZ_STASH): 1 and 2 planes keep neither
     # the feature activations nor their gradients
-    xs = lambda n: 2 * (128 + 8 * 256 + (256 if n >= 2 else 0) + 128)
-    zs = lambda n: 2 * (8 * 256 + (256 if n >= 2 else 0) + 128)
+    xs = lambda n: 2 * (128 + 8 * 256 + (256 if n >= 3 else 0) + 128)
+    zs = lambda n: 2 * (8 * 256 + (256 if n >= 3 else 0) + 128)
     sp = min(pf, pb)
     alg = {"mlp_fwd": evals * (sp * xs(sp) + 16), "mlp_bwd_chain": evals * (pb * zs(pb) + 336),
            "mlp_bwd_weights": evals * pb * (xs(pb) + zs(pb))}

@@ -219,11 +219,11 @@ def t_mlp_fwd():
                                                               p[f"{prefix}.pts_linears.{l}.bias"]))
                     arr = np.frombuffer(sb[off[2 + l]:off[2 + l] + ns * Ppad * HW * 2].tobytes(), dtype=np.uint16)
                     planes = (arr.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, HW)
-                    rep(f"  stash h{l} net={net} planes={ns}", planes.sum(0)[:R * S], h.detach().numpy(), stol)
+                    rep(f"  stash h{l} net={net} planes={ns}", planes[:, :R * S].sum(0), h.detach().numpy(), stol)
                     if l == 4 and D == 8:
                         h = torch.cat([x[:, :63], h], -1)
                 pe = np.frombuffer(sb[off[1]:off[1] + ns * Ppad * 128 * 2].tobytes(), dtype=np.uint16)
-                pe = (pe.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, 128).sum(0)[:R * S]
+                pe = (pe.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, 128)[:, :R * S].sum(0)   # (pad rows are never written)
                 rep(f"  stash x (cols 0..2) net={net} planes={ns}", pe[:, :3], e.numpy()[:, :3], 0.0 if ns == 3 else ptol)
                 for k in (0, 3, 6, 9):
                     rep(f"  stash sin/cos freq 2^{k} net={net} planes={ns}", pe[:, 3 + 6 * k:9 + 6 * k], e.numpy()[:, 3 + 6 * k:9 + 6 * k], ptol)
