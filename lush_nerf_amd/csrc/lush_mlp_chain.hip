@@ -431,13 +431,18 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v0 = acc[rb][8 * t + 2 * i], v1 = acc[rb][8 * t + 2 * i + 1];
-                if (RELU) {   // on the bit patterns: max_i32(bits, 0) is +0 for every negative float and -0, identity otherwise
-                              // (a float max would add a canonicalising second v_max; inline asm draws hazard nops)
+                if (RELU && NS > 1) {   // on the bit patterns: max_i32(bits, 0) is +0 for every negative float and -0, identity otherwise
+                                        // (a float max would add a canonicalising second v_max; inline asm draws hazard nops)
                     v0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v0), 0));
                     v1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v1), 0));
                 }
                 unsigned o[NS];
                 split_pair<NS, DT>(v0, v1, o);
+                if constexpr (RELU && NS == 1) {   // one plane: the same on the converted pair, one v_pk_max_i16 for two values
+                    typedef __attribute__((ext_vector_type(2))) short s16x2;   // (rounding a negative value gives a negative value or -0)
+                    const s16x2 z = {0, 0};
+                    o[0] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o[0]), z));
+                }
 #pragma unroll
                 for (int p = 0; p < NS; ++p) pk[p][i] = o[p];
             }
