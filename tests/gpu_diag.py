@@ -223,7 +223,8 @@ def t_mlp_fwd():
                     if l == 4 and D == 8:
                         h = torch.cat([x[:, :63], h], -1)
                 pe = np.frombuffer(sb[off[1]:off[1] + ns * Ppad * 128 * 2].tobytes(), dtype=np.uint16)
-                pe = (pe.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, 128)[:, :R * S].sum(0)   # (pad rows are never written)
+                with np.errstate(invalid="ignore"):      # (pad rows and the pad columns 96..127 are never written)
+                    pe = (pe.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, 128)[:, :R * S].sum(0)
                 rep(f"  stash x (cols 0..2) net={net} planes={ns}", pe[:, :3], e.numpy()[:, :3], 0.0 if ns == 3 else ptol)
                 for k in (0, 3, 6, 9):
                     rep(f"  stash sin/cos freq 2^{k} net={net} planes={ns}", pe[:, 3 + 6 * k:9 + 6 * k], e.numpy()[:, 3 + 6 * k:9 + 6 * k], ptol)

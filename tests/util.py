@@ -63,10 +63,11 @@ def stash_planes(stash, off, ns, Ppad, cols, f16=False):
     """Decode a [ns][Ppad][cols] bf16-plane (or one fp16 plane) array of the forward stash into fp32."""
     sb = stash.cpu().numpy() if isinstance(stash, torch.Tensor) else stash
     raw = sb[off:off + ns * Ppad * cols * 2].tobytes()
-    if f16:
-        return np.frombuffer(raw, dtype=np.float16).astype(np.float32).reshape(ns, Ppad, cols).sum(0)
-    arr = np.frombuffer(raw, dtype=np.uint16)
-    return (arr.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, cols).sum(0)
+    with np.errstate(invalid="ignore"):      # rows beyond the last point of a 64-point-tile kernel are never written
+        if f16:
+            return np.frombuffer(raw, dtype=np.float16).astype(np.float32).reshape(ns, Ppad, cols).sum(0)
+        arr = np.frombuffer(raw, dtype=np.uint16)
+        return (arr.astype(np.uint32) << 16).view(np.float32).reshape(ns, Ppad, cols).sum(0)
 
 
 def stash_masks(net, ns, P, stash, f16=False):
