@@ -28,7 +28,7 @@ extern "C" {
 typedef void* lush_stream_t;
 
 const char* lush_last_error(void);
-int lush_abi_version(void);
+int lush_abi_version(void);   /* 4 (round 2: lush_mlp_bwd_weights takes the fp32 parameters; fault flags; device-side draws) */
 
 /* ------------------------------------------------------------------ sampling
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.

@@ -1322,12 +1322,12 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
     t -= n0;
     if (t < n1) {
         const int v = t / HW, i = t % HW;
-        const float4* g4 = reinterpret_cast<const float4*>(a.G + v * HW);
-        const float4* w4 = reinterpret_cast<const float4*>(a.w_feat + (long long)i * HW);
+        const float4* g4 = reinterpret_cast<const float4*>(a.G + v * HW);      // scratch: 256-byte aligned
+        const float* wr = a.w_feat + (long long)i * HW;                        // a parameter: only 4-byte alignment is promised
         float acc = 0.f;
         for (int k = 0; k < HW / 4; ++k) {
-            const float4 g = g4[k], w = w4[k];
-            acc += g.x * w.x + g.y * w.y + g.z * w.z + g.w * w.w;
+            const float4 g = g4[k];
+            acc += g.x * wr[4 * k] + g.y * wr[4 * k + 1] + g.z * wr[4 * k + 2] + g.w * wr[4 * k + 3];
         }
         a.g_w_views[(long long)v * a.ldv + i] += acc + a.s[v] * a.b_feat[i];
         return;
