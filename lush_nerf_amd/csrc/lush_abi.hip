@@ -52,10 +52,11 @@ DStashLayout dstash_layout(const NetInfo& n, int ns, long long P) {
     size_t off = 0;
     L.scale = off; off += 256;      // {loss scale, 1/scale, 2 work words} of the fp16 gradient chain
     // 1 and 2 planes: fp32 scratch G = dZv^T h_{NL-1} [HV][HW] then s = sum dZv [HV] (FeatFactorArgs), no d_feature array
-    L.fac = off; off += ns <= 2 ? al256((size_t)(n.HV * n.HW + n.HV) * 4) : 0;
+    // (one plane: DZV_EXT more rows of G / s for the heads, and the [DZV_EXT][HV] + [DZV_EXT] block of the rgb job)
+    L.fac = off; off += ns <= 2 ? al256((size_t)((n.HV + DZV_EXT) * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4) : 0;
     for (int l = 0; l < n.NL; ++l) { L.dz[l] = off; off += al256((size_t)ns * Ppad * n.HW * 2); }
     L.dfeat = off; off += ns >= 3 ? al256((size_t)ns * Ppad * n.HW * 2) : 0;
-    L.dzv = off;   off += al256((size_t)ns * Ppad * n.HV * 2);
+    L.dzv = off;   off += al256((size_t)ns * Ppad * (n.HV + (ns == 1 ? DZV_EXT : 0)) * 2);   // one plane: [dZv | head gradients]
     L.total = off;
     return L;
 }
@@ -366,7 +367,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
             j.Z = Z; j.ldz = ldz; j.n_out = n_out; j.X = X; j.ldx = ldx; j.xcol0 = xcol0; j.k_in = k_in;
             j.X2 = nullptr; j.ldx2 = 0; j.x2col0 = 0; j.k2_in = 0;
             j.z_plane = (long long)L.Ppad * ldz; j.x_plane = (long long)L.Ppad * ldx; j.x2_plane = 0;
-            j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.dW2 = dW; j.ldw2 = ldw; j.wcol2 = 0; j.db = dbias;
+            j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.dW2 = dW; j.ldw2 = ldw; j.wcol2 = 0; j.n_out2 = n_out; j.db = dbias;
             return j;
         };
         auto with_pe = [&](DwJob& j, int col0, int k2, float* dW2, int ldw2, int wcol2) {
@@ -386,13 +387,22 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         // feature + views layers: G = dZv^T h_{NL-1} and s = sum dZv into scratch (launch_feat_factor below turns them
         // into dW_feat, db_feat, dW_views[:, :HW], db_views); the gamma(d) columns of dW_views directly
         if (!prm || !prm->w_views || !prm->w_feat || !prm->b_feat) return set_error("lush_mlp_bwd: the grouped weight gradients need the fp32 parameters");
-        float* facG = (float*)(db + D.fac);
-        float* facS = facG + (size_t)n.HV * n.HW;
-        LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(n.HV * n.HW + n.HV) * 4, st));
+        // One plane: the K<=3 heads ride along (DZV_EXT in lush_mlp.h) unless LUSH_HEAD_KERNEL=1 (A/B switch).
+        static const bool head_kernel = getenv("LUSH_HEAD_KERNEL") != nullptr;
+        const bool fold = planes_b == 1 && !head_kernel;
+        const bool alpha = net == 0 && g->w_alpha != nullptr && g->b_alpha != nullptr;     // (the noise net's alpha head has no gradient)
+        const int ldzv = n.HV + (planes_b == 1 ? DZV_EXT : 0), grow = n.HV + DZV_EXT;
+        float* facG = (float*)(db + D.fac);                  // [grow][HW]
+        float* facS = facG + (size_t)grow * n.HW;            // [grow]
+        float* facH = facS + grow;                           // [DZV_EXT][HV]
+        float* facSH = facH + (size_t)DZV_EXT * n.HV;        // [DZV_EXT]
+        LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(grow * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4, st));
         {
-            DwJob& j = job(a.dzv, n.HV, n.HV, H(n.NL - 1), n.HW, 0, n.HW, facG, n.HW, 0, facS);
+            DwJob& j = job(a.dzv, ldzv, fold && alpha ? grow : n.HV, H(n.NL - 1), n.HW, 0, n.HW, facG, n.HW, 0, facS);
             with_pe(j, PE_X, DV, g->w_views, n.HW + DV, n.HW);
+            j.n_out2 = n.HV;
         }
+        if (fold) job(a.dzv + n.HV, ldzv, DZV_EXT, hv, n.HV, 0, n.HV, facH, n.HV, 0, facSH);   // rgb head: Z = the extra columns, X = views hidden
         const int splits = dw_splits(L.Ppad, 0);
         long long pps = (L.Ppad + splits - 1) / splits;
         pps = (pps + 31) / 32 * 32;
@@ -402,11 +412,16 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         rc = launch_dw_group(G, (int)((L.Ppad + pps - 1) / pps), planes_b, x_f16, z_f16, st);
         if (rc) return rc;
         FeatFactorArgs F{};
-        F.G = facG; F.s = facS; F.w_views = prm->w_views; F.w_feat = prm->w_feat; F.b_feat = prm->b_feat;
+        F.G = facG; F.s = facS;
+        if (fold) {
+            F.Hd = facH; F.sH = facSH; F.g_w_rgb = g->w_rgb; F.g_b_rgb = g->b_rgb;
+            F.g_w_alpha = alpha ? g->w_alpha : nullptr; F.g_b_alpha = alpha ? g->b_alpha : nullptr;
+        }
+        F.w_views = prm->w_views; F.w_feat = prm->w_feat; F.b_feat = prm->b_feat;
         F.g_w_feat = g->w_feat; F.g_b_feat = g->b_feat; F.g_w_views = g->w_views; F.g_b_views = g->b_views;
         F.HW = n.HW; F.HV = n.HV; F.ldv = n.HW + DV;
         rc = launch_feat_factor(F, st);
-        if (rc) return rc;
+        if (rc || fold) return rc;
         return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
                               net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
     }

@@ -184,15 +184,24 @@ struct DwJob {
     const __bf16* X2; int ldx2; int x2col0; int k2_in;     // X2 == null: none; k2_in <= 64
     long long z_plane, x_plane, x2_plane;                   // plane strides in elements (two-plane launches)
     float* dW; int ldw; int wcol0;
-    float* dW2; int ldw2; int wcol2;                        // where the X2 columns go (usually dW / ldw again)
+    float* dW2; int ldw2; int wcol2; int n_out2;            // where the X2 columns go (usually dW / ldw again), rows < n_out2
     float* db;                                              // may be null
 };
 enum { DW_MAX_JOBS = 12 };
+// A one-plane dZv row carries 8 more columns: the head gradients [d_r d_g d_b d_alpha] as a hi and a lo 16-bit plane
+// (hi = round16(x), lo = round16(x - hi): 16 / 22 bits for bf16 / fp16), scaled like dZ.  The grouped weight-gradient
+// launch then gets the K<=3 heads as 8 more GEMM rows of the feature job (row HV+3 + row HV+7 = d_alpha^T h_{NL-1}) and
+// one small job (Z = these 8 columns, X = views hidden): no kernel re-reads h_{NL-1} for the alpha head.
+constexpr int DZV_EXT = 8;
+
 // The feature layer has no activation, so with G = dZv^T h_{NL-1} [HV][HW] and s = sum dZv (what the grouped launch
 // accumulates for the one-plane backward):  dW_feat = Wva^T G,  db_feat = Wva^T s,  dW_views[:, :HW] = G Wf^T + s b_f^T,
 // db_views = s  -- neither the feature activations nor their gradients travel through HBM.
 struct FeatFactorArgs {
-    const float* G; const float* s;               // scratch of this launch (fp32, already unscaled)
+    const float* G; const float* s;               // scratch of this launch (fp32, already unscaled); heads: DZV_EXT more rows
+    const float* Hd; const float* sH;             // heads folded in (or null): [DZV_EXT][HV] = (d_rgb, d_alpha planes)^T hv, and its sums
+    float* g_w_alpha; float* g_b_alpha;           // may be null (the noise net's alpha head has no gradient)
+    float* g_w_rgb; float* g_b_rgb;
     const float* w_views; const float* w_feat; const float* b_feat;
     float* g_w_feat; float* g_b_feat; float* g_w_views; float* g_b_views;   // accumulated into
     int HW, HV, ldv;                              // ldv = row length of w_views (HW + gamma(d) columns)

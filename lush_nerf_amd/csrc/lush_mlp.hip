@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                         const int o = wo * 128 + wi * 32 + acc_row(q, h);
                         const int i = v * 32 + r;
                         if (o < A.n_out) {
-                            if (v < nv2 && i < A.k2_in) atomicAdd(A.dW2 + (long long)o * A.ldw2 + A.wcol2 + i, accs[v][q] * unscale);
+                            if (v < nv2 && i < A.k2_in && o < A.n_out2) atomicAdd(A.dW2 + (long long)o * A.ldw2 + A.wcol2 + i, accs[v][q] * unscale);
                             if (v == bias_blk && r == 31) atomicAdd(A.db + o, accs[v][q] * unscale);
                         }
                     }
@@ -1307,10 +1307,11 @@ int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s
 // part 0: dW_feat[i][k] += sum_v Wva[v][i] G[v][k]   (thread per (i, k), k fastest: G coalesced, Wva broadcast)
 // part 1: dW_views[v][i] += sum_k G[v][k] Wf[i][k] + s[v] b_f[i]   (thread per (v, i))
 // part 2: db_feat[i] += sum_v Wva[v][i] s[v];  db_views[v] += s[v]
+// part 3 (heads folded into the grouped launch): dW_rgb, db_rgb, dW_alpha, db_alpha = hi-plane row + lo-plane row
 // Each output has one owner and the launch is ordered after the grouped dW launch on the same stream: plain adds.
 __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a) {
     const int HW = a.HW, HV = a.HV;
-    const int n0 = HW * HW, n1 = HV * HW, n2 = HW + HV;
+    const int n0 = HW * HW, n1 = HV * HW, n2 = HW + HV, n3 = a.Hd ? 3 * HV + 3 + HW + 1 : 0;
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t < n0) {
         const int i = t / HW, k = t % HW;
@@ -1341,10 +1342,25 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
         } else {
             a.g_b_views[t - HW] += a.s[t - HW];
         }
+        return;
+    }
+    t -= n2;
+    if (t < n3) {     // heads: hi + lo plane rows
+        if (t < 3 * HV) {
+            const int c = t / HV, j = t % HV;
+            a.g_w_rgb[t] += a.Hd[c * HV + j] + a.Hd[(4 + c) * HV + j];
+        } else if (t < 3 * HV + 3) {
+            const int c = t - 3 * HV;
+            a.g_b_rgb[c] += a.sH[c] + a.sH[4 + c];
+        } else if (a.g_w_alpha) {
+            const int k = t - 3 * HV - 3;
+            if (k < HW) a.g_w_alpha[k] += a.G[(HV + 3) * HW + k] + a.G[(HV + 7) * HW + k];
+            else a.g_b_alpha[0] += a.s[HV + 3] + a.s[HV + 7];
+        }
     }
 }
 int launch_feat_factor(const FeatFactorArgs& a, hipStream_t s) {
-    const int n = a.HW * a.HW + a.HV * a.HW + a.HW + a.HV;
+    const int n = a.HW * a.HW + a.HV * a.HW + a.HW + a.HV + (a.Hd ? 3 * a.HV + 3 + a.HW + 1 : 0);
     hipLaunchKernelGGL(feat_factor_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
     LUSH_HIP(hipGetLastError());
     return 0;

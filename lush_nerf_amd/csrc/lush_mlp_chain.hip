@@ -106,6 +106,10 @@ __device__ unsigned long long lush_prof[8];
 #define PROF_ADD(slot, t0)
 #endif
 
+// Row length of the dZv stash: one plane carries DZV_EXT more columns (lush_mlp.h)
+template <int NS, int HV>
+struct DzvLd { static constexpr int v = HV + (NS == 1 ? DZV_EXT : 0); };
+
 template <int N_>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
@@ -884,6 +888,26 @@ __device__ __forceinline__ void bw_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
         }
 }
 
+// The head gradients of this lane's point into the 8 extra columns of its dZv row (lanes 0..31): hi plane, lo plane.
+template <int DT, int LDV, int HV>
+__device__ __forceinline__ void bw_put_heads(__bf16* dzv, long long gpt, const float4& dr, int h) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    if (h == 0) {
+        unsigned a[1], b[1], c[1], d[1];
+        split_pair<1, DT>(dr.x, dr.y, a);
+        split_pair<1, DT>(dr.z, dr.w, b);
+        const float hx = elem_to_f32<DT>(__builtin_bit_cast(__bf16, (unsigned short)(a[0] & 0xFFFFu)));
+        const float hy = elem_to_f32<DT>(__builtin_bit_cast(__bf16, (unsigned short)(a[0] >> 16)));
+        const float hz = elem_to_f32<DT>(__builtin_bit_cast(__bf16, (unsigned short)(b[0] & 0xFFFFu)));
+        const float hw = elem_to_f32<DT>(__builtin_bit_cast(__bf16, (unsigned short)(b[0] >> 16)));
+        split_pair<1, DT>(dr.x - hx, dr.y - hy, c);
+        split_pair<1, DT>(dr.z - hz, dr.w - hw, d);
+        u32x4 v;
+        v[0] = a[0]; v[1] = b[0]; v[2] = c[0]; v[3] = d[0];
+        *reinterpret_cast<u32x4*>(dzv + gpt * LDV + HV) = v;
+    }
+}
+
 template <int NB>
 __device__ __forceinline__ void bw_zero(f32x16 (&acc)[NB]) {
 #pragma unroll
@@ -1000,7 +1024,9 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
         }
         // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
         bw_zero<NRB>(acc);
-        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, HV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * HV, A.plane_hv);
+        constexpr int LDV = DzvLd<NS, HV>::v;
+        if constexpr (NS == 1) bw_put_heads<DT, LDV, HV>(A.dzv, gpt, dr, h);
+        ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, LDV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * LDV, A.plane_hv);
         ChPhase<SC, NS, DT, 1, SC::G_D, SC::NP_VB, B_REG, true, 0, KKH, 0, 1>::run(cx, apd, xin, nullptr, row, nullptr, nullptr, 0);
         {
             unsigned none[NRB];
@@ -1233,11 +1259,13 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
             }
         bw_convert<NS, true, NRBV, KKH, DT>(acc, xin, mw);
         // ---- d_feature = Wva^T dZv (two row halves); d gamma(d) = Wvb^T dZv ----
+        constexpr int LDV = DzvLd<NS, HV>::v;
+        bw_put_heads<DT, LDV, HV>(A.dzv, gpt, dr, h);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             bw_zero<NRBH>(acc);
             if (half == 0)
-                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, HV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * HV, A.plane_hv);
+                ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, LDV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * LDV, A.plane_hv);
             else
                 ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, nullptr, row, nullptr, nullptr, 0);
             unsigned none[NRBH];
