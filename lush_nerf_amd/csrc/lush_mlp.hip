@@ -863,7 +863,10 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_gemm_kernel(const DwArgs A) {
 //  * Completion: each wave waits its own DMAs with a counted s_waitcnt vmcnt(4 * younger stages),
 //    then ONE raw s_barrier per tile makes every wave's rows visible; the slot refilled after that
 //    barrier was last read in the previous iteration, which every wave has left.
-constexpr int DMA_STAGES = 4, DMA_KT = 32, DMA_ROWB = 512, DMA_OPER = DMA_KT * DMA_ROWB;
+#ifndef LUSH_DW_STAGES
+#define LUSH_DW_STAGES 4
+#endif
+constexpr int DMA_STAGES = LUSH_DW_STAGES, DMA_KT = 32, DMA_ROWB = 512, DMA_OPER = DMA_KT * DMA_ROWB;
 
 // bf16 X stash (the hi plane of a 2-plane forward) -> fp16 fragment for the fp16 gradient GEMM: exact (8-bit
 // mantissa into 11 bits) unless |x| < 2^-24 (flushed; such an activation contributes nothing) or > 65504 (no
@@ -914,6 +917,9 @@ __device__ __forceinline__ bf16x8 tr_read(const char* a0) {
     u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ROWB));
     return u.v;
 }
+
+template <int N_>
+__device__ __forceinline__ void grp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 // Everything a workgroup needs of a job while it streams: wave-uniform scalars and the per-lane constants of its DMAs.
 struct GrpStream {
@@ -1012,31 +1018,33 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
         }
     };
     const bool five = NV2 > 0 && x2_wave;           // DMAs this wave issues per stage: 4, or 5 with an X2 piece
+    auto wait_younger = [&](int younger) {          // all but the DMAs of the `younger` most recent stages have landed
+        if (younger >= DMA_STAGES - 2) { if (five) grp_wait<5 * (DMA_STAGES - 2)>(); else grp_wait<4 * (DMA_STAGES - 2)>(); }
+        else if (younger == 2) { if (five) grp_wait<10>(); else grp_wait<8>(); }
+        else if (younger == 1) { if (five) grp_wait<5>(); else grp_wait<4>(); }
+        else grp_wait<0>();
+    };
     for (int t = 0; t < DMA_STAGES - 1 && t < n_tiles; ++t) issue(t);
     int slot = 0;
     const int n_steady = n_tiles - (DMA_STAGES - 1);
-    for (int t = 0; t < n_steady; ++t) {            // two younger stages in flight behind the one awaited
-        if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int t = 0; t < n_steady; ++t) {            // DMA_STAGES - 2 younger stages in flight behind the one awaited
+        if (five) grp_wait<5 * (DMA_STAGES - 2)>(); else grp_wait<4 * (DMA_STAGES - 2)>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue((slot + DMA_STAGES - 1) & (DMA_STAGES - 1));
+        issue(slot == 0 ? DMA_STAGES - 1 : slot - 1);
         compute(slot);
-        slot = (slot + 1) & (DMA_STAGES - 1);
+        slot = slot + 1 == DMA_STAGES ? 0 : slot + 1;
     }
     for (int t = n_steady < 0 ? 0 : n_steady; t < n_tiles; ++t) {     // drain: nothing left to issue
-        const int younger = n_tiles - 1 - t;
-        if (younger >= 2) { if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else if (younger == 1) { if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_younger(n_tiles - 1 - t);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         compute(slot);
-        slot = (slot + 1) & (DMA_STAGES - 1);
+        slot = slot + 1 == DMA_STAGES ? 0 : slot + 1;
     }
 }
 
 template <bool XF16, bool ZF16, int NS>
 __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) {
-    static_assert((DMA_STAGES & (DMA_STAGES - 1)) == 0, "slot arithmetic uses a mask");
+    static_assert(DMA_STAGES >= 2 && DMA_STAGES <= 4, "the drain's wait table covers up to 4 stages");
     static_assert(NS == 1 || (NS == 2 && !XF16 && !ZF16), "two planes are bf16 planes");
     constexpr int KT = DMA_KT / NS;                 // points per stage
     extern __shared__ __attribute__((aligned(16))) char tiles[];   // [4 stages][GRP_STAGE]
