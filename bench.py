@@ -435,6 +435,10 @@ def main():
                        "rays_per_gpu": a.n_rand, "marched_rays_per_gpu": a.n_rand * M, "mlp_evals_per_step": evals_step,
                        "planes_fwd": ("fp16x1" if pf == ops.PLANES_F16 else f"bf16x{pf}"), "planes_bwd": ("fp16x1 (loss-scaled)" if pb == ops.PLANES_F16 else f"bf16x{pb}"), "parallelism": f"dp{world}"},
             "step_tflops_algorithmic": round(flop_step * world * a.steps / dt / 1e12, 2),
+            # whole step against the survey's two ceilings: 3 x 1 186 816 FLOP per evaluation on the dense
+            # bf16 MFMA peak, and the stash written once + read once at 4.35 KB per evaluation on the HBM peak
+            "step_frac_mfma": round(flop_step * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "step_frac_hbm_survey_stash": round(2 * 4352 * evals_step * a.steps / dt / 1e9 / PEAK_HBM_GBS, 4),
             "kernels": kern, "roofline": roof,
         }
         notes = {"2,h": "forward 2 bf16 planes, backward ONE loss-scaled fp16 plane (11-bit operands at the bf16 backward's cost)",
