@@ -724,6 +724,13 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
 #endif
     const int row = w * 32 + n;
     char* tile_w = stage + w * 4096;
+    // Inference (no stash): the transposition tiles are free, so the fp32 bias block lives there and the per-layer
+    // bias reads are LDS reads instead of 32 L2 loads per layer and lane (made visible by the first tile's barrier).
+    static_assert(N::f32_w_rgb * 4 <= CH_NW * 4096, "the bias block must fit the stash tiles");
+    if constexpr (SPK == 0) {
+        for (int i = tid; i < N::f32_w_rgb; i += CH_NT) reinterpret_cast<float*>(stage)[i] = f32b[i];
+    }
+    const float* const bias = SPK == 0 ? reinterpret_cast<const float*>(stage) : f32b;
 
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * CH_MT;
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         // ---- layer 0: gamma(x) from the PE image, two row halves ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            ch_bias_g<NRBH>(acc, f32b + N::f32_b_trunk + half * (HW / 2), h);
+            ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk + half * (HW / 2), h);
             ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_X, B_PEX, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
             ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(0, half), lane);
         }
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         for (int l = 1; l < NL; ++l) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                ch_bias_g<NRBH>(acc, f32b + N::f32_b_trunk + l * HW + half * (HW / 2), h);
+                ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk + l * HW + half * (HW / 2), h);
                 if (l == N::SKIP)
                     ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_X, B_PEX, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
                 if (half == 0)      // the stash of h_{l-1} (this phase's B operand) rides in the first pass
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         // ---- feature head (no activation), two halves; then the alpha head, both on h_{NL-1} ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            ch_bias_g<NRBH>(acc, f32b + N::f32_b_feat + half * (HW / 2), h);
+            ch_bias_g<NRBH>(acc, bias + N::f32_b_feat + half * (HW / 2), h);
             if (half == 0)
                 ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w,
                                                                                          A.h0 + (NL - 1) * A.h_stride + wpt * HW, A.plane_h);
@@ -797,20 +804,20 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         float alpha;
         {
             f32x16 aa[1];
-            ch_bias_g<1>(aa, f32b + N::f32_b_alpha, h);
+            ch_bias_g<1>(aa, bias + N::f32_b_alpha, h);
             ChPhase<SC, NS, DT, 1, SC::G_A, SC::NP_A, B_REG, true, 0, KKH, 0, 1>::run(cx, aa, xin, peimg, row, nullptr, nullptr, 0);
             alpha = aa[0][0];
         }
 #pragma unroll
         for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
-        ch_bias_g<NRBV>(acc, f32b + N::f32_b_views, h);
+        ch_bias_g<NRBV>(acc, bias + N::f32_b_views, h);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VA, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VB, B_PED, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(acc, xin, mrow(NL, 0), lane);
         // ---- rgb head ----
         f32x16 ar[1];
-        ch_bias_g<1>(ar, f32b + N::f32_b_rgb, h);
+        ch_bias_g<1>(ar, bias + N::f32_b_rgb, h);
         if constexpr (SPK > 0) ch_stash_all<NS, SPK, N::KKV, KKH, HV>(xin, tile_w, A.hv + wpt * HV, A.plane_hv, lane);
         ChPhase<SC, NS, DT, 1, SC::G_R, SC::NP_R, B_REG, true, 0, KKH, 0, 1>::run(cx, ar, xin, peimg, row, nullptr, nullptr, 0);
         if (h == 0 && gpt < A.P) {
