@@ -409,8 +409,12 @@ __device__ __forceinline__ void ch_bias(f32x16 (&acc)[NB], const float* b, int h
 // read off the packed 16-bit planes with v_pk_min_u16 (1 instruction per 2 values instead of a
 // compare + select + or per value).  hi == 0 with acc > 0 needs acc below the smallest bf16 / half
 // of the smallest fp16 subnormal: such a unit contributes nothing either way.
-template <int NS, int DT, bool RELU, int NB, int KX, bool MASK>
-__device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin)[KX][NS], unsigned short* mrow, int lane) {
+// REBIAS: as soon as row block rb is converted its accumulators are re-initialised with the biases of the NEXT phase
+// (nextb, global memory), so those L2 loads have the rest of the conversion to land instead of stalling the first
+// MFMAs of the next phase (bias loads issued at the phase start cost 9 % of the stash-writing forward).
+template <int NS, int DT, bool RELU, int NB, int KX, bool MASK, bool REBIAS = false>
+__device__ __forceinline__ void ch_convert(f32x16 (&acc)[NB], bf16x8 (&xin)[KX][NS], unsigned short* mrow, int lane,
+                                           const float* __restrict__ nextb = nullptr) {
     static_assert(2 * NB <= KX, "activation planes do not fit");
 #ifdef LUSH_ABL_NOCONV   // timing ablation only (wrong results): register moves instead of ReLU + plane split
 #pragma unroll
@@ -465,6 +469,17 @@ __device__ __forceinline__ void ch_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
             }
         }
         if constexpr (RELU && MASK) mrow[rb * 64] = (unsigned short)word;
+        if constexpr (REBIAS) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(nextb + rb * 32 + 8 * (lane >> 5));
+            const f32x4 v0 = p[0], v1 = p[1], v2 = p[4], v3 = p[5];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[rb][e] = v0[e];
+                acc[rb][4 + e] = v1[e];
+                acc[rb][8 + e] = v2[e];
+                acc[rb][12 + e] = v3[e];
+            }
+        }
     }
 }
 
@@ -764,11 +779,17 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         bf16x8 xin[KKH][NS], xnx[KKH][NS];
         typedef bf16x8 (&half_ref)[KKH / 2][NS];
         // ---- layer 0: gamma(x) from the PE image, two row halves ----
+        // (with the stash on, every conversion re-initialises its accumulators with the next half-phase's biases:
+        // the trunk and feature biases are contiguous, half-phase j = 2 l + half reads floats 128 j .. 128 j + 127)
+        constexpr bool REB = SPK > 0;
+        static_assert(N::f32_b_feat == N::f32_b_trunk + NL * HW, "feature biases follow the trunk biases");
+        ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk, h);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk + half * (HW / 2), h);
+            if (!REB && half == 1) ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk + (HW / 2), h);
             ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_X, B_PEX, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
-            ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(0, half), lane);
+            ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on, REB>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(0, half), lane,
+                                                                   bias + N::f32_b_trunk + (half + 1) * (HW / 2));
         }
 #pragma unroll
         for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
@@ -777,7 +798,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         for (int l = 1; l < NL; ++l) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk + l * HW + half * (HW / 2), h);
+                if (!REB) ch_bias_g<NRBH>(acc, bias + N::f32_b_trunk + l * HW + half * (HW / 2), h);
                 if (l == N::SKIP)
                     ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_X, B_PEX, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
                 if (half == 0)      // the stash of h_{l-1} (this phase's B operand) rides in the first pass
@@ -785,7 +806,8 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
                                                                                              A.h0 + (l - 1) * A.h_stride + wpt * HW, A.plane_h);
                 else
                     ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
-                ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(l, half), lane);
+                ch_convert<NS, DT, true, NRBH, KKH / 2, stash_on, REB>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), mrow(l, half), lane,
+                                                                       bias + N::f32_b_trunk + (2 * l + half + 1) * (HW / 2));
             }
 #pragma unroll
             for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
@@ -793,13 +815,15 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         // ---- feature head (no activation), two halves; then the alpha head, both on h_{NL-1} ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            ch_bias_g<NRBH>(acc, bias + N::f32_b_feat + half * (HW / 2), h);
+            if (!REB) ch_bias_g<NRBH>(acc, bias + N::f32_b_feat + half * (HW / 2), h);
             if (half == 0)
                 ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w,
                                                                                          A.h0 + (NL - 1) * A.h_stride + wpt * HW, A.plane_h);
             else
                 ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
-            ch_convert<NS, DT, false, NRBH, KKH / 2, false>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), nullptr, lane);
+            static_assert(NRBV == NRBH, "the views layer re-uses the half-row accumulators");
+            ch_convert<NS, DT, false, NRBH, KKH / 2, false, REB>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), nullptr, lane,
+                                                                 half == 0 ? bias + N::f32_b_feat + HW / 2 : bias + N::f32_b_views);
         }
         float alpha;
         {
@@ -811,7 +835,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
 #pragma unroll
         for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
-        ch_bias_g<NRBV>(acc, bias + N::f32_b_views, h);
+        if (!REB) ch_bias_g<NRBV>(acc, bias + N::f32_b_views, h);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VA, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VB, B_PED, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(acc, xin, mrow(NL, 0), lane);
