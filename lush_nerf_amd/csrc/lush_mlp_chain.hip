@@ -815,15 +815,17 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         // ---- feature head (no activation), two halves; then the alpha head, both on h_{NL-1} ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (!REB) ch_bias_g<NRBH>(acc, bias + N::f32_b_feat + half * (HW / 2), h);
+            if (!REB) ch_bias_g<NRBH>(acc, bias + N::f32_b_feat + half * (HW / 2), h);      // (REB: taken during the previous conversion)
             if (half == 0)
                 ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, SPK, HW>::run(cx, acc, xin, peimg, row, tile_w,
                                                                                          A.h0 + (NL - 1) * A.h_stride + wpt * HW, A.plane_h);
             else
                 ChPhase<SC, NS, DT, NRBH, SC::GT, SC::NP_H, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
-            static_assert(NRBV == NRBH, "the views layer re-uses the half-row accumulators");
-            ch_convert<NS, DT, false, NRBH, KKH / 2, false, REB>(acc, reinterpret_cast<half_ref>(xnx[half * (KKH / 2)]), nullptr, lane,
-                                                                 half == 0 ? bias + N::f32_b_feat + HW / 2 : bias + N::f32_b_views);
+            // (the views biases are NOT taken early: the accumulators would stay live across the alpha phase and spill)
+            if (half == 0)
+                ch_convert<NS, DT, false, NRBH, KKH / 2, false, REB>(acc, reinterpret_cast<half_ref>(xnx[0]), nullptr, lane, bias + N::f32_b_feat + HW / 2);
+            else
+                ch_convert<NS, DT, false, NRBH, KKH / 2, false>(acc, reinterpret_cast<half_ref>(xnx[KKH / 2]), nullptr, lane);
         }
         float alpha;
         {
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
 #pragma unroll
         for (int k = 0; k < KKH; ++k) xin[k][0] = xnx[k][0];
         // ---- views layer: relu(Wv [feature ; gamma(d)] + b) ----
-        if (!REB) ch_bias_g<NRBV>(acc, bias + N::f32_b_views, h);
+        ch_bias_g<NRBV>(acc, bias + N::f32_b_views, h);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VA, B_REG, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ChPhase<SC, NS, DT, NRBV, SC::G_V, SC::NP_VB, B_PED, true, 0, KKH, 0, 1>::run(cx, acc, xin, peimg, row, nullptr, nullptr, 0);
         ch_convert<NS, DT, true, NRBV, KKH, stash_on>(acc, xin, mrow(NL, 0), lane);
