@@ -487,3 +487,29 @@ def test_trainer_over_rccl_two_ranks(diag, tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", port, str(script), root, str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("planes,switch", [("h,h", "LUSH_HEAD_KERNEL"), ("h,h", "LUSH_BWD_512"), ("h,h", "LUSH_FWD_512"),
+                                           ("2,2", "LUSH_HEAD_KERNEL")])
+def test_ab_switches_agree(tmp_path, planes, switch):
+    """The developer A/B switches (read once per process, hence the two child processes) select an older kernel for the
+    same work: both variants must give the same outputs and gradients up to the rounding of the mode
+    (the two forwards are bit-identical in their MFMA order; d_rgb / d_alpha travel as 16 + 16 bits with the heads folded)."""
+    import os, subprocess, sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for on in (False, True):
+        env = dict(os.environ, LUSH_PLANES=planes)
+        env.pop(switch, None)
+        if on:
+            env[switch] = "1"
+        out = str(tmp_path / f"ab_{int(on)}.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tests", "ab_worker.py"), out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    a, b = outs
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        scale = float(np.abs(b[k]).max())
+        err = float(np.abs(a[k] - b[k]).max()) / max(scale, 1e-30)
+        assert np.isfinite(a[k]).all() and err < (2e-6 if k == "raw" else 2e-3), (switch, k, err)
