@@ -37,8 +37,8 @@ def BYTES_X_STASH(planes):
 
 
 def BYTES_DZ_STASH(planes):
-    # dZ_0..dZ_7, [d feature], dZ views, [1, 2 planes: the head gradients as 8 more columns of the dZ-views rows]
-    return 2 * (8 * 256 + (256 if planes >= 3 else 0) + 128 + (8 if planes <= 2 else 0))
+    # dZ_0..dZ_7, [d feature], dZ views, [one plane: the head gradients as 8 more columns of the dZ-views rows]
+    return 2 * (8 * 256 + (256 if planes >= 3 else 0) + 128 + (8 if planes == 1 else 0))
 
 
 def make_model(args_ns, device, precision, seed=0, num_img=30):

@@ -56,7 +56,7 @@ DStashLayout dstash_layout(const NetInfo& n, int ns, long long P) {
     L.fac = off; off += ns <= 2 ? al256((size_t)((n.HV + DZV_EXT) * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4) : 0;
     for (int l = 0; l < n.NL; ++l) { L.dz[l] = off; off += al256((size_t)ns * Ppad * n.HW * 2); }
     L.dfeat = off; off += ns >= 3 ? al256((size_t)ns * Ppad * n.HW * 2) : 0;
-    L.dzv = off;   off += al256((size_t)ns * Ppad * (n.HV + (ns <= 2 ? DZV_EXT : 0)) * 2);   // 1, 2 planes: [dZv | head gradients]
+    L.dzv = off;   off += al256((size_t)ns * Ppad * (n.HV + (ns == 1 ? DZV_EXT : 0)) * 2);   // one plane: [dZv | head gradients]
     L.total = off;
     return L;
 }
@@ -322,8 +322,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.dz_stride = n.NL > 1 ? (long long)(D.dz[1] - D.dz[0]) / 2 : 0;
     a.dfeat = (__bf16*)(db + D.dfeat);
     a.dzv = (__bf16*)(db + D.dzv);
-    a.plane_h = plane_h;
-    a.plane_hv = L.Ppad * (n.HV + (planes_b <= 2 ? DZV_EXT : 0));     // plane stride of the dZv rows (1, 2 planes: + head gradients)
+    a.plane_h = plane_h; a.plane_hv = plane_hv;
     a.dpts = dpts;
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
@@ -388,11 +387,11 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         // feature + views layers: G = dZv^T h_{NL-1} and s = sum dZv into scratch (launch_feat_factor below turns them
         // into dW_feat, db_feat, dW_views[:, :HW], db_views); the gamma(d) columns of dW_views directly
         if (!prm || !prm->w_views || !prm->w_feat || !prm->b_feat) return set_error("lush_mlp_bwd: the grouped weight gradients need the fp32 parameters");
-        // The K<=3 heads ride along (DZV_EXT in lush_mlp.h) unless LUSH_HEAD_KERNEL=1 (A/B switch).
+        // One plane: the K<=3 heads ride along (DZV_EXT in lush_mlp.h) unless LUSH_HEAD_KERNEL=1 (A/B switch).
         static const bool head_kernel = getenv("LUSH_HEAD_KERNEL") != nullptr;
-        const bool fold = !head_kernel;
+        const bool fold = planes_b == 1 && !head_kernel;
         const bool alpha = net == 0 && g->w_alpha != nullptr && g->b_alpha != nullptr;     // (the noise net's alpha head has no gradient)
-        const int ldzv = n.HV + DZV_EXT, grow = n.HV + DZV_EXT;
+        const int ldzv = n.HV + (planes_b == 1 ? DZV_EXT : 0), grow = n.HV + DZV_EXT;
         float* facG = (float*)(db + D.fac);                  // [grow][HW]
         float* facS = facG + (size_t)grow * n.HW;            // [grow]
         float* facH = facS + grow;                           // [DZV_EXT][HV]

@@ -188,9 +188,8 @@ struct DwJob {
     float* db;                                              // may be null
 };
 enum { DW_MAX_JOBS = 12 };
-// A dZv row of a 1- or 2-plane backward carries 8 more columns: the head gradients [d_r d_g d_b d_alpha] as a hi and a lo
-// 16-bit value (hi = round16(x), lo = round16(x - hi): 16 / 22 bits for bf16 / fp16), scaled like dZ -- one plane: columns
-// [hi | lo]; two planes: [hi | 0] in plane 0, [lo | 0] in plane 1.  The grouped weight-gradient
+// A one-plane dZv row carries 8 more columns: the head gradients [d_r d_g d_b d_alpha] as a hi and a lo 16-bit plane
+// (hi = round16(x), lo = round16(x - hi): 16 / 22 bits for bf16 / fp16), scaled like dZ.  The grouped weight-gradient
 // launch then gets the K<=3 heads as 8 more GEMM rows of the feature job (row HV+3 + row HV+7 = d_alpha^T h_{NL-1}) and
 // one small job (Z = these 8 columns, X = views hidden): no kernel re-reads h_{NL-1} for the alpha head.
 constexpr int DZV_EXT = 8;

@@ -108,7 +108,7 @@ __device__ unsigned long long lush_prof[8];
 
 // Row length of the dZv stash: one plane carries DZV_EXT more columns (lush_mlp.h)
 template <int NS, int HV>
-struct DzvLd { static constexpr int v = HV + (NS <= 2 ? DZV_EXT : 0); };
+struct DzvLd { static constexpr int v = HV + (NS == 1 ? DZV_EXT : 0); };
 
 template <int N_>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
@@ -921,10 +921,9 @@ __device__ __forceinline__ void bw_convert(const f32x16 (&acc)[NB], bf16x8 (&xin
         }
 }
 
-// The head gradients of this lane's point into the 8 extra columns of its dZv row (lanes 0..31).  One plane: columns
-// [hi (4) | lo (4)]; two planes: plane 0 gets [hi (4) | 0], plane 1 [lo (4) | 0] -- the same rows of G either way.
-template <int NS, int DT, int LDV, int HV>
-__device__ __forceinline__ void bw_put_heads(__bf16* dzv, long long plane, long long gpt, const float4& dr, int h) {
+// The head gradients of this lane's point into the 8 extra columns of its dZv row (lanes 0..31): hi plane, lo plane.
+template <int DT, int LDV, int HV>
+__device__ __forceinline__ void bw_put_heads(__bf16* dzv, long long gpt, const float4& dr, int h) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     if (h == 0) {
         unsigned a[1], b[1], c[1], d[1];
@@ -937,15 +936,8 @@ __device__ __forceinline__ void bw_put_heads(__bf16* dzv, long long plane, long 
         split_pair<1, DT>(dr.x - hx, dr.y - hy, c);
         split_pair<1, DT>(dr.z - hz, dr.w - hw, d);
         u32x4 v;
-        if constexpr (NS == 1) {
-            v[0] = a[0]; v[1] = b[0]; v[2] = c[0]; v[3] = d[0];
-            *reinterpret_cast<u32x4*>(dzv + gpt * LDV + HV) = v;
-        } else {
-            v[0] = a[0]; v[1] = b[0]; v[2] = 0u; v[3] = 0u;
-            *reinterpret_cast<u32x4*>(dzv + gpt * LDV + HV) = v;
-            v[0] = c[0]; v[1] = d[0];
-            *reinterpret_cast<u32x4*>(dzv + plane + gpt * LDV + HV) = v;
-        }
+        v[0] = a[0]; v[1] = b[0]; v[2] = c[0]; v[3] = d[0];
+        *reinterpret_cast<u32x4*>(dzv + gpt * LDV + HV) = v;
     }
 }
 
@@ -1066,7 +1058,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
         // ---- d_feature = Wva^T dZv ; d gamma(d) = Wvb^T dZv ----
         bw_zero<NRB>(acc);
         constexpr int LDV = DzvLd<NS, HV>::v;
-        bw_put_heads<NS, DT, LDV, HV>(A.dzv, A.plane_hv, gpt, dr, h);
+        if constexpr (NS == 1) bw_put_heads<DT, LDV, HV>(A.dzv, gpt, dr, h);
         ChPhase<SC, NS, DT, NRB, SC::GT, SC::NP_VA, B_REG, true, 0, KKH, NS, LDV>::run(cx, acc, xin, nullptr, row, tile_w, A.dzv + wpt * LDV, A.plane_hv);
         ChPhase<SC, NS, DT, 1, SC::G_D, SC::NP_VB, B_REG, true, 0, KKH, 0, 1>::run(cx, apd, xin, nullptr, row, nullptr, nullptr, 0);
         {
@@ -1301,7 +1293,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
         bw_convert<NS, true, NRBV, KKH, DT>(acc, xin, mw);
         // ---- d_feature = Wva^T dZv (two row halves); d gamma(d) = Wvb^T dZv ----
         constexpr int LDV = DzvLd<NS, HV>::v;
-        bw_put_heads<NS, DT, LDV, HV>(A.dzv, A.plane_hv, gpt, dr, h);
+        bw_put_heads<DT, LDV, HV>(A.dzv, gpt, dr, h);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             bw_zero<NRBH>(acc);

@@ -72,7 +72,7 @@ if per:
     # bytes per MLP evaluation and plane (bench.py BYTES_X_STASH / BYTES_DZ_STASH): 1 and 2 planes keep neither
     # the feature activations nor their gradients
     xs = lambda n: 2 * (128 + 8 * 256 + (256 if n >= 3 else 0) + 128)
-    zs = lambda n: 2 * (8 * 256 + (256 if n >= 3 else 0) + 128 + (8 if n <= 2 else 0))
+    zs = lambda n: 2 * (8 * 256 + (256 if n >= 3 else 0) + 128 + (8 if n == 1 else 0))
     sp = min(pf, pb)
     alg = {"mlp_fwd": evals * (sp * xs(sp) + 16), "mlp_bwd_chain": evals * (pb * zs(pb) + 336),
            "mlp_bwd_weights": evals * pb * (xs(pb) + zs(pb))}
