@@ -296,10 +296,12 @@ def test_large_configs_spot_parity(diag, cfg):
 # Band of the training-trajectory test: max over the 40 steps of |loss_gpu - loss_reference| / loss_reference.
 # The reference run is fp32 torch on CPU; rays and draws are fresh every step, so the curve tests the composed
 # forward + backward + Adam + lr path, and errors compound through the parameters.
-# Measured (round 2): (2,2) 6.0e-4, (2,1) 4.5e-4, (h,1) 7.0e-4 -- the same for every mode, the fp32-equivalent one
-# included: what accumulates over the steps is the chaotic sensitivity of the run itself (flipped ReLU kinks, Adam's
-# m / sqrt(v) in its first steps), not the arithmetic of a mode.  One band for all.
-TRAJ_BAND = {"2,2": 2e-3, "2,1": 2e-3, "h,1": 2e-3, "2,h": 2e-3, "h,h": 2e-3}
+# Measured (round 2, final kernels, 6 repetitions x 5 modes on one box): typically 2e-4 .. 8e-4 in EVERY mode, the
+# fp32-equivalent (2,2) included, with outliers of 1.2e-3 ((2,2)) and 1.8e-3 ((2,1)) -- the repetitions differ only in the
+# order of the fp32 atomics of the weight-gradient sums, and what accumulates over the steps is the chaotic sensitivity
+# of the run itself (flipped ReLU kinks, Adam's m / sqrt(v) in its first steps), not the arithmetic of a mode.
+# One band for all: twice the largest deviation seen in those 30 runs.
+TRAJ_BAND = {"2,2": 4e-3, "2,1": 4e-3, "h,1": 4e-3, "2,h": 4e-3, "h,h": 4e-3}
 
 
 @pytest.mark.parametrize("planes", ["2,2", "2,1", "h,1", "2,h", "h,h"])
