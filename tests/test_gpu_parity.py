@@ -511,7 +511,13 @@ def test_ab_switches_agree(tmp_path, planes, switch):
         outs.append(np.load(out))
     a, b = outs
     assert set(a.files) == set(b.files)
+    worst = {}
     for k in a.files:
         scale = float(np.abs(b[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / max(scale, 1e-30)
+        worst["raw" if k == "raw" else "grads"] = max(worst.get("raw" if k == "raw" else "grads", 0.0), err)
+        # measured: outputs identical (the variants keep the MFMA order); gradients 9e-7 (heads folded, fp16 hi + lo),
+        # 1.3e-5 (heads folded, bf16 hi + lo), 1.6e-6 (forward variants: atomics order), 3.4e-4 (the 256-register
+        # backward chain keeps d(gamma) in 16 bits)
         assert np.isfinite(a[k]).all() and err < (2e-6 if k == "raw" else 2e-3), (switch, k, err)
+    print(f"A/B {switch} ({planes}): outputs differ by {worst.get('raw', 0.0):.1e}, gradients by {worst.get('grads', 0.0):.1e}")
