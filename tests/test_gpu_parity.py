@@ -68,8 +68,9 @@ def test_fp16_forward_mode(diag, monkeypatch):
 
 @pytest.mark.parametrize("planes", ["2,1", "2,h", "h,h"])
 def test_headline_mode_end_to_end(diag, planes, monkeypatch):
-    """The bench headline mode (2 planes forward, bf16 backward): forward within 1e-4 of the reference
-    fixtures, end-to-end gradients inside the same 3e-2 gate as the fp32-equivalent mode."""
+    """The faster precision modes -- (h,h) is the bench headline, (2,1) was round 1's, (2,h) is the fall-back -- on the
+    reference fixtures: forward within 1e-4, gradients through gpu_diag's mode-aware gates (masked oracle primary,
+    fixture secondary)."""
     monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes(planes))
     for section in ("t_march_e2e", "t_train_e2e", "t_consistency", "t_lindisp_white"):
         diag.RESULTS.clear()
@@ -100,12 +101,21 @@ def _model(Ni=64, precision=(2, 2), seed=0):
     return net.to("cuda:0")
 
 
-def test_full_size_properties(diag):
-    """BASELINE config 2 size (20 480 marched rays, 64+64): size-independent properties."""
+# Render-output bounds per forward mode at full size: 1e-4 is the north-star bound for both; depth_map as everywhere 1e-3.
+FULL_SIZE_MODES = ["2,2", "h,h"]
+
+
+@pytest.mark.parametrize("planes", FULL_SIZE_MODES)
+def test_full_size_properties(diag, planes):
+    """BASELINE config 2 size (20 480 marched rays, 64+64): size-independent properties and 64 rays against the oracle,
+    in the fp32-equivalent mode AND in the bench headline mode (h,h): 20 480 fine tiles = 40 per persistent workgroup of
+    mlp_chain_fwd_half_kernel (80 for the 512-register kernel), i.e. the weight stream wraps into the next tile as it
+    does in bench.py -- both the inference variant (no stash) and the stash-writing variant the training step runs."""
     from lush_nerf_amd import ops, synth
     from oracle import lush_oracle as O
     dev = torch.device("cuda:0")
-    net = _model().train()
+    prec = ops.Precision(*ops.parse_planes(planes))
+    net = _model(precision=(prec.fwd, prec.bwd)).train()
     R, Ns, Ni = 20480, 64, 64
     b = synth.ray_batch(R, 5)
     batch = ops.PackRays.apply(torch.from_numpy(b["rays"]).to(dev), synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF,
@@ -113,12 +123,19 @@ def test_full_size_properties(diag):
     d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(R, Ns, Ni, 5).items()}
     kw = dict(N_samples=Ns, N_importance=Ni, perturb=1., raw_noise_std=1., retraw=True)
     with torch.no_grad():
-        cfg = ops.MarchCfg(Ns, Ni, 1., 1., precision=ops.Precision(2, 2), want_grad=False)
+        cfg = ops.MarchCfg(Ns, Ni, 1., 1., precision=prec, want_grad=False)
         coarse, fine = net.mlp_coarse.tensors(), net.mlp_fine.tensors()
         out = ops.March.apply(batch, cfg, d, len(coarse), *coarse, *fine)
         out2 = ops.March.apply(batch, cfg, d, len(coarse), *coarse, *fine)
     rgb, depth, acc, density, raw, weights, z = out[:7]
     assert all(torch.equal(a, b_) for a, b_ in zip(out, out2)), "forward is not deterministic"
+    # the stash-writing variant of the same kernels (what a training step launches) gives the same render outputs
+    cfg_g = ops.MarchCfg(Ns, Ni, 1., 1., precision=prec, want_grad=True)
+    out_g = ops.March.apply(batch, cfg_g, d, len(coarse), *coarse, *fine)
+    assert out_g[0].requires_grad, "the training variant did not run"
+    for i in (0, 1, 2, 7):
+        assert diag.util.relerr(out_g[i].detach(), out[i]) < 1e-6, (i, diag.util.relerr(out_g[i].detach(), out[i]))
+    del out_g
     assert bool((z[:, 1:] >= z[:, :-1]).all()), "merged z_vals not sorted"
     # the last sample has alpha == 1, so the weights telescope to exactly 1 (models/lushnerf.py:338-341)
     assert float((acc - 1).abs().max()) < 2e-6
@@ -138,8 +155,23 @@ def test_full_size_properties(diag):
     with torch.no_grad():
         ref = O.render_rays(p, batch[idx].cpu(), Ns, perturb=1., N_importance=Ni, raw_noise_std=1.,
                             draws={k: v[idx].cpu() for k, v in d.items()}, with_noise_branch=False)
-    assert diag.util.relerr(rgb[idx], ref["rgb_map"]) < 1e-4
-    assert diag.util.relerr(out[7][idx], ref["rgb0"]) < 1e-4
+    e_rgb, e_rgb0, e_depth = (diag.util.relerr(rgb[idx], ref["rgb_map"]), diag.util.relerr(out[7][idx], ref["rgb0"]),
+                              diag.util.relerr(depth[idx], ref["depth_map"]))
+    print(f"full size {planes}: rgb_map {e_rgb:.2e}, rgb0 {e_rgb0:.2e}, depth_map {e_depth:.2e} (64 rays against the oracle)")
+    assert e_rgb < 1e-4 and e_rgb0 < 1e-4 and e_depth < 1e-3
+
+
+@pytest.mark.parametrize("planes", ["2,2", "h,h"])
+def test_bench_regime_against_the_oracle(diag, planes, monkeypatch):
+    """N_rand 512, blur kernel on (2 560 marched rays, 327 680 fine points = 2 560 tiles): every persistent workgroup of
+    the forward / backward chain kernels walks >= 5 tiles (10 for the 512-register kernels) and dw_group_kernel many
+    slices -- the regime of the bench -- with outputs at 1e-4 against the fp32 oracle and per-tensor gradients against
+    the masked float64 oracle (gpu_diag.masked_grad_check with the existing floors)."""
+    monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes(planes))
+    diag.RESULTS.clear()
+    diag.t_train_bench_regime()
+    bad = [(n, e, t) for n, e, t, ok in diag.RESULTS if not ok]
+    assert diag.RESULTS and not bad, bad[:8]
 
 
 def _canon(net):
@@ -243,9 +275,12 @@ def test_eval_path_runs(diag):
     assert bool(torch.isfinite(rgbs).all()) and bool(torch.isfinite(noise).all())
 
 
-def test_full_size_backward_is_additive_over_rays(diag):
+@pytest.mark.parametrize("planes,tol", [("2,2", 2e-4), ("h,h", 2e-4)])
+def test_full_size_backward_is_additive_over_rays(diag, planes, tol):
     """BASELINE config 2 size, backward: the loss is a mean over rays, so the gradient of the full 4096-ray batch
-    equals the sum of the gradients of its two halves (each weighted by its share) -- fp32-equivalent mode, 2e-4."""
+    equals the sum of the gradients of its two halves (each weighted by its share), 2e-4 in the fp32-equivalent mode and
+    in the headline mode (h,h) alike: the halves run the same 16-bit arithmetic per point, their loss scales are powers
+    of two, and only the order of the fp32 sums differs (measured 4.6e-7 / 4.0e-7)."""
     from lush_nerf_amd import synth
     from lush_nerf_amd.trainer import Trainer
     dev = torch.device("cuda:0")
@@ -254,33 +289,37 @@ def test_full_size_backward_is_additive_over_rays(diag):
     d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(n * 5, 64, 64, 4).items()}
     res = []
     for mb in (0, 2048):
-        net = _model(seed=6, precision=(2, 2))
+        net = _model(seed=6, precision=diag.ops.parse_planes(planes))
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64, micro_batch=mb)
         loss = tr.step(b, 0, draws=d)
         res.append((float(loss), tr.flat.grad.clone()))
         assert tr.faults() == 0
         del tr, net
     assert abs(res[0][0] - res[1][0]) < 2e-6 * max(1.0, abs(res[0][0]))
-    assert diag.util.relerr(res[1][1], res[0][1]) < 2e-4
+    e_all = diag.util.relerr(res[1][1], res[0][1])
     a, bb = 0, 2 * 595844          # per segment too: coarse + fine MLP block
-    assert diag.util.relerr(res[1][1][a:bb], res[0][1][a:bb]) < 2e-4
+    e_mlp = diag.util.relerr(res[1][1][a:bb], res[0][1][a:bb])
+    print(f"additivity {planes}: whole gradient {e_all:.2e}, MLP segment {e_mlp:.2e} (tol {tol:.0e})")
+    assert e_all < tol and e_mlp < tol
 
 
+@pytest.mark.parametrize("planes", FULL_SIZE_MODES)
 @pytest.mark.parametrize("cfg", ["C3", "C5"])
-def test_large_configs_spot_parity(diag, cfg):
+def test_large_configs_spot_parity(diag, cfg, planes):
     """BASELINE configs 3 / 5 at their full marched-ray counts (40 960 rays 64+64; 81 920 rays 128+128), forward:
-    64 rays spread over the batch against the oracle at 1e-4, as for config 2."""
+    64 rays spread over the batch against the oracle at 1e-4, as for config 2, in the fp32-equivalent and the headline mode."""
     from lush_nerf_amd import ops, synth
     from oracle import lush_oracle as O
     dev = torch.device("cuda:0")
     R, Ns, Ni = (40960, 64, 64) if cfg == "C3" else (81920, 128, 128)
-    net = _model(Ni=Ni).train()
+    prec = ops.Precision(*ops.parse_planes(planes))
+    net = _model(Ni=Ni, precision=(prec.fwd, prec.bwd)).train()
     b = synth.ray_batch(R, 15)
     batch = ops.PackRays.apply(torch.from_numpy(b["rays"]).to(dev), synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, True, 0., 1.)
     idx = torch.arange(0, R, R // 64)[:64]
     d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(R, Ns, Ni, 15).items()}
     with torch.no_grad():
-        cfgm = ops.MarchCfg(Ns, Ni, 1., 1., precision=ops.Precision(2, 2), want_grad=False)
+        cfgm = ops.MarchCfg(Ns, Ni, 1., 1., precision=prec, want_grad=False)
         coarse, fine = net.mlp_coarse.tensors(), net.mlp_fine.tensors()
         out = ops.March.apply(batch, cfgm, d, len(coarse), *coarse, *fine)
         p = {k: v.detach().cpu() for k, v in _canon(net).items()}
