@@ -28,7 +28,7 @@ extern "C" {
 typedef void* lush_stream_t;
 
 const char* lush_last_error(void);
-int lush_abi_version(void);   /* 4 (round 2: lush_mlp_bwd_weights takes the fp32 parameters; fault flags; device-side draws) */
+int lush_abi_version(void);   /* 5 (round 3: explicit kernel-variant argument instead of environment switches) */
 
 /* ------------------------------------------------------------------ sampling
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
@@ -210,6 +210,14 @@ typedef struct {
     float *w_feat, *b_feat, *w_alpha, *b_alpha, *w_views, *b_views, *w_rgb, *b_rgb;
 } lush_mlp_grads;
 
+/* Kernel variants.  The MLP entry points take a bit mask `variant`; 0 is the product's choice (what bench.py
+ * measures).  The bits select an older kernel for the same work, for A/B timing and for the tests that check
+ * that the variants agree; nothing in the library reads the environment. */
+#define LUSH_VARIANT_FWD_HALF 1      /* one fp16 plane forward: two 128-point workgroups per CU (round 2) instead of 64 points per wave */
+#define LUSH_VARIANT_FWD_512 2       /* ... the one-workgroup 32-points-per-wave kernel (round 1) */
+#define LUSH_VARIANT_BWD_512 4       /* fp16 gradient chain: the one-workgroup kernel instead of two workgroups per CU */
+#define LUSH_VARIANT_HEAD_KERNEL 8   /* one-plane backward: K<=3 head gradients by their own kernel instead of riding in the grouped launch */
+
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream);
@@ -223,7 +231,7 @@ size_t lush_mlp_dstash_bytes(int net, int planes, long long P);
  * many planes as it computes with) plus the encoded inputs.  stash_planes = 0 is inference:
  * the buffer is then only the kernel's gamma-row workspace and nothing is kept for a backward. */
 int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
-                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash,
+                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash, int variant,
                  lush_stream_t stream);
 /* Backward: draw [R*S][4] -> parameter gradients (accumulate, fp32 atomics) and
  * dpts [R*S][8] = d/dpoint (3), 0, d/dviewdir (3), 0 (overwritten).
@@ -231,7 +239,7 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
  * plane count of the backward arithmetic; packed_b holds planes_b planes. */
 int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                  const void* packed_b, const lush_mlp_params* prm, const float* draw,
-                 const void* stash, void* dstash, const lush_mlp_grads* grads, float* dpts,
+                 const void* stash, void* dstash, const lush_mlp_grads* grads, float* dpts, int variant,
                  lush_stream_t stream);
 /* The same in two halves (so each kernel group can be timed / overlapped separately):
  * _chain runs the fused dX chain (writes dstash + dpts); _weights runs the weight-gradient
@@ -242,10 +250,10 @@ int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const f
  * parameters in `prm` (which it therefore needs). */
 int lush_mlp_bwd_chain(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                        const void* packed_b, const lush_mlp_params* prm, const float* draw,
-                       const void* stash, void* dstash, float* dpts, lush_stream_t stream);
+                       const void* stash, void* dstash, float* dpts, int variant, lush_stream_t stream);
 int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const lush_mlp_params* prm,
                          const float* draw, const void* stash, void* dstash, const lush_mlp_grads* grads,
-                         lush_stream_t stream);
+                         int variant, lush_stream_t stream);
 /* d rays from d points: pts = o + d*z (models/lushnerf.py:414, 525).  dpts [R*S][8]
  * -> drays [R][11] accumulate (o: 0..2, d: 3..5, viewdir: 8..10). */
 int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays,

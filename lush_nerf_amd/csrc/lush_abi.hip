@@ -3,8 +3,6 @@
 #include "lush_host.h"
 #include "../../include/lush_march.h"
 
-#include <cstdlib>
-
 using namespace lush;
 
 namespace {
@@ -20,7 +18,7 @@ bool net_info(int net, NetInfo& o) {
 // plane code -> number of 16-bit planes stored / computed with
 inline bool code_ok(int c) { return (c >= 1 && c <= 3) || c == PLANES_F16; }
 inline int nplanes(int c) { return c == PLANES_F16 ? 1 : c; }
-constexpr int PT_PAD = 128;     // point arrays are padded to the largest tile
+constexpr int PT_PAD = 256;     // point arrays are padded to the largest tile (mlp_wide_fwd_kernel: 256 points)
 inline long long pad_pts(long long P) { return (P + PT_PAD - 1) / PT_PAD * PT_PAD; }
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -28,7 +26,7 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // `sp` (stash) planes, then the gamma rows with `pf` (forward) planes -- the forward itself
 // re-reads them.  sp == 0 (inference) leaves only the gamma rows.
 struct StashLayout {
-    size_t mask, pe, h[NET_MAX_LAYERS], feat, hv, total;
+    size_t mask, mask_dummy, pe, h[NET_MAX_LAYERS], feat, hv, total;
     long long Ppad;
 };
 StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
@@ -36,6 +34,7 @@ StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
     L.Ppad = pad_pts(P);
     size_t off = 0;
     L.mask = off; off += sp ? al256((size_t)(L.Ppad / 32) * (n.NL + 1) * n.NRB * 16 * 8) : 0;
+    L.mask_dummy = off; off += sp ? 4096 : 0;
     for (int l = 0; l < n.NL; ++l) { L.h[l] = off; off += al256((size_t)sp * L.Ppad * n.HW * 2); }
     // the grouped weight-gradient launch (1 and 2 planes) takes the feature layer's gradients from dZv^T h_{NL-1}
     // (FeatFactorArgs): the feature activations are kept for the three-plane reference mode only
@@ -157,6 +156,44 @@ void build_pack_table_half(const lush_mlp_params* p, PackTable& T, int& blocks) 
     add(p->w_rgb, HV, 3, HV, 1, N::KKV);
 }
 
+// Fourth forward copy (NetT::fwd4_base): quarter-row stream of mlp_wide_fwd_kernel (lush_mlp_wide.hip).
+template <class N>
+void build_pack_table_wide(const lush_mlp_params* p, PackTable& T, int& blocks) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP, QR = 64;
+    T.n = 0;
+    blocks = 0;
+    int dst = N::fwd4_base;
+    auto add = [&](const float* src, int sr, int rows, int cols, int nrb, int kk) {
+        PackJob& j = T.j[T.n++];
+        j.src = src; j.sr = sr; j.sk = 1; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk; j.perm = 1;
+        j.dst_entry = dst; j.first_block = blocks;
+        blocks += nrb * kk;
+        dst += nrb * kk;
+    };
+    const int XV = PE_X_VALID, DV = PE_D_VALID;
+    for (int q = 0; q < HW / QR; ++q) add(p->w[0] + (long long)q * QR * XV, XV, QR, XV, 2, N::KKX);
+    for (int l = 1; l < NL; ++l) {
+        const int ld = l == SK ? XV + HW : HW;
+        for (int q = 0; q < HW / QR; ++q) {
+            const float* w = p->w[l] + (long long)q * QR * ld;
+            if (l == SK) {
+                add(w, ld, QR, XV, 2, N::KKX);
+                add(w + XV, ld, QR, HW, 2, N::KKH);
+            } else {
+                add(w, ld, QR, HW, 2, N::KKH);
+            }
+        }
+    }
+    for (int q = 0; q < HW / QR; ++q) add(p->w_feat + (long long)q * QR * HW, HW, QR, HW, 2, N::KKH);
+    add(p->w_alpha, HW, 1, HW, 1, N::KKH);
+    for (int q = 0; q < HV / QR; ++q) {
+        const float* w = p->w_views + (long long)q * QR * (HW + DV);
+        add(w + HW, HW + DV, QR, DV, 2, 4);          // gamma(d) part, K zero-padded to 4 k-blocks (one position)
+        add(w, HW + DV, QR, HW, 2, N::KKH);
+    }
+    add(p->w_rgb, HV, 3, HV, 1, N::KKV);
+}
+
 // Third transposed copy (NetT::bwd3_base): half-row stream of mlp_chain_bwd_half_kernel.
 template <class N>
 void build_pack_table_half_bwd(const lush_mlp_params* p, PackTable& T, int& blocks) {
@@ -223,6 +260,10 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
             build_pack_table_half_bwd<NetNerf>(prm, T, blocks);
             rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
             if (rc) return rc;
+            build_pack_table_wide<NetNerf>(prm, T, blocks);     // quarter-row forward stream (64 points per wave)
+            if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
+            rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+            if (rc) return rc;
         }
     }
     return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
@@ -253,7 +294,7 @@ int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
 }
 
 int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
-                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash, lush_stream_t stream) {
+                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash, int variant, lush_stream_t stream) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_fwd: bad net");
     if (!code_ok(planes)) return set_error("lush_mlp_fwd: planes must be 1..3 or 17 (one fp16 plane)");
@@ -275,20 +316,21 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     a.write_stash = stash_planes > 0;
     char* b = (char*)stash;
     a.mask = (unsigned long long*)(b + L.mask);
+    a.mask_dummy = b + L.mask_dummy;
     a.pe = (__bf16*)(b + L.pe);
     a.h0 = (__bf16*)(b + L.h[0]);
     a.h_stride = n.NL > 1 ? (long long)(L.h[1] - L.h[0]) / 2 : 0;
     a.feat = (__bf16*)(b + L.feat);
     a.hv = (__bf16*)(b + L.hv);
     a.plane_pe = L.Ppad * PE_ROW; a.plane_h = L.Ppad * n.HW; a.plane_hv = L.Ppad * n.HV;
-    if (chain) return launch_mlp_chain_fwd(net, planes, a, (hipStream_t)stream);
+    if (chain) return launch_mlp_chain_fwd(net, planes, a, variant, (hipStream_t)stream);
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
 }
 
 static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                         const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
-                        void* dstash, const lush_mlp_grads* g, float* dpts, lush_stream_t stream, int do_chain,
+                        void* dstash, const lush_mlp_grads* g, float* dpts, int variant, lush_stream_t stream, int do_chain,
                         int do_weights) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
@@ -332,7 +374,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         rc = launch_grad_scale(draw, P * 4, gscale, st);
         if (rc) return rc;
     }
-    if (do_chain) rc = chain ? launch_mlp_chain_bwd(net, code_b, a, st) : launch_mlp_bwd(net, planes_b, a, grid, st);
+    if (do_chain) rc = chain ? launch_mlp_chain_bwd(net, code_b, a, variant, st) : launch_mlp_bwd(net, planes_b, a, grid, st);
     if (rc || !do_weights) return rc;
 
     const __bf16* pe = (const __bf16*)(sb + L.pe);
@@ -387,9 +429,8 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         // feature + views layers: G = dZv^T h_{NL-1} and s = sum dZv into scratch (launch_feat_factor below turns them
         // into dW_feat, db_feat, dW_views[:, :HW], db_views); the gamma(d) columns of dW_views directly
         if (!prm || !prm->w_views || !prm->w_feat || !prm->b_feat) return set_error("lush_mlp_bwd: the grouped weight gradients need the fp32 parameters");
-        // One plane: the K<=3 heads ride along (DZV_EXT in lush_mlp.h) unless LUSH_HEAD_KERNEL=1 (A/B switch).
-        static const bool head_kernel = getenv("LUSH_HEAD_KERNEL") != nullptr;
-        const bool fold = planes_b == 1 && !head_kernel;
+        // One plane: the K<=3 heads ride along (DZV_EXT in lush_mlp.h) unless the caller asks for the separate head kernel.
+        const bool fold = planes_b == 1 && !(variant & LUSH_VARIANT_HEAD_KERNEL);
         const bool alpha = net == 0 && g->w_alpha != nullptr && g->b_alpha != nullptr;     // (the noise net's alpha head has no gradient)
         const int ldzv = n.HV + (planes_b == 1 ? DZV_EXT : 0), grow = n.HV + DZV_EXT;
         float* facG = (float*)(db + D.fac);                  // [grow][HW]
@@ -450,17 +491,17 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
 
 int lush_mlp_bwd(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                  const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
-                 void* dstash, const lush_mlp_grads* g, float* dpts, lush_stream_t stream) {
-    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, g, dpts, stream, 1, 1);
+                 void* dstash, const lush_mlp_grads* g, float* dpts, int variant, lush_stream_t stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, g, dpts, variant, stream, 1, 1);
 }
 int lush_mlp_bwd_chain(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                        const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
-                       void* dstash, float* dpts, lush_stream_t stream) {
-    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, nullptr, dpts, stream, 1, 0);
+                       void* dstash, float* dpts, int variant, lush_stream_t stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw, stash, dstash, nullptr, dpts, variant, stream, 1, 0);
 }
 int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, const lush_mlp_params* prm, const float* draw,
-                         const void* stash, void* dstash, const lush_mlp_grads* g, lush_stream_t stream) {
-    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, prm, draw, stash, dstash, g, nullptr, stream, 0, 1);
+                         const void* stash, void* dstash, const lush_mlp_grads* g, int variant, lush_stream_t stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, prm, draw, stash, dstash, g, nullptr, variant, stream, 0, 1);
 }
 
 }  // extern "C"

@@ -23,9 +23,12 @@ int launch_mlp_fwd(int net, int ns, const MlpFwdArgs& a, int grid, hipStream_t s
 int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s);
 // lush_mlp_chain.hip
 bool mlp_fwd_chain_enabled(int planes);
-int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, hipStream_t s);
+int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, int variant, hipStream_t s);
 bool mlp_bwd_chain_enabled(int planes);
-int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s);
+int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, int variant, hipStream_t s);
+// lush_mlp_wide.hip
+size_t mlp_wide_fwd_lds_bytes();
+int launch_mlp_wide_fwd(const MlpFwdArgs& a, hipStream_t s);
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
 int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s);
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);

@@ -15,6 +15,8 @@ namespace lush {
 
 enum { NET_MAX_LAYERS = 8 };
 enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
+// kernel-variant bits of the C ABI (include/lush_march.h LUSH_VARIANT_*): 0 = the product's choice
+enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8 };
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -70,7 +72,14 @@ struct NetT {
     // ... and of the transposed segments for mlp_chain_bwd_half_kernel: [VAT h0 | VAT h1 | VBT | FEATT h0 | h1 |
     // per layer NL-1..1: (skip: a) b h0 | b h1 | L0T], every full-width segment in 128-row halves
     static constexpr int bwd3_base = fwd3_base + fwd_END;
-    static constexpr int total_entries = bwd3_base + (bwd_END - bwd_VAT);
+    // fourth copy of the forward segments for the 64-points-per-wave kernel (mlp_wide_fwd_kernel, lush_mlp_wide.hip):
+    // rows permuted by chain_row(); every full-width segment cut into 64-row QUARTERS, the stream runs quarter by quarter
+    // (skip layer: [x part | h part] per quarter) in positions of 8 fragments = 4 k-blocks x 2 row blocks (k-block major);
+    // ALPHA 2 positions of 8 k-blocks; the views layer per 64-row quarter [gamma(d) part, K zero-padded to 4 k-blocks |
+    // feature part]; RGB one position of 8 k-blocks.
+    static constexpr int fwd4_base = bwd3_base + (bwd_END - bwd_VAT);
+    static constexpr int fwd4_len = fwd_ALPHA + KKH + (HV / 64) * (8 + 2 * KKH) + KKV;
+    static constexpr int total_entries = fwd4_base + fwd4_len;
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
 
@@ -137,6 +146,7 @@ struct MlpFwdArgs {
     const uint4* wpk;              // packed fragments (NS planes) followed by the fp32 block
     float* raw;                    // [P][4]
     unsigned long long* mask;      // ReLU sign bits, see mask_index()
+    void* mask_dummy;              // 4 KiB nobody reads: where a kernel that runs the feature layer through its ReLU-layer code sends the words
     __bf16* pe;                    // [NS][Ppad][PE_ROW]
     __bf16* h0;                    // h_l = h0 + l*h_stride, each [sp][Ppad][HW]
     __bf16* feat;                  // [sp][Ppad][HW]

@@ -1453,20 +1453,14 @@ static int launch_chain_half_sp(const MlpFwdArgs& a, hipStream_t s) {
     return 0;
 }
 
-static bool fwd_half_enabled() {
-    static int off = -1;
-    if (off < 0) {
-        const char* e = getenv("LUSH_FWD_512");       // A/B switch: 1 = the one-wave-per-SIMD kernel for one plane too
-        off = (e && e[0] == '1') ? 1 : 0;
-    }
-    return !off;
-}
-
 template <class N, int NS, bool HAS_ALPHA, int DT>
-static int launch_chain_k(const MlpFwdArgs& a, hipStream_t s) {
+static int launch_chain_k(const MlpFwdArgs& a, int variant, hipStream_t s) {
     const int sp = a.write_stash ? a.stash_planes : 0;
     if constexpr (NS == 1 && HAS_ALPHA && N::HW == 256) {
-        if (fwd_half_enabled()) {
+        if constexpr (DT == DT_F16) {      // the headline forward: 64 points per wave unless a variant bit selects an older kernel
+            if (!(variant & (LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512)) && sp <= 1) return launch_mlp_wide_fwd(a, s);
+        }
+        if (!(variant & LUSH_VARIANT_FWD_512)) {
             if (sp == 0) return launch_chain_half_sp<N, DT, 0>(a, s);
             if (sp == 1) return launch_chain_half_sp<N, DT, 1>(a, s);
         }
@@ -1490,17 +1484,17 @@ extern "C" int lush_debug_prof(unsigned long long* out) {
 // planes 1, 2 and the fp16 code run on the chain kernel (128-point tiles); 3 planes keep mlp_fwd_kernel.
 bool mlp_fwd_chain_enabled(int planes) { return planes == 1 || planes == 2 || planes == PLANES_F16; }
 
-int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, hipStream_t s) {
+int launch_mlp_chain_fwd(int net, int planes, const MlpFwdArgs& a, int variant, hipStream_t s) {
     if (planes == PLANES_F16) {
-        if (net == 0) return launch_chain_k<NetNerf, 1, true, DT_F16>(a, s);
-        return launch_chain_k<NetNoise, 1, false, DT_F16>(a, s);
+        if (net == 0) return launch_chain_k<NetNerf, 1, true, DT_F16>(a, variant, s);
+        return launch_chain_k<NetNoise, 1, false, DT_F16>(a, variant, s);
     }
     if (net == 0) {
-        if (planes == 1) return launch_chain_k<NetNerf, 1, true, DT_BF16>(a, s);
-        if (planes == 2) return launch_chain_k<NetNerf, 2, true, DT_BF16>(a, s);
+        if (planes == 1) return launch_chain_k<NetNerf, 1, true, DT_BF16>(a, variant, s);
+        if (planes == 2) return launch_chain_k<NetNerf, 2, true, DT_BF16>(a, variant, s);
     } else {
-        if (planes == 1) return launch_chain_k<NetNoise, 1, false, DT_BF16>(a, s);
-        if (planes == 2) return launch_chain_k<NetNoise, 2, false, DT_BF16>(a, s);
+        if (planes == 1) return launch_chain_k<NetNoise, 1, false, DT_BF16>(a, variant, s);
+        if (planes == 2) return launch_chain_k<NetNoise, 2, false, DT_BF16>(a, variant, s);
     }
     return set_error("launch_mlp_chain_fwd: bad net/planes");
 }
@@ -1546,19 +1540,10 @@ static int launch_chain_bwd_half(const MlpBwdArgs& a, hipStream_t s) {
     return 0;
 }
 
-static bool bwd_half_enabled() {
-    static int off = -1;
-    if (off < 0) {
-        const char* e = getenv("LUSH_BWD_512");       // A/B switch: 1 = the one-wave-per-SIMD backward chain for one plane too
-        off = (e && e[0] == '1') ? 1 : 0;
-    }
-    return !off;
-}
-
-int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, hipStream_t s) {
+int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, int variant, hipStream_t s) {
     if (planes == PLANES_F16) {
         if (a.scale == nullptr) return set_error("launch_mlp_chain_bwd: the fp16 chain needs its loss scale");
-        if (net == 0) return bwd_half_enabled() ? launch_chain_bwd_half<NetNerf, true, DT_F16>(a, s) : launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
+        if (net == 0) return !(variant & LUSH_VARIANT_BWD_512) ? launch_chain_bwd_half<NetNerf, true, DT_F16>(a, s) : launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
         return launch_chain_bwd_k<NetNoise, 1, false, DT_F16>(a, s);
     }
     if (net == 0) {

@@ -1,0 +1,761 @@
+// lush-march: one-plane forward chain of the 8x256 NeRF MLP with 64 points per wave (gfx950 / MI355X).
+//
+// Same function as mlp_chain_fwd_half_kernel (lush_mlp_chain.hip; utils/run_lushnerf_helpers.py:334-344, 394-423 and
+// NeRFAll.mlpforward, models/lushnerf.py:234-266), other organisation.  What the SQ counters of the 32-points-per-wave
+// kernels say (profiles/r02_sq_counters.md): 8 non-MFMA instructions per MFMA, matrix pipe 46-48 % busy per SIMD --
+// every weight fragment read from LDS feeds ONE MFMA, and the accumulator -> next-operand conversion (ReLU, 16-bit
+// pack, decision bits) runs between the GEMM phases, where only a second workgroup on the CU can hide it.  Here:
+//
+//   * a wave owns 64 points = TWO 32-column MFMA blocks: every A fragment (weights, from the LDS ring) feeds two
+//     MFMAs, so fragment reads, ring DMAs, barriers and slot arithmetic per MFMA halve;
+//   * a layer is computed in four QUARTER passes of 64 output rows (2 row blocks x 2 column blocks = 64 accumulator
+//     registers) over the whole K, with two accumulator sets in ping-pong: while set X accumulates pass p, the VALU
+//     converts set Y (pass p-1) into k-blocks of the NEXT layer's B operand as fillers between X's MFMAs, then
+//     re-loads Y with the biases of pass p+1.  The conversion therefore hides behind MFMAs of the same wave: one
+//     workgroup per CU, one wave per SIMD, 512 registers (two B-operand buffers of 128 registers in ping-pong by layer);
+//   * the weight stream (NetT::fwd4 copy) is uniform: positions of 8 KiB = 4 k-blocks x 2 row blocks, one s_barrier
+//     per position ("mid-step", as in the chain kernels), 16 MFMAs per wave between two barriers.
+//
+// The schedule is written out: after every MFMA a fixed list of fillers (fragment read / DMA, conversion units of the
+// pending accumulator set, bias re-loads, stash traffic), pinned with sched_barrier.
+#include "lush_common.h"
+#include "lush_mlp.h"
+#include "lush_mlp_dev.h"
+#include "lush_host.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+
+namespace lush {
+
+constexpr int WD_MT = 256, WD_NT = 256;     // points per tile, threads (4 waves x 64 points)
+#ifndef LUSH_WD_S
+#define LUSH_WD_S 6
+#endif
+constexpr int WD_S = LUSH_WD_S;             // ring slots = prefetch distance in positions
+constexpr int WD_SLOT = 8192;               // one position: 8 one-KiB fragments
+// PE image of this kernel: rows of 272 bytes (256 + 16), no XOR swizzle.  A 16-lane group of a ds_read_b128 reads 16 different
+// rows at the same chunk: with a pitch of 68 dwords their 4-dword pieces fall on 16 disjoint bank quads (68 r mod 64 = 4 r), so
+// the fragment reads are conflict-free AND chunk offsets are immediates of the instruction (one address register per column
+// block instead of one per (column block, chunk): the XOR-swizzled addresses were hoisted out of the tile loop and spilled).
+constexpr int WD_PE_PITCH = PE_ROW * 2 + 16;
+constexpr int WD_PE_PLANE = WD_MT * WD_PE_PITCH;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+enum { WB_NONE = 0, WB_REG = 1, WB_PEX = 2, WB_PED = 3 };     // B operand of a position
+enum { WC_NONE = 0, WC_ACT = 1, WC_ALPHA = 2 };               // what happens to the pending accumulator set
+
+constexpr int WD_WRAP = NetNerf::fwd4_len / 8;      // stream positions per tile
+static_assert(NetNerf::fwd4_len % 8 == 0, "the quarter-row stream is whole positions");
+
+// compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E-1>)
+template <int B, int E, class F>
+__device__ __forceinline__ void wd_unroll(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        wd_unroll<B + 1, E>(f);
+    }
+}
+
+// Two 1-KiB LDS-DMA pieces 4 KiB apart under one M0 save/restore with ONE per-lane offset register: two scalar bases.
+// (The instruction's immediate offset is no help: measured in rounds 2 and 3, it does not move the global address of an
+// LDS-DMA -- `offset:-4096` from base + 4096 fetched the wrong bytes.)
+__device__ __forceinline__ void wd_dma_pair(const void* sbase0, const void* sbase1, unsigned voff, unsigned lds0, unsigned lds1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase0), "s"(sbase1), "s"(lds0), "s"(lds1) : "memory");
+}
+
+template <int N_>
+__device__ __forceinline__ void wd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+#ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back through lush_debug_prof_wide
+__device__ unsigned long long lush_prof_wide[16];
+#define WPROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define WPROF_ADD(slot, t0) cx.prof[slot] += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define WPROF_T(var)
+#define WPROF_ADD(slot, t0)
+#endif
+
+struct WdCtx {
+#ifdef LUSH_PROF
+    unsigned long long prof[16];
+#endif
+    const char* ring;      // LDS ring (generic pointer, fragment reads)
+    unsigned ring_lds;     // its LDS byte address (DMA destination)
+    const char* gbase;     // stream base (wave-uniform)
+    unsigned slot_off;     // ring byte offset of the slot being consumed (0, SLOT, .. (S-1) SLOT)
+    unsigned fetch_off;    // stream byte offset of the position the next refill DMA fetches (consumed position + S, wrapped)
+    unsigned dma_base;     // ring_lds + 1 KiB x wave: LDS address of this wave's first DMA piece in slot 0
+    int w, lane;
+    unsigned voff;         // per-lane byte offset of this wave's first DMA piece of a position (the second: + 4 KiB)
+};
+
+// Per-pass runtime parameters (wave-uniform unless noted)
+struct WdRt {
+    bool pre_on;                   // the leading gamma(x) position runs (skip layer)
+    unsigned clamp;                // packed lower clamp of the conversion: 0 = ReLU, 0x80008000 = identity
+    char* mptr[2];                 // uniform: decision words of (column block c, row block 0 of the pending set's layer); + 2 lane
+    unsigned lane2;                // per-lane: 2 * lane
+    const float* nextbias;         // LDS: biases of the rows the pending set accumulates next (row block 0, +8h applied by the reader)
+    char* tile;                    // this wave's 4-KiB LDS transposition tile
+    char* srows;                   // stash rows of this wave's first point (uniform), bytes
+    unsigned soff[2];              // per-lane: byte offset of (row n of column block c, 8 hh) in a [point][HW] stash array
+    unsigned srow_off;             // per-lane: byte offset of (row lane>>3, 16-byte chunk lane&7) in a [point][HW] stash array
+};
+
+// ---------------------------------------------------------------------------------------------
+// conversion of a pending accumulator set, cut into filler units
+// ---------------------------------------------------------------------------------------------
+// Block b = rbl * 2 + c (row block major: the k-blocks of the next operand complete in k order).  Per block and
+// t = 0, 1 (accumulators 8t .. 8t+7 -> k-block KB0 + 2 rbl + t): four pairs i, each one unit [convert, clamp] and,
+// with MASK, one unit [zero flags of the pair, merged into the block's decision word]: the flags are
+// v_pk_sub_u16(1, x) with clamp (1 where the clamped 16-bit value is zero) and a v_dot2_u32_u16 against the constant
+// {1 << bit, 2 << bit} puts both at their place of the word (bit q = accumulator q: mask_index() layout), inverted
+// once at the end.  VALU units per block: MASK ? 16 : 8.
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+struct WdConvTmp {
+    unsigned o[4];       // the packed pairs of the current (block, t)
+    unsigned m;          // zero flags of the current block, merged
+    unsigned word[4];    // decision word per block
+};
+
+template <int NRQP, int KB0, bool MASK>
+struct WdConv {
+    static constexpr int NB = 2 * NRQP;
+    static constexpr int UPT = MASK ? 8 : 4;          // units per (block, t)
+    static constexpr int UPB = 2 * UPT;
+    static constexpr int NVU = NB * UPB;
+
+    // unit u of (block, t): MASK: cvt0 cvt1 msk0 cvt2 msk1 cvt3 msk2 msk3 ; else cvt0..3
+    template <int K>
+    static __device__ __forceinline__ void unit(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], WdConvTmp& t, unsigned clamp) {
+        constexpr int b = K / UPB, r = K % UPB, tt = r / UPT, u = r % UPT;
+        constexpr int c = b % 2, rbl = b / 2, kb = KB0 + 2 * rbl + tt;
+        constexpr int kind = MASK ? ((u == 0 || u == 1 || u == 3 || u == 5) ? 0 : 1) : 0;
+        constexpr int i = MASK ? (kind == 0 ? (u == 0 ? 0 : (u == 1 ? 1 : (u == 3 ? 2 : 3))) : (u == 2 ? 0 : (u == 4 ? 1 : (u == 6 ? 2 : 3)))) : u;
+        if constexpr (kind == 0) {
+            unsigned o[1];
+            split_pair<1, DT_F16>(pend[c][rbl][8 * tt + 2 * i], pend[c][rbl][8 * tt + 2 * i + 1], o);
+            const s16x2 lo = __builtin_bit_cast(s16x2, clamp);
+            o[0] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o[0]), lo));
+            t.o[i] = o[0];
+            if constexpr (i == 3) {      // the k-block leaves as one 128-bit value (one tuple copy into the operand buffer)
+                const u32x4 v = {t.o[0], t.o[1], t.o[2], t.o[3]};
+                xout[c][kb] = v;
+            }
+        } else {
+            constexpr int bit = 8 * tt + 2 * i;
+            const u16x2 one = {1, 1};
+            const u16x2 z = __builtin_elementwise_sub_sat(one, __builtin_bit_cast(u16x2, t.o[i]));
+            const unsigned prev = (tt == 0 && i == 0) ? 0u : t.m;
+            t.m = __builtin_amdgcn_udot2(z, __builtin_bit_cast(u16x2, (1u << bit) | (2u << (bit + 16))), prev, false);
+            if constexpr (tt == 1 && i == 3) t.word[b] = ~t.m;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// one quarter pass
+// ---------------------------------------------------------------------------------------------
+// MFMAs: [PRE position] + NPOS main positions; a position = 8 units x 2 column blocks, two halves around the
+// mid-step.  NRQ = 2: unit u = (k-block u/2, row block u%2); NRQ = 1: unit u = k-block u, row block 0.
+//
+// One wave per SIMD: an MFMA occupies the matrix pipe for 32 cycles and the wave issues in order, so whatever stands
+// between two MFMAs beyond ~6 issue slots (24 cycles) delays the next MFMA and the pipe idles -- and a gap with fewer
+// fillers cannot make up for it.  The fillers are therefore laid out by a small compile-time list scheduler: every
+// main-position gap g = 16 I + m starts with its FIXED load
+//   m 0..3  : fragment read of the position's second half        m 4, 5 : the scalar slot arithmetic of the coming refill
+//   m 8     : the refill DMA pair + a fragment of the next position   m 9..11 : fragments of the next position
+//   stash   : (layers that stash their input) LDS writes / read-backs in m 12..15, the row stores in m 4..7
+// and the items of the pending accumulator set -- per block its conversion units, its decision-word store and its four
+// bias re-loads, in dependency order -- are poured into the gaps up to a cap of issue slots per gap (raised only if the
+// pass's deadline D could not be met otherwise).
+struct WdCarry {             // registers that live from pass to pass
+    bf16x8 a0[4];            // first-half fragments of the coming position
+    u32x4 sb[4];             // stash rows read back from the LDS tile, waiting to be stored
+};
+
+template <int NRQ, int NPOS, int BMAIN, int KB0, int PRE, int CK, int NRQP, int CKB0, bool MASK, int NRQN, int D, int PQ, bool STASH, int LD>
+struct WdPass {
+    static constexpr int KBPP = 8 / NRQ;
+    static constexpr int NG = NPOS * 16;
+    static constexpr int DG = D < NG ? D : NG;
+    using CV = WdConv<NRQP, CKB0, MASK>;
+    static constexpr int NBLK = CK == WC_ACT ? CV::NB : 0;
+    static constexpr int IPB = CK == WC_ACT ? CV::UPB + 5 : 0;      // items per block: VALU units, word store, 4 bias loads
+    static constexpr int NIT = NBLK * IPB;
+    static_assert(BMAIN == WB_REG || NPOS == 1, "a PE-image segment is one position");
+    static_assert(!STASH || NPOS == 4, "the stash pipeline is laid out over the 16 positions of a layer");
+
+    struct Regs {
+        bf16x8 a1[4];
+        u32x4 bpe[2][4];
+        WdConvTmp ct;
+        unsigned dma_dst, dma_off;
+    };
+
+    // ---- stash pipeline over the layer's 16 positions P = 4 PQ + I: job j = (column block j % 2, k-blocks 4 (j/2) ..):
+    // LDS writes in P = 2j (gaps 12..15), read-backs in P = 2j + 1 (gaps 12..15), row stores in P = 2j + 2 (gaps 4..7);
+    // the last job's stores follow position 15 directly.
+    static constexpr int st_kind(int g) {          // 0 none, 1 LDS write, 2 read-back, 3 row store
+        if (!STASH) return 0;
+        const int P = 4 * PQ + g / 16, m = g % 16;
+        if (m >= 12) return P % 2 == 0 ? 1 : 2;
+        if (m >= 4 && m < 8 && P % 2 == 0 && P >= 2) return 3;
+        return 0;
+    }
+    static constexpr int st_job(int g) {
+        const int P = 4 * PQ + g / 16, m = g % 16;
+        return m >= 12 ? P / 2 : P / 2 - 1;
+    }
+
+    // ---- the list scheduler ----
+    static constexpr int item_weight(int k) {      // issue slots of item k
+        const int r = k % (IPB > 0 ? IPB : 1), b = k / (IPB > 0 ? IPB : 1);
+        if (r < CV::UPB) {
+            if (!MASK) return 3;
+            const int u = r % CV::UPT;
+            return (u == 0 || u == 1 || u == 3 || u == 5) ? 3 : 2;       // [cvt, clamp, (accvgpr_write)] / [flags, dot2]
+        }
+        if (r == CV::UPB) return MASK ? 2 : 0;                              // decision-word store
+        return (b / 2) < NRQN ? 1 : 0;                                      // bias re-load (only the row blocks the next pass uses)
+    }
+    static constexpr int fixed_load(int g) {
+        const int m = g % 16;
+        int w = 0;
+        if (m < 4) w += 1;
+        if (m == 4 || m == 5) w += 3;
+        if (m == 8) w += 10;
+        if (m >= 9 && m <= 11) w += 1;
+        const int sk = st_kind(g);
+        if (sk == 1 || sk == 2) w += 1;
+        if (sk == 3) w += 2;
+        return w;
+    }
+    struct Sched {
+        int first[NG + 1];       // items first[g] .. first[g+1]-1 go to gap g
+        int cap;
+    };
+    static constexpr Sched make_sched() {
+        Sched S{};
+        for (int cap = 6; cap < 64; ++cap) {
+            int k = 0;
+            for (int g = 0; g < NG; ++g) {
+                S.first[g] = k;
+                int load = fixed_load(g);
+                if (g < DG || g == NG - 1) {
+                    while (k < NIT) {
+                        const int w = item_weight(k);
+                        if (w > 0 && load + w > cap && !(g == NG - 1)) break;
+                        load += w;
+                        ++k;
+                    }
+                }
+            }
+            S.first[NG] = k;
+            S.cap = cap;
+            // accept when everything before the deadline gap fitted without the overflow into the last gap
+            int last = 0;
+            for (int g = 0; g < NG; ++g)
+                if (S.first[g + 1] > S.first[g]) last = g;
+            if (k == NIT && (last < DG || NIT == 0)) return S;
+        }
+        return S;
+    }
+    static constexpr Sched SC = make_sched();
+
+    template <int SRC, int NKB>
+    static __device__ __forceinline__ void load_bpe(Regs& r, const char* peimg, int row0, int lane) {
+        const int n = lane & 31, hh = lane >> 5;
+        const char* p = peimg + (row0 + n) * WD_PE_PITCH + hh * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < NKB; ++k)
+                r.bpe[c][k] = *reinterpret_cast<const u32x4*>(p + c * 32 * WD_PE_PITCH + ((SRC == WB_PED ? PE_X / 8 : 0) + 2 * k) * 16);
+    }
+
+    template <int SRC, int NRQ_, int I, int M>
+    static __device__ __forceinline__ void mfma(f32x16 (&act)[2][2], const Regs& r, const WdCarry& cr, const u32x4 (&xin)[2][16]) {
+        constexpr int u = M / 2, c = M % 2;
+        constexpr int kbl = NRQ_ == 2 ? u / 2 : u, rbl = NRQ_ == 2 ? u % 2 : 0;
+        const bf16x8 a = u < 4 ? cr.a0[u] : r.a1[u - 4];
+        if constexpr (SRC == WB_REG) act[c][rbl] = mfma_f16(a, __builtin_bit_cast(bf16x8, xin[c][KB0 + I * (8 / NRQ_) + kbl]), act[c][rbl]);
+        else act[c][rbl] = mfma_f16(a, __builtin_bit_cast(bf16x8, r.bpe[c][SRC == WB_PED ? kbl % 2 : kbl]), act[c][rbl]);
+    }
+
+    // fixed fillers of gap M of a position: fragment reads, the refill's scalar arithmetic, the DMA pair
+    template <int M>
+    static __device__ __forceinline__ void fixed(WdCtx& cx, Regs& r, WdCarry& cr, const char* rd, const char* rd_next) {
+        if constexpr (M < 4) {
+            r.a1[M] = *reinterpret_cast<const bf16x8*>(rd + (4 + M) * 1024 + cx.lane * 16);
+        } else if constexpr (M == 4) {
+            r.dma_dst = cx.dma_base + cx.slot_off;              // refill the slot this position frees ...
+            r.dma_off = cx.fetch_off;                           // ... with stream position +S
+        } else if constexpr (M == 5) {
+            cx.fetch_off = cx.fetch_off + WD_SLOT == (unsigned)WD_WRAP * WD_SLOT ? 0u : cx.fetch_off + WD_SLOT;
+            cx.slot_off = cx.slot_off + WD_SLOT == (unsigned)WD_S * WD_SLOT ? 0u : cx.slot_off + WD_SLOT;
+        } else if constexpr (M == 8) {
+#ifndef LUSH_ABL_NODMA
+            wd_dma_pair(cx.gbase + r.dma_off, cx.gbase + r.dma_off + 4096u, cx.voff, r.dma_dst, r.dma_dst + 4096u);
+#endif
+            cr.a0[0] = *reinterpret_cast<const bf16x8*>(rd_next + cx.lane * 16);
+        } else if constexpr (M >= 9 && M <= 11) {
+            cr.a0[M - 8] = *reinterpret_cast<const bf16x8*>(rd_next + (M - 8) * 1024 + cx.lane * 16);
+        }
+    }
+
+    // item K of the pending set's stream
+    template <int K>
+    static __device__ __forceinline__ void item(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], Regs& r, const WdRt& rt, int lane) {
+        constexpr int b = K / IPB, rr = K % IPB, c = b % 2, rbl = b / 2;
+        if constexpr (rr < CV::UPB) {
+            CV::template unit<b * CV::UPB + rr>(pend, xout, r.ct, rt.clamp);
+        } else if constexpr (rr == CV::UPB) {
+            if constexpr (MASK) *reinterpret_cast<unsigned short*>(rt.mptr[c] + rbl * 128 + rt.lane2) = (unsigned short)r.ct.word[b];
+        } else if constexpr (rbl < NRQN) {
+            constexpr int j = rr - CV::UPB;       // 1..4
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rt.nextbias + rbl * 32 + 8 * (lane >> 5) + (j == 1 ? 0 : j == 2 ? 4 : j == 3 ? 16 : 20));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pend[c][rbl][4 * (j - 1) + e] = v[e];
+        }
+    }
+
+    template <int G>
+    static __device__ __forceinline__ void pending(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], Regs& r, const WdRt& rt, int lane, float (&alpha)[2]) {
+        if constexpr (CK == WC_ACT) {
+            wd_unroll<SC.first[G], SC.first[G + 1]>([&](auto kc) __attribute__((always_inline)) { item<decltype(kc)::value>(pend, xout, r, rt, lane); });
+        } else if constexpr (CK == WC_ALPHA) {
+            if constexpr (G == 0) {
+                alpha[0] = pend[0][0][0];
+                alpha[1] = pend[1][0][0];
+            }
+            if constexpr (G >= 1 && G <= 8) {       // re-load both blocks of each column set with the next pass's biases
+                constexpr int q = G - 1, c = q % 2, rbl = (q / 2) % 2, jj = q / 4;    // two loads per gap
+                if constexpr (rbl < NRQN) {
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int j = 1 + 2 * jj + j2;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(rt.nextbias + rbl * 32 + 8 * (lane >> 5) + (j == 1 ? 0 : j == 2 ? 4 : j == 3 ? 16 : 20));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pend[c][rbl][4 * (j - 1) + e] = v[e];
+                    }
+                }
+            }
+        }
+    }
+
+    template <int JOB, int I4>
+    static __device__ __forceinline__ void stash_store(const WdCarry& cr, const WdRt& rt) {
+        constexpr int c = JOB % 2, j = JOB / 2;      // uniform row-block base + ONE per-lane offset
+#ifndef LUSH_ABL_NOSTORE
+        __builtin_nontemporal_store(cr.sb[I4], reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off));
+#else
+        asm volatile("" ::"v"(cr.sb[I4]));
+#endif
+    }
+    template <int G>
+    static __device__ __forceinline__ void stash(const u32x4 (&xin)[2][16], WdCarry& cr, const WdRt& rt, int lane) {
+        if constexpr (st_kind(G) != 0) {
+            constexpr int job = st_job(G), c = job % 2, j = job / 2, m = G % 16;
+            if constexpr (st_kind(G) == 1) {
+                constexpr int o = m - 12;
+                const int n = lane & 31, hh = lane >> 5;
+                *reinterpret_cast<u32x4*>(rt.tile + n * 128 + (((2 * o + hh) ^ (n & 7)) << 4)) = xin[c][4 * j + o];
+            } else if constexpr (st_kind(G) == 2) {
+                constexpr int i = m - 12;
+                const int row = 8 * i + (lane >> 3);
+                cr.sb[i] = *reinterpret_cast<const u32x4*>(rt.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+            } else {
+                stash_store<job, m - 4>(cr, rt);
+            }
+        }
+    }
+
+    // stores this wave issues in main gaps [g0, g1) (vmcnt bookkeeping; only what is certain: an undercount is safe)
+    static constexpr int stores_in(int g0, int g1) {
+        int n = 0;
+        for (int g = g0 < 0 ? 0 : g0; g < g1 && g < NG; ++g) {
+            if (st_kind(g) == 3) ++n;
+            if (CK == WC_ACT && MASK)
+                for (int k = SC.first[g]; k < SC.first[g + 1]; ++k)
+                    if (k % IPB == CV::UPB) ++n;
+        }
+        return n;
+    }
+
+    template <int SRC, int NRQ_, int I, bool MAIN>
+    static __device__ __forceinline__ void position(WdCtx& cx, f32x16 (&act)[2][2], f32x16 (&pend)[2][2], const u32x4 (&xin)[2][16],
+                                                    u32x4 (&xout)[2][16], Regs& r, WdCarry& cr, const char* peimg, int row0, const WdRt& rt,
+                                                    float (&alpha)[2]) {
+        // (gamma(d) is 2 k-blocks; the stream pads its K to 4 with zero weights: those MFMAs re-use the two real operands)
+        if constexpr (SRC != WB_REG) load_bpe<SRC, (SRC == WB_PED ? 2 : 4)>(r, peimg, row0, cx.lane);
+        const char* rd = cx.ring + cx.slot_off;
+        __builtin_amdgcn_sched_barrier(0);
+        wd_unroll<0, 8>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int M = decltype(mc)::value;
+            mfma<SRC, NRQ_, I, M>(act, r, cr, xin);
+            fixed<M>(cx, r, cr, rd, nullptr);
+            if constexpr (MAIN) {
+                stash<16 * I + M>(xin, cr, rt, cx.lane);
+                pending<16 * I + M>(pend, xout, r, rt, cx.lane, alpha);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // mid-step: my pieces of position +1 have landed (the DMAs of +2 .. +S-1 and the stores issued since are younger);
+        // after the barrier everyone's have, and nobody reads this position's slot any more
+        constexpr int younger = 2 * (WD_S - 2) + (MAIN ? stores_in(16 * (I + 1 - WD_S) + 8, 16 * I + 8) : 0);
+        WPROF_T(t_w0);
+#ifndef LUSH_ABL_NOVMWAIT
+        wd_wait_vm<(younger < 63 ? younger : 63)>();
+#endif
+        WPROF_T(t_w1);
+        lds_barrier();
+#ifdef LUSH_PROF
+        cx.prof[5] += t_w1 - t_w0;
+        cx.prof[6] += __builtin_amdgcn_s_memtime() - t_w1;
+        cx.prof[7] += 1;
+#endif
+        const char* rd_next = cx.ring + cx.slot_off;        // (slot_off already names the next slot: gap 5)
+        __builtin_amdgcn_sched_barrier(0);
+        wd_unroll<8, 16>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int M = decltype(mc)::value;
+            mfma<SRC, NRQ_, I, M>(act, r, cr, xin);
+            fixed<M>(cx, r, cr, rd, rd_next);
+            if constexpr (MAIN) {
+                stash<16 * I + M>(xin, cr, rt, cx.lane);
+                pending<16 * I + M>(pend, xout, r, rt, cx.lane, alpha);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    static __device__ __forceinline__ void run(WdCtx& cx, f32x16 (&act)[2][2], f32x16 (&pend)[2][2], const u32x4 (&xin)[2][16],
+                                               u32x4 (&xout)[2][16], WdCarry& cr, const char* peimg, int row0, const WdRt& rt, float (&alpha)[2]) {
+        Regs r;
+        if constexpr (PRE == WB_PEX) {
+            if (rt.pre_on) position<WB_PEX, 2, 0, false>(cx, act, pend, xin, xout, r, cr, peimg, row0, rt, alpha);
+        } else if constexpr (PRE == WB_PED) {
+            position<WB_PED, 2, 0, false>(cx, act, pend, xin, xout, r, cr, peimg, row0, rt, alpha);
+        }
+        wd_unroll<0, NPOS>([&](auto ic) __attribute__((always_inline)) {
+            position<BMAIN, NRQ, decltype(ic)::value, true>(cx, act, pend, xin, xout, r, cr, peimg, row0, rt, alpha);
+        });
+        if constexpr (STASH && PQ == 3) {     // the layer's last job: its read-backs were this position's last fillers
+            stash_store<7, 0>(cr, rt);
+            stash_store<7, 1>(cr, rt);
+            stash_store<7, 2>(cr, rt);
+            stash_store<7, 3>(cr, rt);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+// gamma(x), gamma(d) of the tile's 256 points as fp16 into the padded image, one point per thread (pe_tile of
+// lush_mlp_dev.h with this kernel's row pitch; utils/run_lushnerf_helpers.py:334-361)
+__device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid) {
+    const long long gpt = tile_pt0 + tid;
+    float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (gpt < P) point_of(rays, z, S, gpt, x, d);
+    _Float16* row = reinterpret_cast<_Float16*>(peimg + tid * WD_PE_PITCH);
+    for (int u = 0; u < L_X + L_D; ++u) {
+        const bool isd = u >= L_X;
+        const int k = isd ? u - L_X : u;
+        const int base = isd ? PE_X : 0;
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float v = isd ? d[i] : x[i];
+            if (k == 0) row[base + i] = (_Float16)v;
+            float sn, cs;
+            lush_sincos(v * f, &sn, &cs);
+            row[base + 3 + 6 * k + i] = (_Float16)sn;
+            row[base + 3 + 6 * k + 3 + i] = (_Float16)cs;
+        }
+    }
+    row[PE_X_VALID] = (_Float16)0.f;      // zero padding columns that the K loops do read
+#pragma unroll
+    for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) row[c] = (_Float16)0.f;
+}
+
+// acc[c][rbl][q] = b[32 rbl + 16 (q>>3) + 8 h + (q&7)] from the LDS bias block (chain_row() order, as ch_bias)
+__device__ __forceinline__ void wd_bias(f32x16 (&acc)[2][2], const float* b, int h, int nrq) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int rbl = 0; rbl < 2; ++rbl) {
+            if (rbl < nrq) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(b + rbl * 32 + 8 * h);
+                const f32x4 v0 = p[0], v1 = p[1], v2 = p[4], v3 = p[5];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[c][rbl][e] = v0[e];
+                    acc[c][rbl][4 + e] = v1[e];
+                    acc[c][rbl][8 + e] = v2[e];
+                    acc[c][rbl][12 + e] = v3[e];
+                }
+            }
+        }
+}
+
+template <class N, int SPK>
+__global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A) {
+    static_assert(N::HW == 256 && N::NL == 8 && N::HV == 128, "the wide kernel is built for the 8x256 net");
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, NRB = N::NRB;
+    constexpr int NBIAS = N::f32_w_rgb;
+    constexpr bool MASK = SPK > 0;
+    constexpr int ML_BYTES = NRB * 128;                        // decision words of one (column block, layer)
+    constexpr int CB_BYTES = N::n_mask_layers * ML_BYTES;      // ... of one column block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // The bias block comes first: its reads then are one per-lane register + an immediate (DS offsets reach 64 KiB; placed
+    // behind the images every distinct bias address became a register of its own, hoisted out of the tile loop and spilled).
+    float* biasl = reinterpret_cast<float*>(smem);             // [NBIAS] fp32
+    char* ring = smem + NBIAS * 4;                             // [WD_S][8 KiB]
+    char* stage = ring + WD_S * WD_SLOT;                       // [4 waves][4 KiB] stash transposition tiles (SPK > 0)
+    char* peimg = stage + 4 * 4096;                            // [256 points][272 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const char* wbase = reinterpret_cast<const char*>(A.wpk);
+    {
+        const float* f32 = reinterpret_cast<const float*>(wbase + (long long)N::total_entries * 1024);
+        for (int i = tid; i < NBIAS; i += WD_NT) biasl[i] = f32[i];
+    }
+    WdCtx cx;
+    cx.ring = ring;
+    cx.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    cx.gbase = wbase + (long long)N::fwd4_base * 1024;
+    cx.slot_off = 0;
+    cx.fetch_off = (unsigned)(WD_S % WD_WRAP) * WD_SLOT;
+    cx.dma_base = __builtin_amdgcn_readfirstlane(cx.ring_lds + (unsigned)w * 1024u);
+    cx.w = w;
+    cx.lane = lane;
+    cx.voff = (unsigned)lane * 16u + (unsigned)w * 1024u;
+#ifdef LUSH_PROF
+    for (int i = 0; i < 16; ++i) cx.prof[i] = 0;
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int j = 0; j < WD_S; ++j)
+        wd_dma_pair(cx.gbase + (unsigned)j * WD_SLOT, cx.gbase + (unsigned)j * WD_SLOT + 4096u, cx.voff, cx.dma_base + (unsigned)j * WD_SLOT, cx.dma_base + (unsigned)j * WD_SLOT + 4096u);
+
+    const int row0 = w * 64;
+    WdRt rt;
+    rt.tile = stage + w * 4096;
+    rt.pre_on = false;
+    rt.srows = nullptr;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) rt.soff[c] = (unsigned)(((c * 32 + n) * HW + h * 8) * 2);
+    rt.srow_off = (unsigned)(((lane >> 3) * HW + (lane & 7) * 8) * 2);
+    rt.lane2 = (unsigned)lane * 2u;
+    float alpha[2] = {0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * WD_MT;
+        const long long wpt = pt0 + row0;
+        WPROF_T(t_tile);
+#ifndef LUSH_ABL_NOPE
+        wd_pe_tile(peimg, A.rays, A.z, A.S, A.P, pt0, tid);
+#endif
+        // my pieces of the tile's first position have landed.  First tile: the prologue issued S positions, S-1 are younger.
+        // Later tiles: that DMA left S positions ago, in the views layer's second quarter; younger are the DMAs of S-1
+        // positions and AT LEAST the 16 stash stores of the views hidden + the raw store (an undercount is safe) -- a full
+        // drain here would wait for every stash store of the tile to reach memory (microseconds, 40 times per launch).
+        if (tile == (int)blockIdx.x) wd_wait_vm<2 * (WD_S - 1)>();
+        else wd_wait_vm<2 * (WD_S - 1) + (SPK > 0 ? 17 : 1)>();
+        lds_barrier();
+        if (SPK > 0) {
+            for (int i = tid; i < WD_MT * 12; i += WD_NT) {
+                const int c = i % 12, pt = i / 12;
+                const uint4 v = *reinterpret_cast<const uint4*>(peimg + pt * WD_PE_PITCH + c * 16);
+                *reinterpret_cast<uint4*>(A.pe + (pt0 + pt) * PE_ROW + c * 8) = v;
+            }
+        }
+        {   // opaque per tile (keeps the static stream addresses from being hoisted out of the tile loop)
+            unsigned long long gb = (unsigned long long)cx.gbase;
+            asm volatile("" : "+s"(gb));
+            cx.gbase = (const char*)gb;
+        }
+        // decision words of (this wave's column block c, layer ml, row block rb): mbase[c] + ml * ML_BYTES + rb * 128 (+ 2 lane)
+        char* mbase[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) mbase[c] = reinterpret_cast<char*>(A.mask) + (wpt / 32 + c) * CB_BYTES;
+        char* mdummy = reinterpret_cast<char*>(A.mask_dummy);
+        auto mset = [&](int ml, int rb, bool dummy) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) rt.mptr[c] = dummy ? mdummy + c * 256 : mbase[c] + ml * ML_BYTES + rb * 128;
+        };
+
+        f32x16 accA[2][2], accB[2][2];
+        u32x4 B0[2][16], B1[2][16];
+        WdCarry a0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0.a0[i] = *reinterpret_cast<const bf16x8*>(cx.ring + cx.slot_off + i * 1024 + lane * 16);
+        const float* btr = biasl + N::f32_b_trunk;
+        wd_bias(accA, btr, h, 2);
+        wd_bias(accB, btr + 64, h, 2);
+
+        WPROF_ADD(1, t_tile);
+        WPROF_T(t_l0);
+        // ---- layer 0: gamma(x) from the PE image, four quarter passes of one position ----
+        rt.clamp = 0u;
+        WdPass<2, 1, WB_PEX, 0, WB_NONE, WC_NONE, 2, 0, MASK, 2, 16, 0, false, HW>::run(cx, accA, accB, B0, B0, a0, peimg, row0, rt, alpha);
+        mset(0, 0, false); rt.nextbias = btr + 128;
+        WdPass<2, 1, WB_PEX, 0, WB_NONE, WC_ACT, 2, 0, MASK, 2, 16, 0, false, HW>::run(cx, accB, accA, B0, B0, a0, peimg, row0, rt, alpha);
+        mset(0, 2, false); rt.nextbias = btr + 192;
+        WdPass<2, 1, WB_PEX, 0, WB_NONE, WC_ACT, 2, 4, MASK, 2, 16, 0, false, HW>::run(cx, accA, accB, B0, B0, a0, peimg, row0, rt, alpha);
+        mset(0, 4, false); rt.nextbias = btr + HW;
+        WdPass<2, 1, WB_PEX, 0, WB_NONE, WC_ACT, 2, 8, MASK, 2, 16, 0, false, HW>::run(cx, accB, accA, B0, B0, a0, peimg, row0, rt, alpha);
+
+        // ---- layers 1 .. NL-1 and the feature layer (l = NL: no activation, no decision words), two per iteration so
+        // that the B-operand buffers swap roles without copies: odd member B0 -> B1, even member B1 -> B0 ----
+        auto layer = [&](int l, u32x4 (&xin)[2][16], u32x4 (&xout)[2][16]) __attribute__((always_inline)) {
+            const bool feat = l == NL;
+            const float* bl = btr + l * HW;                         // (the feature biases follow the trunk biases)
+            rt.pre_on = l == N::SKIP;
+            rt.srows = reinterpret_cast<char*>(A.h0 + (long long)(l - 1) * A.h_stride + wpt * HW);
+            // pass 0: set A accumulates rows 0..63; set B (last quarter of the previous layer) -> xin k-blocks 12..15
+            rt.clamp = 0u; mset(l - 1, 6, false); rt.nextbias = bl + 64;
+            WdPass<2, 4, WB_REG, 0, WB_PEX, WC_ACT, 2, 12, MASK, 2, 48, 0, (SPK > 0), HW>::run(cx, accA, accB, xin, xin, a0, peimg, row0, rt, alpha);
+            rt.clamp = feat ? 0x80008000u : 0u;
+            mset(l, 0, feat); rt.nextbias = bl + 128;
+            WdPass<2, 4, WB_REG, 0, WB_PEX, WC_ACT, 2, 0, MASK, 2, 60, 1, (SPK > 0), HW>::run(cx, accB, accA, xin, xout, a0, peimg, row0, rt, alpha);
+            mset(l, 2, feat); rt.nextbias = bl + 192;
+            WdPass<2, 4, WB_REG, 0, WB_PEX, WC_ACT, 2, 4, MASK, 2, 60, 2, (SPK > 0), HW>::run(cx, accA, accB, xin, xout, a0, peimg, row0, rt, alpha);
+            mset(l, 4, feat); rt.nextbias = feat ? biasl + N::f32_b_alpha : bl + HW;
+            WdPass<2, 4, WB_REG, 0, WB_PEX, WC_ACT, 2, 8, MASK, 2, 60, 3, (SPK > 0), HW>::run(cx, accB, accA, xin, xout, a0, peimg, row0, rt, alpha);
+        };
+        WPROF_ADD(2, t_l0);
+        WPROF_T(t_trunk);
+#pragma unroll 1
+        for (int l2 = 0; l2 < NL / 2; ++l2) {
+            layer(1 + 2 * l2, B0, B1);
+            layer(2 + 2 * l2, B1, B0);
+        }
+        WPROF_ADD(3, t_trunk);
+        WPROF_T(t_tail);
+        // now: B1 = h_{NL-1}, B0 = feature k-blocks 0..11; set B holds the feature layer's last quarter, set A the alpha bias
+        rt.pre_on = false;
+        // ---- alpha head on h_{NL-1} (1 row block, 2 positions); set B -> feature k-blocks 12..15 ----
+        rt.clamp = 0x80008000u; mset(0, 0, true); rt.nextbias = biasl + N::f32_b_views;
+        WdPass<1, 2, WB_REG, 0, WB_NONE, WC_ACT, 2, 12, MASK, 2, 32, 0, false, HW>::run(cx, accA, accB, B1, B0, a0, peimg, row0, rt, alpha);
+        // ---- views layer: relu(Wv [feature ; gamma(d)] + b), two quarter passes ----
+        rt.nextbias = biasl + N::f32_b_views + 64;
+        WdPass<2, 4, WB_REG, 0, WB_PED, WC_ALPHA, 1, 0, MASK, 2, 60, 0, false, HW>::run(cx, accB, accA, B0, B0, a0, peimg, row0, rt, alpha);
+        rt.clamp = 0u; mset(NL, 0, false); rt.nextbias = biasl + N::f32_b_rgb;
+        WdPass<2, 4, WB_REG, 0, WB_PED, WC_ACT, 2, 0, MASK, 1, 60, 0, false, HW>::run(cx, accA, accB, B0, B1, a0, peimg, row0, rt, alpha);
+        {   // the second views quarter has no MFMAs left to hide behind
+            WdConvTmp ct;
+            using CV = WdConv<2, 4, MASK>;
+            mset(NL, 2, false);
+            wd_unroll<0, CV::NVU>([&](auto kc) __attribute__((always_inline)) { CV::template unit<decltype(kc)::value>(accA, B1, ct, 0u); });
+            if constexpr (MASK) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) *reinterpret_cast<unsigned short*>(rt.mptr[b % 2] + (b / 2) * 128 + rt.lane2) = (unsigned short)ct.word[b];
+            }
+        }
+        if constexpr (SPK > 0) {    // views hidden -> stash rows [point][HV]
+            char* hvrows = reinterpret_cast<char*>(A.hv + wpt * HV);
+#ifndef LUSH_WD_DIRECT_STASH
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < N::KKV / 4; ++j) {
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+                        *reinterpret_cast<u32x4*>(rt.tile + n * 128 + (((2 * kq + h) ^ (n & 7)) << 4)) = B1[c][4 * j + kq];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 8 * i + (lane >> 3);
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(rt.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(hvrows + ((c * 32 + 8 * i) * HV + j * 64) * 2 + (unsigned)(((lane >> 3) * HV + (lane & 7) * 8) * 2)));
+                    }
+                }
+#else
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned off = (unsigned)(((c * 32 + n) * HV + h * 8) * 2);
+#pragma unroll
+                for (int kb = 0; kb < N::KKV; ++kb) __builtin_nontemporal_store(B1[c][kb], reinterpret_cast<u32x4*>(hvrows + off + kb * 32));
+            }
+#endif
+        }
+        // ---- rgb head (1 row block, 1 position) ----
+        WdPass<1, 1, WB_REG, 0, WB_NONE, WC_NONE, 2, 0, MASK, 2, 16, 0, false, HW>::run(cx, accB, accA, B1, B1, a0, peimg, row0, rt, alpha);
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const long long gpt = wpt + c * 32 + n;
+                if (gpt < A.P) {
+                    float4 o;
+                    o.x = accB[c][0][0];
+                    o.y = accB[c][0][1];
+                    o.z = accB[c][0][2];
+                    o.w = alpha[c];
+                    *reinterpret_cast<float4*>(A.raw + gpt * 4) = o;
+                }
+            }
+        }
+        WPROF_ADD(4, t_tail);
+#ifdef LUSH_PROF
+        cx.prof[8] += 1;
+#endif
+    }
+#ifdef LUSH_PROF
+    if (blockIdx.x == 0 && tid == 0) {
+        cx.prof[0] = __builtin_amdgcn_s_memtime() - t_kernel;
+        for (int i = 0; i < 16; ++i) lush_prof_wide[i] = cx.prof[i];
+    }
+#endif
+    wd_wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static_assert((NetNerf::f32_w_rgb * 4) % 16 == 0, "the ring behind the bias block stays 16-byte aligned");
+size_t mlp_wide_fwd_lds_bytes() { return (size_t)WD_S * WD_SLOT + (size_t)WD_PE_PLANE + (size_t)NetNerf::f32_w_rgb * 4 + 4 * 4096; }
+
+template <int SPK>
+static int launch_wide_sp(const MlpFwdArgs& a, hipStream_t s) {
+    auto k = mlp_wide_fwd_kernel<NetNerf, SPK>;
+    const size_t lds = mlp_wide_fwd_lds_bytes();
+    int dev = 0, n_cu = 0;
+    LUSH_HIP(hipGetDevice(&dev));
+    LUSH_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cu <= 0) n_cu = 256;
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles = (a.n_tiles * 128 + WD_MT - 1) / WD_MT;      // a.n_tiles counts 128-point tiles (point arrays are padded to 256)
+    MlpFwdArgs b = a;
+    b.n_tiles = tiles;
+    const int grid = tiles < n_cu ? tiles : n_cu;                 // one workgroup per CU, tiles strided
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WD_NT), lds, s, b);
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+#ifdef LUSH_PROF
+extern "C" int lush_debug_prof_wide(unsigned long long* out) {
+    LUSH_HIP(hipDeviceSynchronize());
+    LUSH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lush_prof_wide), sizeof(unsigned long long) * 16));
+    return 0;
+}
+#endif
+
+// One fp16 plane, the 8x256 net: a.stash_planes 0 (inference) or 1.
+int launch_mlp_wide_fwd(const MlpFwdArgs& a, hipStream_t s) {
+    const int sp = a.write_stash ? a.stash_planes : 0;
+    if (sp == 0) return launch_wide_sp<0>(a, s);
+    if (sp == 1) return launch_wide_sp<1>(a, s);
+    return set_error("launch_mlp_wide_fwd: one stash plane at most");
+}
+
+}  // namespace lush

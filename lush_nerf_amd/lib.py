@@ -14,7 +14,7 @@ from typing import Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("LUSH_SO") or os.path.join(HERE, "liblush_march.so")   # LUSH_SO: developer ablation builds
-SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_abi.hip"]
+SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_mlp_wide.hip", "lush_abi.hip"]
 HEADERS = ["lush_common.h", "lush_mlp.h", "lush_mlp_dev.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
 
 _lib = None
@@ -44,17 +44,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *os.environ.get("LUSH_HIPCC_FLAGS", "").split()]
+    # per file: the 64-points-per-wave kernels keep their accumulators in VGPRs (the VALU converts them; AGPR-resident
+    # accumulators cost one v_accvgpr_read per value) and let the B-operand buffers, which only MFMAs read, go to AGPRs
+    per_file = {"lush_mlp_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     with tempfile.TemporaryDirectory(prefix="lush_build_") as tmp:
         def compile_one(f):
             obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
-            cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, f), "-o", obj]
+            cmd = [_hipcc(), *flags, *per_file.get(f, []), "-c", os.path.join(CSRC, f), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
             return obj
-        with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        with ThreadPoolExecutor(max_workers=min(5, len(SOURCES))) as ex:
             objs = list(ex.map(compile_one, SOURCES))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", SO_PATH + ".tmp"]
         if verbose:
@@ -108,17 +111,19 @@ _SIGS = {
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
     "lush_mlp_stash_bytes": ([_i, _i, _i, _ll], _sz),
     "lush_mlp_dstash_bytes": ([_i, _i, _ll], _sz),
-    "lush_mlp_fwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p], _i),
+    "lush_mlp_fwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _i, _p], _i),
     "lush_mlp_bwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p,
-                      C.POINTER(MlpParams), _p, _p], _i),
-    "lush_mlp_bwd_chain": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _p], _i),
-    "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(MlpParams), _p], _i),
+                      C.POINTER(MlpParams), _p, _i, _p], _i),
+    "lush_mlp_bwd_chain": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _i, _p], _i),
+    "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(MlpParams), _i, _p], _i),
     "lush_ray_grad_reduce": ([_p, _p, _i, _i, _p, _p], _i),
     "lush_adam": ([_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p], _i),
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 4
+ABI_VERSION = 5
+# include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
+VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL = 1, 2, 4, 8
 # include/lush_march.h: LUSH_FAULT_*
 FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
                128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}

@@ -58,9 +58,10 @@ class Precision:
     power-of-two loss scale chosen on the device from max|d_raw| -- 11-bit operands at the cost of the 8-bit ones."""
     fwd: int = 2
     bwd: int = 2
+    variant: int = 0      # lib.VARIANT_* bits: an older kernel for the same work (A/B timing, agreement tests); 0 = the product's choice
 
     def noise(self) -> "Precision":
-        return Precision(2, self.bwd) if self.fwd == PLANES_F16 else self
+        return Precision(2, self.bwd, self.variant) if self.fwd == PLANES_F16 else self
 
 
 # ----------------------------------------------------------------------------- MLP plumbing
@@ -99,7 +100,7 @@ TIMER: Optional[KernelTimer] = None
 DEBUG_KEEP: Optional[dict] = None
 
 
-def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0):
+def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0, variant: int = 0):
     """stash_planes: planes kept for the backward (default: all `planes`)."""
     R, S = z.shape
     sp = nplanes(stash_planes or planes) if want_stash else 0   # 0 = inference: only the gamma-row workspace
@@ -111,7 +112,7 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
     if ev:
         ev[0].record()
     lib.call("lush_mlp_fwd", net, planes, sp, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st),
-             lib.ptr(raw), lib.ptr(stash), _stream())
+             lib.ptr(raw), lib.ptr(stash), int(variant), _stream())
     if ev:
         ev[1].record()
     return raw, (stash if want_stash else None)
@@ -134,7 +135,7 @@ def grad_sink(tensors):
     return gs
 
 
-def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash, sink=None):
+def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash, sink=None, variant: int = 0):
     """Returns (list of parameter grads in `tensors` order, dpts [P][8]).  With `sink` (a list of fp32
     buffers, one per tensor) the gradients are ADDED to those buffers and the returned list holds None."""
     R, S = z.shape
@@ -155,14 +156,14 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
     if ev:
         ev[0].record()
     lib.call("lush_mlp_bwd_chain", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b),
-             C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), _stream())
+             C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), int(variant), _stream())
     if ev:
         ev[1].record()
     ev = TIMER.span("mlp_bwd_weights", R * S) if timed else None
     if ev:
         ev[0].record()
     lib.call("lush_mlp_bwd_weights", net, planes_f, planes_b, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash),
-             lib.ptr(dstash), C.byref(gs), _stream())
+             lib.ptr(dstash), C.byref(gs), int(variant), _stream())
     if ev:
         ev[1].record()
     return ([None] * len(tensors) if sink is not None else grads), dpts
@@ -286,7 +287,8 @@ class March(torch.autograd.Function):
         noise_c = _opt(draws.get("noise_c")) if cfg.raw_noise_std > 0 else None
         zc = zgrid(batch, cfg.N_samples, cfg.lindisp, t_rand)
         pk_c = mlp_pack(NET_NERF, pf, coarse)
-        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb))
+        var = cfg.precision.variant
+        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb), var)
         rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, noise_c, cfg,
                                                           lib.FAULT_COARSE_SHIFT if cfg.N_importance > 0 else 0)
         outs = [rgb, depth, acc, density]
@@ -298,7 +300,7 @@ class March(torch.autograd.Function):
             zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, u, cfg.flags)
             same = fine is coarse
             pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
-            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb))
+            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb), var)
             rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, noise_f, cfg)
             outs = [rgb1, depth1, acc1, density1]
             saved.update(zf=zf, raw_f=raw_f, noise_f=noise_f, stash_f=stash_f)
@@ -336,7 +338,7 @@ class March(torch.autograd.Function):
             if pk is None:
                 pk = mlp_pack(NET_NERF, pb, tensors)
             gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash,
-                                    sink=grad_sink(tensors))
+                                    sink=grad_sink(tensors), variant=cfg.precision.variant)
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays),
                      _stream())
             return gr
@@ -368,7 +370,8 @@ class NoiseMlp(torch.autograd.Function):
         lib.call("lush_zfixed", lib.ptr(batch), R, int(N_samples), int(index), int(lindisp), lib.ptr(z), _stream())
         pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
         need = bool(want_grad) and any(ctx.needs_input_grad)
-        raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, stash_code(precision.fwd, precision.bwd))
+        raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, stash_code(precision.fwd, precision.bwd),
+                                 precision.variant)
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.update(stash_noise=stash, P_noise=R)
         ctx.batch, ctx.z, ctx.tensors, ctx.stash, ctx.precision = batch, z, tensors, stash, precision
@@ -381,7 +384,7 @@ class NoiseMlp(torch.autograd.Function):
         draw[:, :3] = g
         pk = mlp_pack(NET_NOISE, pr.bwd, ctx.tensors)
         grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash,
-                                sink=grad_sink(ctx.tensors))
+                                sink=grad_sink(ctx.tensors), variant=pr.variant)
         ctx.stash = None
         o = 2 * _NL[NET_NOISE] + 4   # alpha_linear is dead in NeRF_Noise (helpers:496,505,512): grad None
         grads[o] = None

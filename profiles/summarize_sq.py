@@ -6,7 +6,9 @@ import csv, glob, os, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"sq_{tag}")
-KEEP = {"mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_chain_fwd_half_kernel (one fp16 plane, stash on, 2 workgroups per CU)",
+KEEP = {"mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 1>": "mlp_wide_fwd_kernel (one fp16 plane, stash on, 64 points per wave, 1 workgroup per CU)",
+        "mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 0>": "mlp_wide_fwd_kernel (one fp16 plane, no stash)",
+        "mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_chain_fwd_half_kernel (one fp16 plane, stash on, 2 workgroups per CU)",
         "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_chain_fwd_kernel",
         "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_chain_bwd_kernel (one loss-scaled fp16 plane)",
         "mlp_chain_bwd_half_kernel<lush::NetT<256": "mlp_chain_bwd_half_kernel (one loss-scaled fp16 plane, 2 workgroups per CU)",

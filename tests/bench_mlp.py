@@ -12,6 +12,7 @@ R = int(os.environ.get("R", 20480)); S = int(os.environ.get("S", 128))
 modes = [ops.parse_planes(m) for m in os.environ.get("MODES", "2,2;1,1").split(";")]
 what = os.environ.get("WHAT", "fwd,fwd_nostash,chain,weights").split(",")
 reps = int(os.environ.get("REPS", 3))
+variant = int(os.environ.get("VARIANT", 0))        # lib.VARIANT_* bits (A/B timing of kernel variants)
 w = synth.all_weights(30, 0)
 names = [f"mlp_fine.pts_linears.{l}.{s}" for l in range(8) for s in ("weight", "bias")] + \
         [f"mlp_fine.{n}.{s}" for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear") for s in ("weight", "bias")]
@@ -35,10 +36,10 @@ for nf, nb in modes:
     pkb = pk if nb == nf else ops.mlp_pack(0, nb, tens)
     res = {}
     if "fwd" in what:
-        res["fwd"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb)))
+        res["fwd"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb), variant))
     if "fwd_nostash" in what:
-        res["fwd_nostash"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, False))
-    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb))
+        res["fwd_nostash"] = timeit(lambda: ops.mlp_forward(0, nf, tens, pk, batch, z, False, 0, variant))
+    raw, stash = ops.mlp_forward(0, nf, tens, pk, batch, z, True, ops.stash_code(nf, nb), variant)
     nf_s = ops.stash_code(nf, nb)
     import ctypes as C
     dstash = torch.empty(lib.load().lush_mlp_dstash_bytes(0, nb, R * S), dtype=torch.uint8, device=dev)
@@ -47,9 +48,9 @@ for nf, nb in modes:
     st, gs = lib.mlp_struct(tens, 8), lib.mlp_struct(grads, 8)
     def chain():
         lib.call("lush_mlp_bwd_chain", 0, nf_s, nb, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pkb), C.byref(st),
-                 lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), ops._stream())
+                 lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), variant, ops._stream())
     def weights():
-        lib.call("lush_mlp_bwd_weights", 0, nf_s, nb, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), ops._stream())
+        lib.call("lush_mlp_bwd_weights", 0, nf_s, nb, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), C.byref(gs), variant, ops._stream())
     if "chain" in what:
         res["chain"] = timeit(chain)
     else:
@@ -57,4 +58,4 @@ for nf, nb in modes:
     if "weights" in what:
         res["weights"] = timeit(weights)
     fl = 2 * MACS * R * S / 1e9
-    print(json.dumps({"planes": [nf, nb], "R": R, "S": S, **{k: {"ms": round(v, 3), "alg_TF": round(fl / v, 1)} for k, v in res.items()}}), flush=True)
+    print(json.dumps({"planes": [nf, nb], "variant": variant, "R": R, "S": S, **{k: {"ms": round(v, 3), "alg_TF": round(fl / v, 1)} for k, v in res.items()}}), flush=True)

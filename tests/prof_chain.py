@@ -41,7 +41,7 @@ for nf, nb in ((2, 1), (2, 2)):
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         lib.call("lush_mlp_bwd_chain", 0, ops.stash_code(nf, nb), nb, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pkb), C.byref(st),
-                 lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), ops._stream())
+                 lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), 0, ops._stream())
         e.record(); torch.cuda.synchronize()
     out = (C.c_ulonglong * 8)(); L.lush_debug_prof(out); v = list(out); ms = a.elapsed_time(e)
     print(f"bwd planes={nb} ms={ms:.3f} kernel_cycles={v[0]} -> {v[0]/ms/1e3:.0f} MHz; per tile: total={v[0]/80:.0f} pe_bwd={v[1]/80:.0f} phase/layer={v[3]/80/7:.0f} conv/layer={v[4]/80/7:.0f}")

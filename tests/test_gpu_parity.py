@@ -530,21 +530,19 @@ def test_trainer_over_rccl_two_ranks(diag, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("planes,switch", [("h,h", "LUSH_HEAD_KERNEL"), ("h,h", "LUSH_BWD_512"), ("h,h", "LUSH_FWD_512"),
-                                           ("2,1", "LUSH_HEAD_KERNEL")])
-def test_ab_switches_agree(tmp_path, planes, switch):
-    """The developer A/B switches (read once per process, hence the two child processes) select an older kernel for the
-    same work: both variants must give the same outputs and gradients up to the rounding of the mode
-    (the two forwards are bit-identical in their MFMA order; d_rgb / d_alpha travel as 16 + 16 bits with the heads folded)."""
+@pytest.mark.parametrize("planes,variant", [("h,h", "HEAD_KERNEL"), ("h,h", "BWD_512"), ("h,h", "FWD_512"), ("h,h", "FWD_HALF"),
+                                            ("2,1", "HEAD_KERNEL")])
+def test_variants_agree(tmp_path, planes, variant):
+    """The kernel variants of the C ABI (include/lush_march.h LUSH_VARIANT_*: an older kernel for the same work) against
+    the product's choice: same outputs and gradients up to the rounding of the mode (the forwards keep the MFMA order
+    per output; d_rgb / d_alpha travel as 16 + 16 bits with the heads folded).  Each variant runs in a child process."""
     import os, subprocess, sys
     import numpy as np
+    from lush_nerf_amd import lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for on in (False, True):
-        env = dict(os.environ, LUSH_PLANES=planes)
-        env.pop(switch, None)
-        if on:
-            env[switch] = "1"
+        env = dict(os.environ, LUSH_PLANES=planes, LUSH_VARIANT=str(getattr(lib, "VARIANT_" + variant) if on else 0))
         out = str(tmp_path / f"ab_{int(on)}.npz")
         subprocess.run([sys.executable, os.path.join(root, "tests", "ab_worker.py"), out], check=True, env=env, timeout=300)
         outs.append(np.load(out))
@@ -555,8 +553,8 @@ def test_ab_switches_agree(tmp_path, planes, switch):
         scale = float(np.abs(b[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / max(scale, 1e-30)
         worst["raw" if k == "raw" else "grads"] = max(worst.get("raw" if k == "raw" else "grads", 0.0), err)
-        # measured: outputs identical (the variants keep the MFMA order); gradients 9e-7 (heads folded, fp16 hi + lo),
+        # measured (round 2): outputs identical (the variants keep the MFMA order); gradients 9e-7 (heads folded, fp16 hi + lo),
         # 1.3e-5 (heads folded, bf16 hi + lo), 1.6e-6 (forward variants: atomics order), 3.4e-4 (the 256-register
         # backward chain keeps d(gamma) in 16 bits)
-        assert np.isfinite(a[k]).all() and err < (2e-6 if k == "raw" else 2e-3), (switch, k, err)
-    print(f"A/B {switch} ({planes}): outputs differ by {worst.get('raw', 0.0):.1e}, gradients by {worst.get('grads', 0.0):.1e}")
+        assert np.isfinite(a[k]).all() and err < (2e-6 if k == "raw" else 2e-3), (variant, k, err)
+    print(f"variant {variant} ({planes}): outputs differ by {worst.get('raw', 0.0):.1e}, gradients by {worst.get('grads', 0.0):.1e}")
