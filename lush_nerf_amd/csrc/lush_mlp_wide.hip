@@ -114,9 +114,8 @@ struct WdRt {
 // Block b = rbl * 2 + c (row block major: the k-blocks of the next operand complete in k order).  Per block and
 // t = 0, 1 (accumulators 8t .. 8t+7 -> k-block KB0 + 2 rbl + t): four pairs i, each one unit [convert, clamp] and,
 // with MASK, one unit [zero flags of the pair, merged into the block's decision word]: the flags are
-// v_pk_sub_u16(1, x) with clamp (1 where the clamped 16-bit value is zero) and a v_dot2_u32_u16 against the constant
-// {1 << bit, 2 << bit} puts both at their place of the word (bit q = accumulator q: mask_index() layout), inverted
-// once at the end.  VALU units per block: MASK ? 16 : 8.
+// v_pk_sub_u16(1, x) with clamp (1 where the clamped 16-bit value is zero), shifted into place by a v_lshl_or_b32 and
+// inverted once at the end (bit q = accumulator q: mask_index() layout).  VALU units per block: MASK ? 16 : 8.
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 struct WdConvTmp {
     unsigned o[4];       // the packed pairs of the current (block, t)
@@ -138,23 +137,34 @@ struct WdConv {
         constexpr int c = b % 2, rbl = b / 2, kb = KB0 + 2 * rbl + tt;
         constexpr int kind = MASK ? ((u == 0 || u == 1 || u == 3 || u == 5) ? 0 : 1) : 0;
         constexpr int i = MASK ? (kind == 0 ? (u == 0 ? 0 : (u == 1 ? 1 : (u == 3 ? 2 : 3))) : (u == 2 ? 0 : (u == 4 ? 1 : (u == 6 ? 2 : 3)))) : u;
+        // Each unit is ONE volatile asm statement: pure VALU code is otherwise free to leave its filler slot -- the
+        // compiler gathered a whole pass's conversions at the head of the basic block, where nothing hides them.
         if constexpr (kind == 0) {
-            unsigned o[1];
-            split_pair<1, DT_F16>(pend[c][rbl][8 * tt + 2 * i], pend[c][rbl][8 * tt + 2 * i + 1], o);
-            const s16x2 lo = __builtin_bit_cast(s16x2, clamp);
-            o[0] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, o[0]), lo));
-            t.o[i] = o[0];
+            unsigned o;
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, %3"
+                         : "=&v"(o) : "v"(pend[c][rbl][8 * tt + 2 * i]), "v"(pend[c][rbl][8 * tt + 2 * i + 1]), "s"(clamp));
+            t.o[i] = o;
             if constexpr (i == 3) {      // the k-block leaves as one 128-bit value (one tuple copy into the operand buffer)
                 const u32x4 v = {t.o[0], t.o[1], t.o[2], t.o[3]};
                 xout[c][kb] = v;
             }
         } else {
-            constexpr int bit = 8 * tt + 2 * i;
-            const u16x2 one = {1, 1};
-            const u16x2 z = __builtin_elementwise_sub_sat(one, __builtin_bit_cast(u16x2, t.o[i]));
-            const unsigned prev = (tt == 0 && i == 0) ? 0u : t.m;
-            t.m = __builtin_amdgcn_udot2(z, __builtin_bit_cast(u16x2, (1u << bit) | (2u << (bit + 16))), prev, false);
-            if constexpr (tt == 1 && i == 3) t.word[b] = ~t.m;
+            // zero flags of the pair (1 where the clamped halfword is zero) at bits 0 and 16, shifted to 8 tt + 2 i / + 16 and
+            // merged; the last unit folds the high halves in and inverts: bit q = accumulator q positive.
+            // (v_dot2_u32_u16 would place both flags in one instruction, but costs ~12 cycles and stalls the matrix pipe:
+            // tests/micro/mfma_fillers.hip; v_lshl_or_b32 hides behind the MFMAs like any plain VALU instruction.)
+            constexpr int sh = 8 * tt + 2 * i;
+            unsigned z;
+            if constexpr (tt == 0 && i == 0) {
+                asm volatile("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(t.m) : "v"(t.o[i]));
+            } else if constexpr (tt == 1 && i == 3) {
+                unsigned w;
+                asm volatile("v_pk_sub_u16 %1, 1, %3 op_sel_hi:[0,1] clamp\n\tv_lshl_or_b32 %2, %1, %4, %2\n\tv_lshrrev_b32 %1, 15, %2\n\tv_or_b32 %1, %1, %2\n\tv_not_b32 %0, %1"
+                             : "=v"(w), "=&v"(z), "+v"(t.m) : "v"(t.o[i]), "n"(sh));
+                t.word[b] = w;
+            } else {
+                asm volatile("v_pk_sub_u16 %0, 1, %2 op_sel_hi:[0,1] clamp\n\tv_lshl_or_b32 %1, %0, %3, %1" : "=&v"(z), "+v"(t.m) : "v"(t.o[i]), "n"(sh));
+            }
         }
     }
 };
@@ -328,6 +338,9 @@ struct WdPass {
 
     template <int G>
     static __device__ __forceinline__ void pending(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], Regs& r, const WdRt& rt, int lane, float (&alpha)[2]) {
+#ifdef LUSH_ABL_NOCONV      // timing ablation only (wrong results): the MFMA + fragment / DMA skeleton alone
+        return;
+#endif
         if constexpr (CK == WC_ACT) {
             wd_unroll<SC.first[G], SC.first[G + 1]>([&](auto kc) __attribute__((always_inline)) { item<decltype(kc)::value>(pend, xout, r, rt, lane); });
         } else if constexpr (CK == WC_ALPHA) {
@@ -415,7 +428,11 @@ struct WdPass {
         wd_wait_vm<(younger < 63 ? younger : 63)>();
 #endif
         WPROF_T(t_w1);
+#ifndef LUSH_ABL_NOBAR
         lds_barrier();
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #ifdef LUSH_PROF
         cx.prof[5] += t_w1 - t_w0;
         cx.prof[6] += __builtin_amdgcn_s_memtime() - t_w1;
@@ -458,31 +475,51 @@ struct WdPass {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-// gamma(x), gamma(d) of the tile's 256 points as fp16 into the padded image, one point per thread (pe_tile of
-// lush_mlp_dev.h with this kernel's row pitch; utils/run_lushnerf_helpers.py:334-361)
+// gamma(x), gamma(d) of the tile's 256 points as fp16 into the padded image, one point per thread
+// (utils/run_lushnerf_helpers.py:334-361).  With ONE workgroup per CU nothing hides this prologue, so it is built for
+// speed: sin / cos on the hardware unit (v_sin_f32 / v_cos_f32 take revolutions) behind an exact range reduction --
+// x / (2 pi) as a double-float hi + lo (one FMA), times the power of two (exact), v_fract (exact), + the scaled lo -- and
+// the row leaves as twelve 16-byte LDS writes.  Measured against float64 over 2^k [-2, 2], k = 0..9: 4.2e-7 absolute
+// (tests/micro/sincos_hw.hip), 1/500 of the fp16 grid this kernel rounds the result to (the two-plane bf16 kernels, which
+// carry 2^-17, keep the Cody-Waite + fdlibm form of lush_mlp_dev.h).
+__device__ __forceinline__ void wd_sincos_rev(float hi, float lo, int k, float* sn, float* cs) {
+    const float s = (float)(1 << k);
+    const float r = __builtin_amdgcn_fractf(hi * s) + lo * s;
+    *sn = __builtin_amdgcn_sinf(r);
+    *cs = __builtin_amdgcn_cosf(r);
+}
 __device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid) {
     const long long gpt = tile_pt0 + tid;
     float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (gpt < P) point_of(rays, z, S, gpt, x, d);
-    _Float16* row = reinterpret_cast<_Float16*>(peimg + tid * WD_PE_PITCH);
-    for (int u = 0; u < L_X + L_D; ++u) {
-        const bool isd = u >= L_X;
-        const int k = isd ? u - L_X : u;
-        const int base = isd ? PE_X : 0;
-        const float f = (float)(1 << k);
+    constexpr float C_HI = 0.15915494309189535f;
+    constexpr float C_LO = (float)(0.15915494309189533576888 - (double)C_HI);
+    float v[PE_X + PE_D];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float v = isd ? d[i] : x[i];
-            if (k == 0) row[base + i] = (_Float16)v;
-            float sn, cs;
-            lush_sincos(v * f, &sn, &cs);
-            row[base + 3 + 6 * k + i] = (_Float16)sn;
-            row[base + 3 + 6 * k + 3 + i] = (_Float16)cs;
-        }
+    for (int c = 0; c < PE_X + PE_D; ++c) v[c] = 0.f;      // (col 63 and cols 91..95: zero padding the K loops do read)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[i] = x[i];
+        v[PE_X + i] = d[i];
+        const float hx = x[i] * C_HI, lx = __builtin_fmaf(x[i], C_HI, -hx) + x[i] * C_LO;
+        const float hd = d[i] * C_HI, ld = __builtin_fmaf(d[i], C_HI, -hd) + d[i] * C_LO;
+#pragma unroll
+        for (int k = 0; k < L_X; ++k) wd_sincos_rev(hx, lx, k, &v[3 + 6 * k + i], &v[3 + 6 * k + 3 + i]);
+#pragma unroll
+        for (int k = 0; k < L_D; ++k) wd_sincos_rev(hd, ld, k, &v[PE_X + 3 + 6 * k + i], &v[PE_X + 3 + 6 * k + 3 + i]);
     }
-    row[PE_X_VALID] = (_Float16)0.f;      // zero padding columns that the K loops do read
+    char* row = peimg + tid * WD_PE_PITCH;
 #pragma unroll
-    for (int c = PE_X + PE_D_VALID; c < PE_X + PE_D; ++c) row[c] = (_Float16)0.f;
+    for (int c = 0; c < (PE_X + PE_D) / 8; ++c) {
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned o[1];
+            split_pair<1, DT_F16>(v[8 * c + 2 * j], v[8 * c + 2 * j + 1], o);
+            w[j] = o[0];
+        }
+        *reinterpret_cast<u32x4*>(row + c * 16) = w;
+    }
 }
 
 // acc[c][rbl][q] = b[32 rbl + 16 (q>>3) + 8 h + (q&7)] from the LDS bias block (chain_row() order, as ch_bias)

@@ -553,8 +553,12 @@ def test_variants_agree(tmp_path, planes, variant):
         scale = float(np.abs(b[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / max(scale, 1e-30)
         worst["raw" if k == "raw" else "grads"] = max(worst.get("raw" if k == "raw" else "grads", 0.0), err)
-        # measured (round 2): outputs identical (the variants keep the MFMA order); gradients 9e-7 (heads folded, fp16 hi + lo),
-        # 1.3e-5 (heads folded, bf16 hi + lo), 1.6e-6 (forward variants: atomics order), 3.4e-4 (the 256-register
-        # backward chain keeps d(gamma) in 16 bits)
-        assert np.isfinite(a[k]).all() and err < (2e-6 if k == "raw" else 2e-3), (variant, k, err)
+        # measured: backward variants leave the outputs identical; gradients 9e-7 (heads folded, fp16 hi + lo), 1.3e-5 (heads
+        # folded, bf16 hi + lo), 3.4e-4 (the 256-register backward chain keeps d(gamma) in 16 bits).  The FORWARD variants
+        # differ in their positional encoding (mlp_wide_fwd_kernel: hardware sin / cos behind an exact range reduction,
+        # 4e-7 absolute; the others: Cody-Waite + fdlibm, 7e-8): the same fp16 operand grid, but a few encodings round to
+        # the neighbouring fp16 value -- raw outputs within 1.4e-4 of each other, both within 6e-4 of the fp32 oracle
+        # (t_mlp_fwd gates 4e-3), gradients accordingly.
+        fwd_variant = variant.startswith("FWD")
+        assert np.isfinite(a[k]).all() and err < ((1e-3 if fwd_variant else 2e-6) if k == "raw" else (1e-2 if fwd_variant else 2e-3)), (variant, k, err)
     print(f"variant {variant} ({planes}): outputs differ by {worst.get('raw', 0.0):.1e}, gradients by {worst.get('grads', 0.0):.1e}")
