@@ -259,6 +259,52 @@ int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, cons
 int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays,
                          lush_stream_t stream);
 
+/* ------------------------------------------------------ the march in one call
+ * NeRFAll.render_rays_nonoise (models/lushnerf.py:481-583) -- z grid + jitter (:501-523), coarse MLP
+ * (mlpforward :234-266), raw2outputs (:296-352), sample_pdf + sort (:544-549, utils/run_lushnerf_helpers.py:566-609),
+ * fine MLP, raw2outputs -- and its autograd backward, each as ONE call that enqueues the kernels behind the
+ * piecewise entry points above on `stream`, out of one caller-provided workspace (lush_march_workspace_bytes; 256-byte
+ * aligned).  The forward leaves what the backward needs (z, raw, weights, packed weights, activation stashes) in the
+ * workspace: keep it untouched between the two calls.  render_rays (:354-479) is this plus lush_zfixed + lush_mlp_fwd of
+ * the noise net; the blur-kernel branch feeds it N (M+1) warped rays (lush_rbk_warp_fwd + lush_pack_rays_fwd). */
+typedef struct {
+    int R;                         /* marched rays */
+    int N_samples, N_importance;   /* N_importance = 0: coarse pass only */
+    float perturb, raw_noise_std;  /* > 0: the matching draws are used */
+    int white_bkgd, lindisp;
+    float near_mask;               /* eval only: render_rmnearplane / 128 (models/lushnerf.py:331-335); < 0 = off */
+    int planes_fwd;                /* plane code of the forward: 1..3 bf16 planes, 17 = one fp16 plane */
+    int planes_bwd;                /* plane code of the backward; 0 = inference (nothing is kept, lush_march_bwd refuses) */
+    int variant;                   /* LUSH_VARIANT_* bits, 0 = the product's choice */
+    int same_net;                  /* the fine pass evaluates the coarse parameters (mlp_fine is None, models/lushnerf.py:214) */
+} lush_march_cfg;
+/* The random draws of a march in the reference's shapes (see lush_draws); NULL = that draw is off. */
+typedef struct { const float *t_rand, *noise_c, *u, *noise_f; } lush_march_draws;
+/* Caller-owned outputs: rgb [R][3], depth [R], acc [R], density [R][S(+Ni)-1] of the final pass; with N_importance > 0
+ * also the coarse pass's rgb0, depth0, acc0, density0 [R][S-1] and z_std [R] (:465). */
+typedef struct { float *rgb, *depth, *acc, *density, *rgb0, *depth0, *acc0, *density0, *z_std; } lush_march_out;
+/* d loss / d (rgb_map, depth_map, acc_map, rgb0, depth0, acc0); NULL = zero.  A pass none of whose outputs
+ * received a gradient is skipped (the coarse net of the consistency branch, models/lushnerf.py:949-989). */
+typedef struct { const float *rgb, *depth, *acc, *rgb0, *depth0, *acc0; } lush_march_gout;
+
+size_t lush_march_workspace_bytes(const lush_march_cfg* cfg);     /* 0 = bad configuration */
+/* Where the forward left its by-products inside the workspace (byte offset, size): */
+#define LUSH_VIEW_Z 0             /* z_vals of the final pass [R][S(+Ni)], sorted */
+#define LUSH_VIEW_RAW 1           /* raw of the final pass [R][S(+Ni)][4] */
+#define LUSH_VIEW_WEIGHTS 2       /* compositing weights of the final pass [R][S(+Ni)] */
+#define LUSH_VIEW_Z_COARSE 3      /* z_vals of the coarse pass [R][S] */
+#define LUSH_VIEW_STASH_COARSE 4  /* activation stash of the coarse / fine MLP evaluation (tests: lush_debug_stash_layout) */
+#define LUSH_VIEW_STASH_FINE 5
+int lush_march_view(const lush_march_cfg* cfg, int which, size_t* offset, size_t* bytes);
+/* rays [R][11]; flags: the numerical-fault word (may be NULL).  fine may be NULL when same_net or N_importance == 0. */
+int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,
+                   const lush_march_draws* draws, const lush_march_out* out, void* workspace, int* flags, lush_stream_t stream);
+/* Parameter gradients are ADDED to g_coarse / g_fine (fp32 atomics; same_net: everything goes to g_coarse);
+ * drays [R][11] accumulates d loss / d ray batch (columns 0..5, 8..10); z_samples are detached as in the reference (:546). */
+int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,
+                   const lush_march_draws* draws, const lush_march_gout* gout, void* workspace, const lush_mlp_grads* g_coarse,
+                   const lush_mlp_grads* g_fine, float* drays, lush_stream_t stream);
+
 /* ---------------------------------------------------------------------- Adam
  * torch.optim.Adam step on a flat segment (run_lushnerf.py:368-371, 675-685). */
 int lush_adam(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1,

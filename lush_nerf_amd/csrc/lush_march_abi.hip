@@ -1,0 +1,176 @@
+// lush-march: ONE C-ABI call per ray march: lush_march_fwd / lush_march_bwd are
+// NeRFAll.render_rays_nonoise (models/lushnerf.py:481-583) and its autograd backward, composed on the host from the
+// kernels behind the piecewise entry points -- z grid + jitter, weight packing, coarse MLP, compositing, sample_pdf +
+// merge, fine MLP, compositing -- enqueued on the caller's stream, working out of ONE caller-provided workspace whose
+// size is queried first (lush_march_workspace_bytes).  No allocation, no synchronisation, no state between calls: what
+// the backward needs (z, raw, weights, the packed weights, the activation stashes) stays in the workspace.
+#include "lush_common.h"
+#include "lush_host.h"
+#include "../../include/lush_march.h"
+
+using namespace lush;
+
+namespace {
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int nplanes(int c) { return c == PLANES_F16 ? 1 : c; }
+// what the forward keeps for the backward (ops.stash_code): an fp16 forward stashes its single fp16 plane, otherwise the
+// first min(forward planes, backward planes) bf16 planes
+inline int stash_code(int pf, int pb) { return pb == 0 ? 0 : (pf == PLANES_F16 ? PLANES_F16 : (pf < nplanes(pb) ? pf : nplanes(pb))); }
+
+struct Layout {
+    size_t zc, wc, rawc, pkc, stashc;            // coarse pass
+    size_t zf, zs, wf, rawf, pkf, stashf;        // fine pass (N_importance > 0)
+    size_t pkbc, pkbf;                           // packed weights of the backward when its plane code differs
+    size_t draw, dstash, dpts;                   // backward scratch (shared by the two passes)
+    size_t total;
+    size_t stashc_bytes, stashf_bytes;
+};
+
+bool layout(const lush_march_cfg* c, Layout& L) {
+    if (!c || c->R <= 0 || c->N_samples < 2 || c->N_importance < 0) return false;
+    const long long R = c->R, S = c->N_samples, Ni = c->N_importance, Sf = S + Ni;
+    const int pf = c->planes_fwd, pb = c->planes_bwd, sc = stash_code(pf, pb);
+    const size_t pk_f = lush_mlp_packed_bytes(0, pf), pk_b = pb ? lush_mlp_packed_bytes(0, pb) : 0;
+    if (pk_f == 0 || (pb && pk_b == 0)) return false;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
+    L = Layout{};
+    L.zc = take(R * S * 4); L.wc = take(R * S * 4); L.rawc = take(R * S * 16); L.pkc = take(pk_f);
+    L.stashc_bytes = lush_mlp_stash_bytes(0, pf, sc, R * S);
+    L.stashc = take(L.stashc_bytes);
+    if (Ni > 0) {
+        L.zf = take(R * Sf * 4); L.zs = take(R * Ni * 4); L.wf = take(R * Sf * 4); L.rawf = take(R * Sf * 16);
+        L.pkf = c->same_net ? L.pkc : take(pk_f);
+        L.stashf_bytes = lush_mlp_stash_bytes(0, pf, sc, R * Sf);
+        L.stashf = take(L.stashf_bytes);
+    }
+    if (pb) {
+        const long long Pmax = R * (Ni > 0 ? Sf : S);
+        L.pkbc = pb == pf ? L.pkc : take(pk_b);
+        L.pkbf = Ni > 0 ? (pb == pf ? L.pkf : (c->same_net ? L.pkbc : take(pk_b))) : 0;
+        L.draw = take(Pmax * 16);
+        L.dstash = take(lush_mlp_dstash_bytes(0, pb, Pmax));
+        L.dpts = take(Pmax * 32);
+    }
+    L.total = off;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t lush_march_workspace_bytes(const lush_march_cfg* cfg) {
+    Layout L;
+    return layout(cfg, L) ? L.total : 0;
+}
+
+int lush_march_view(const lush_march_cfg* cfg, int which, size_t* offset, size_t* bytes) {
+    Layout L;
+    if (!layout(cfg, L) || !offset || !bytes) return set_error("lush_march_view: bad configuration");
+    const long long R = cfg->R, S = cfg->N_samples, Ni = cfg->N_importance, Sf = S + Ni;
+    const bool fine = Ni > 0;
+    switch (which) {
+        case LUSH_VIEW_Z: *offset = fine ? L.zf : L.zc; *bytes = R * (fine ? Sf : S) * 4; return 0;
+        case LUSH_VIEW_RAW: *offset = fine ? L.rawf : L.rawc; *bytes = R * (fine ? Sf : S) * 16; return 0;
+        case LUSH_VIEW_WEIGHTS: *offset = fine ? L.wf : L.wc; *bytes = R * (fine ? Sf : S) * 4; return 0;
+        case LUSH_VIEW_Z_COARSE: *offset = L.zc; *bytes = R * S * 4; return 0;
+        case LUSH_VIEW_STASH_COARSE: *offset = L.stashc; *bytes = L.stashc_bytes; return 0;
+        case LUSH_VIEW_STASH_FINE:
+            if (!fine) return set_error("lush_march_view: no fine pass");
+            *offset = L.stashf; *bytes = L.stashf_bytes; return 0;
+        default: return set_error("lush_march_view: unknown view");
+    }
+}
+
+int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,
+                   const lush_march_draws* draws, const lush_march_out* out, void* workspace, int* flags, lush_stream_t st) {
+    Layout L;
+    if (!layout(cfg, L)) return set_error("lush_march_fwd: bad configuration");
+    if (!rays || !coarse || !out || !workspace) return set_error("lush_march_fwd: rays, coarse parameters, outputs and workspace are required");
+    const int R = cfg->R, S = cfg->N_samples, Ni = cfg->N_importance, Sf = S + Ni;
+    const bool two = Ni > 0;
+    if (two && !cfg->same_net && !fine) return set_error("lush_march_fwd: the fine parameters are required");
+    if (!out->rgb || !out->depth || !out->acc || !out->density) return set_error("lush_march_fwd: rgb, depth, acc, density outputs are required");
+    if (two && (!out->rgb0 || !out->depth0 || !out->acc0 || !out->density0 || !out->z_std)) return set_error("lush_march_fwd: the coarse outputs and z_std are required when N_importance > 0");
+    const lush_mlp_params* pfine = cfg->same_net ? coarse : fine;
+    char* w = (char*)workspace;
+    const int pf = cfg->planes_fwd, sc = stash_code(pf, cfg->planes_bwd), var = cfg->variant;
+    const float* t_rand = draws && cfg->perturb > 0.f ? draws->t_rand : nullptr;
+    const float* noise_c = draws && cfg->raw_noise_std > 0.f ? draws->noise_c : nullptr;
+    const float* u = draws && cfg->perturb > 0.f ? draws->u : nullptr;
+    const float* noise_f = draws && cfg->raw_noise_std > 0.f ? draws->noise_f : nullptr;
+    float* zc = (float*)(w + L.zc);
+    int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, st);
+    if (rc) return rc;
+    rc = lush_mlp_pack(0, pf, coarse, w + L.pkc, st);
+    if (rc) return rc;
+    rc = lush_mlp_fwd(0, pf, sc, rays, zc, R, S, w + L.pkc, coarse, (float*)(w + L.rawc), w + L.stashc, var, st);
+    if (rc) return rc;
+    // the coarse pass's results are rgb0 .. when a fine pass follows, else the final ones
+    rc = lush_composite_fwd((const float*)(w + L.rawc), zc, rays, R, S, noise_c, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
+                            two ? out->rgb0 : out->rgb, two ? out->depth0 : out->depth, two ? out->acc0 : out->acc, (float*)(w + L.wc),
+                            two ? out->density0 : out->density, flags, two ? LUSH_FAULT_COARSE_SHIFT : 0, st);
+    if (rc || !two) return rc;
+    float* zf = (float*)(w + L.zf);
+    rc = lush_sample_merge(zc, (const float*)(w + L.wc), R, S, Ni, u, zf, (float*)(w + L.zs), out->z_std, flags, st);
+    if (rc) return rc;
+    if (!cfg->same_net) {
+        rc = lush_mlp_pack(0, pf, pfine, w + L.pkf, st);
+        if (rc) return rc;
+    }
+    rc = lush_mlp_fwd(0, pf, sc, rays, zf, R, Sf, w + L.pkf, pfine, (float*)(w + L.rawf), w + L.stashf, var, st);
+    if (rc) return rc;
+    return lush_composite_fwd((const float*)(w + L.rawf), zf, rays, R, Sf, noise_f, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
+                              out->rgb, out->depth, out->acc, (float*)(w + L.wf), out->density, flags, 0, st);
+}
+
+int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,
+                   const lush_march_draws* draws, const lush_march_gout* g, void* workspace, const lush_mlp_grads* g_coarse,
+                   const lush_mlp_grads* g_fine, float* drays, lush_stream_t st) {
+    Layout L;
+    if (!layout(cfg, L)) return set_error("lush_march_bwd: bad configuration");
+    if (cfg->planes_bwd == 0) return set_error("lush_march_bwd: the forward ran as inference (planes_bwd = 0): nothing was kept");
+    if (!rays || !coarse || !g || !workspace || !drays) return set_error("lush_march_bwd: rays, parameters, output gradients, workspace and drays are required");
+    const int R = cfg->R, S = cfg->N_samples, Ni = cfg->N_importance, Sf = S + Ni;
+    const bool two = Ni > 0;
+    const lush_mlp_params* pfine = cfg->same_net ? coarse : fine;
+    const lush_mlp_grads* gfine = cfg->same_net ? g_coarse : g_fine;
+    char* w = (char*)workspace;
+    const int pf = cfg->planes_fwd, pb = cfg->planes_bwd, sc = stash_code(pf, pb), var = cfg->variant;
+    const float* noise_c = draws && cfg->raw_noise_std > 0.f ? draws->noise_c : nullptr;
+    const float* noise_f = draws && cfg->raw_noise_std > 0.f ? draws->noise_f : nullptr;
+    float* draw = (float*)(w + L.draw);
+    float* dpts = (float*)(w + L.dpts);
+    auto pass = [&](const lush_mlp_params* prm, const lush_mlp_grads* gr, size_t zoff, size_t rawoff, size_t stashoff, size_t pkoff, size_t pkboff,
+                    bool repack, int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc) -> int {
+        if (!gr) return set_error("lush_march_bwd: gradient buffers of a pass that received output gradients are required");
+        const float* z = (const float*)(w + zoff);
+        int rc = lush_composite_bwd((const float*)(w + rawoff), z, rays, R, Sp, noise, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
+                                    g_rgb, g_depth, g_acc, draw, drays, st);
+        if (rc) return rc;
+        if (repack) {       // the backward computes with another plane code than the forward: its own fragments
+            rc = lush_mlp_pack(0, pb, prm, w + pkboff, st);
+            if (rc) return rc;
+        }
+        rc = lush_mlp_bwd(0, sc, pb, rays, z, R, Sp, w + (pb == pf ? pkoff : pkboff), prm, draw, w + stashoff, w + L.dstash, gr, dpts, var, st);
+        if (rc) return rc;
+        return lush_ray_grad_reduce(dpts, z, R, Sp, drays, st);
+    };
+    int rc = 0;
+    const bool any_main = g->rgb || g->depth || g->acc;
+    const bool any_c = two ? (g->rgb0 || g->depth0 || g->acc0) : any_main;
+    bool packed_b_c = false;
+    if (two && any_main) {
+        rc = pass(pfine, gfine, L.zf, L.rawf, L.stashf, L.pkf, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc);
+        if (rc) return rc;
+        packed_b_c = cfg->same_net && pb != pf;     // the shared net's backward fragments are packed now
+    }
+    if (any_c)
+        rc = pass(coarse, g_coarse, L.zc, L.rawc, L.stashc, L.pkc, L.pkbc, pb != pf && !packed_b_c, S, noise_c, two ? g->rgb0 : g->rgb,
+                  two ? g->depth0 : g->depth, two ? g->acc0 : g->acc);
+    return rc;
+}
+
+}  // extern "C"

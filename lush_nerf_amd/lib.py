@@ -14,7 +14,7 @@ from typing import Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("LUSH_SO") or os.path.join(HERE, "liblush_march.so")   # LUSH_SO: developer ablation builds
-SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_mlp_wide.hip", "lush_abi.hip"]
+SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_mlp_wide.hip", "lush_abi.hip", "lush_march_abi.hip"]
 HEADERS = ["lush_common.h", "lush_mlp.h", "lush_mlp_dev.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
 
 _lib = None
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
             return obj
-        with ThreadPoolExecutor(max_workers=min(5, len(SOURCES))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
             objs = list(ex.map(compile_one, SOURCES))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", SO_PATH + ".tmp"]
         if verbose:
@@ -80,6 +80,26 @@ class RbkParams(C.Structure):
         [(n, C.c_void_p) for n in ("w_rb", "b_rb", "w_vb", "b_vb", "w_wb", "b_wb", "w_r", "b_r",
                                    "w_v", "b_v", "w_w", "b_w")]
 
+
+class MarchCfgC(C.Structure):       # include/lush_march.h: lush_march_cfg
+    _fields_ = [("R", C.c_int), ("N_samples", C.c_int), ("N_importance", C.c_int), ("perturb", C.c_float),
+                ("raw_noise_std", C.c_float), ("white_bkgd", C.c_int), ("lindisp", C.c_int), ("near_mask", C.c_float),
+                ("planes_fwd", C.c_int), ("planes_bwd", C.c_int), ("variant", C.c_int), ("same_net", C.c_int)]
+
+
+class MarchDraws(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("t_rand", "noise_c", "u", "noise_f")]
+
+
+class MarchOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rgb", "depth", "acc", "density", "rgb0", "depth0", "acc0", "density0", "z_std")]
+
+
+class MarchGout(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rgb", "depth", "acc", "rgb0", "depth0", "acc0")]
+
+
+VIEW_Z, VIEW_RAW, VIEW_WEIGHTS, VIEW_Z_COARSE, VIEW_STASH_COARSE, VIEW_STASH_FINE = range(6)
 
 _p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 _SIGS = {
@@ -117,6 +137,12 @@ _SIGS = {
     "lush_mlp_bwd_chain": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _i, _p], _i),
     "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(MlpParams), _i, _p], _i),
     "lush_ray_grad_reduce": ([_p, _p, _i, _i, _p, _p], _i),
+    "lush_march_workspace_bytes": ([C.POINTER(MarchCfgC)], _sz),
+    "lush_march_view": ([C.POINTER(MarchCfgC), _i, C.POINTER(_sz), C.POINTER(_sz)], _i),
+    "lush_march_fwd": ([C.POINTER(MarchCfgC), _p, C.POINTER(MlpParams), C.POINTER(MlpParams), C.POINTER(MarchDraws),
+                        C.POINTER(MarchOut), _p, _p, _p], _i),
+    "lush_march_bwd": ([C.POINTER(MarchCfgC), _p, C.POINTER(MlpParams), C.POINTER(MlpParams), C.POINTER(MarchDraws),
+                        C.POINTER(MarchGout), _p, C.POINTER(MlpParams), C.POINTER(MlpParams), _p, _p], _i),
     "lush_adam": ([_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p], _i),
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }

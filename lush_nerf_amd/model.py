@@ -92,9 +92,9 @@ class Rigid_Blurring_Kernel(nn.Module):
             t += [m.weight, m.bias]
         return t
 
-    def forward(self, rays, rays_info, grad_mask=None):
+    def forward(self, rays, rays_info, grad_mask=None, hooks=None):
         """rays [N,3,2], rays_info['images_idx'] [N,1] -> (new_rays [N*(M+1),3,2], ccw [N,M+1])."""
-        return ops.RbkWarp.apply(rays, rays_info['images_idx'], self.num_motion, self.rv_window, grad_mask,
+        return ops.RbkWarp.apply(rays, rays_info['images_idx'], self.num_motion, self.rv_window, grad_mask, hooks,
                                  *self.tensors())
 
     def rbk_weighted_sum(self, rgb, depth, acc, extras, ccw):
@@ -148,6 +148,9 @@ class NeRFAll(nn.Module):
         # fetches and clears it.  Not persistent: the reference state_dict has exactly 108 keys.
         self.register_buffer("_faults", torch.zeros(1, dtype=torch.int32), persistent=False)
         self.rng_stream = 0      # Philox stream of the march draws; the trainer sets it to the data-parallel rank
+        # per-model switches of the ops (timer / stash hand-out for tests / gradient sink / draw counter): carried here and
+        # handed to every op, nothing process-global (DataParallel worker threads share no state)
+        self.hooks = ops.Hooks()
 
     # ------------------------------------------------------------------ helpers
     def tonemapping(self, x, noise_raw=None):
@@ -172,7 +175,7 @@ class NeRFAll(nn.Module):
         helpers:578) unless given explicitly (parity tests): one device-side Philox launch."""
         if draws is not None:
             return draws
-        return ops.march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, stream_id=self.rng_stream)
+        return ops.march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, stream_id=self.rng_stream, hooks=self.hooks)
 
     def _march(self, ray_batch, N_samples, N_importance, perturb, raw_noise_std, white_bkgd, lindisp, retraw,
                draws=None):
@@ -183,7 +186,7 @@ class NeRFAll(nn.Module):
                        raw_noise_std=float(raw_noise_std), white_bkgd=bool(white_bkgd), lindisp=bool(lindisp),
                        near_mask=near_mask, precision=self.precision, has_fine=self.mlp_fine is not None,
                        want_grad=torch.is_grad_enabled(),
-                       flags=self._faults if self._faults.is_cuda else None)
+                       flags=self._faults if self._faults.is_cuda else None, hooks=self.hooks)
         R = ray_batch.shape[0]
         d = self._draws(R, N_samples, N_importance, perturb, raw_noise_std, ray_batch.device, draws)
         coarse = self.mlp_coarse.tensors()
@@ -198,7 +201,7 @@ class NeRFAll(nn.Module):
 
     def _noise(self, ray_batch, N_samples, lindisp):
         return ops.NoiseMlp.apply(ray_batch.detach(), N_samples, 16, bool(lindisp), self.precision.noise(),
-                                  torch.is_grad_enabled(),
+                                  torch.is_grad_enabled(), self.hooks,
                                   *self.mlp_noise_coarse.tensors())
 
     # ------------------------------------------------------------------ render_rays trio
@@ -294,7 +297,7 @@ class NeRFAll(nn.Module):
             if self.blur_kernel_net is not None and not force_baseline and self.blur_model_type == 'dpnerf':
                 kwargs['img_idx'] = rays_info['images_idx'].squeeze(-1)
                 mask = kernel_pixel if allkernel else None      # torch.where(mask, x, x.detach()) (:641-643)
-                rays_transform, ccw = self.mlp_rbk(rays, rays_info, grad_mask=mask)
+                rays_transform, ccw = self.mlp_rbk(rays, rays_info, grad_mask=mask, hooks=self.hooks)
                 rgb, depth, acc, extras = self.render_train_scene(H, W, K, chunk, rays_transform, **kwargs)
                 noise_raw = self.render_train_noise(H, W, K, chunk, rays, **kwargs)
                 rgb_noise = ops.NoiseAct.apply(noise_raw)
@@ -354,19 +357,6 @@ class NeRFAll(nn.Module):
         rgb, _, _, _ = self.render_train_scene(H, W, K, chunk=chunk, rays=rays.detach(), render_noise=False,
                                                **render_kwargs)
         return rgb.reshape(V, samples.numel(), 3), certainty
-
-
-def get_rays(H, W, K, c2w):
-    """utils/run_lushnerf_helpers.py:517-528 in torch ops (kept for callers that want the host formula; the
-    product paths use ops.gen_rays / ops.gen_rays_image)."""
-    dev = c2w.device
-    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=dev), torch.linspace(0, H - 1, H, device=dev),
-                          indexing='ij')
-    i, j = i.t(), j.t()
-    dirs = torch.stack([(i + (0.5 - K[0][2])) / K[0][0], -(j + (0.5 - K[1][2])) / K[1][1], -torch.ones_like(i)], -1)
-    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
-    rays_o = c2w[:3, -1].expand(rays_d.shape)
-    return rays_o, rays_d
 
 
 def load_reference_weights(model: NeRFAll, weights: Dict[str, "torch.Tensor"]):

@@ -94,13 +94,26 @@ class KernelTimer:
         return out
 
 
-TIMER: Optional[KernelTimer] = None
-# Test hook (tests/ only): when set to a dict, March / NoiseMlp forward leave their activation stashes in it
-# ("stash_c", "stash_f", "stash_noise" + the point counts) so a test can read the ReLU decisions the GPU took.
-DEBUG_KEEP: Optional[dict] = None
+@dataclass
+class Hooks:
+    """Per-model switches of the ops (carried by NeRFAll / Trainer and handed to every op: nothing here is process-global,
+    the reference calls its model from DataParallel worker threads).
+      timer: bench.py -- HIP-event timing of the MLP kernel groups; the march then runs kernel group by kernel group
+             through the piecewise entry points instead of the one-call lush_march_fwd / lush_march_bwd;
+      keep:  tests -- a dict that receives the activation stashes of the last forward ("stash_c", "stash_f",
+             "stash_noise" + the point counts), so a test can read the ReLU decisions the GPU took;
+      sink:  Trainer.step -- parameter gradients are accumulated by the weight-gradient kernels' own atomics straight
+             into each parameter's existing .grad buffer (the trainer's flat gradient) and autograd receives None for
+             them: no per-tensor temporaries, zero-fills or `grad += tmp` kernels on the step;
+      draw_offset: Philox offset of the next lush_draws call (march_draws)."""
+    timer: Optional[KernelTimer] = None
+    keep: Optional[dict] = None
+    sink: bool = False
+    draw_offset: int = 0
 
 
-def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0, variant: int = 0):
+def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0, variant: int = 0,
+                timer: Optional[KernelTimer] = None):
     """stash_planes: planes kept for the backward (default: all `planes`)."""
     R, S = z.shape
     sp = nplanes(stash_planes or planes) if want_stash else 0   # 0 = inference: only the gamma-row workspace
@@ -108,7 +121,7 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
     stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, sp, R * S), dtype=torch.uint8,
                         device=rays.device)
     st = lib.mlp_struct(tensors, _NL[net])
-    ev = TIMER.span("mlp_fwd" if net == NET_NERF else "noise_fwd", R * S) if TIMER is not None else None
+    ev = timer.span("mlp_fwd" if net == NET_NERF else "noise_fwd", R * S) if timer is not None else None
     if ev:
         ev[0].record()
     lib.call("lush_mlp_fwd", net, planes, sp, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st),
@@ -118,15 +131,9 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
     return raw, (stash if want_stash else None)
 
 
-# When True (set by Trainer.step), parameter gradients are accumulated by the weight-gradient kernels' own
-# atomics straight into each parameter's existing .grad buffer (the trainer's flat gradient) and autograd
-# receives None for them: no per-tensor temporaries, zero-fills or `grad += tmp` kernels on the step.
-ACCUMULATE_INTO_PARAM_GRAD = False
-
-
-def grad_sink(tensors):
-    """The .grad buffers of `tensors` if accumulation into them is enabled and every one is usable, else None."""
-    if not ACCUMULATE_INTO_PARAM_GRAD:
+def grad_sink(tensors, hooks: Optional[Hooks]):
+    """The .grad buffers of `tensors` if accumulation into them is enabled (hooks.sink) and every one is usable, else None."""
+    if hooks is None or not hooks.sink:
         return None
     gs = [getattr(t, "grad", None) for t in tensors]
     for g, t in zip(gs, tensors):
@@ -135,7 +142,8 @@ def grad_sink(tensors):
     return gs
 
 
-def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash, sink=None, variant: int = 0):
+def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash, sink=None, variant: int = 0,
+                 timer: Optional[KernelTimer] = None):
     """Returns (list of parameter grads in `tensors` order, dpts [P][8]).  With `sink` (a list of fp32
     buffers, one per tensor) the gradients are ADDED to those buffers and the returned list holds None."""
     R, S = z.shape
@@ -151,15 +159,15 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
             o += t.numel()
     dpts = torch.empty(R * S, 8, dtype=torch.float32, device=dev)
     st, gs = lib.mlp_struct(tensors, _NL[net]), lib.mlp_struct(grads, _NL[net])
-    timed = TIMER is not None and net == NET_NERF
-    ev = TIMER.span("mlp_bwd_chain", R * S) if timed else None
+    timed = timer is not None and net == NET_NERF
+    ev = timer.span("mlp_bwd_chain", R * S) if timed else None
     if ev:
         ev[0].record()
     lib.call("lush_mlp_bwd_chain", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b),
              C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), int(variant), _stream())
     if ev:
         ev[1].record()
-    ev = TIMER.span("mlp_bwd_weights", R * S) if timed else None
+    ev = timer.span("mlp_bwd_weights", R * S) if timed else None
     if ev:
         ev[0].record()
     lib.call("lush_mlp_bwd_weights", net, planes_f, planes_b, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash),
@@ -212,10 +220,13 @@ class MarchCfg:
     has_fine: bool = True
     want_grad: bool = True           # set by the caller from torch.is_grad_enabled() (it is off inside forward)
     flags: Optional[torch.Tensor] = None   # int32 [1] numerical-fault word (include/lush_march.h LUSH_FAULT_*), or None
+    hooks: Optional[Hooks] = None
 
     def __post_init__(self):
         if self.precision is None:
             self.precision = Precision()
+        if self.hooks is None:
+            self.hooks = Hooks()
 
 
 def zgrid(batch, S, lindisp, t_rand):
@@ -263,14 +274,28 @@ def _opt(g):
     return None if g is None else _f32(g)
 
 
+def _flat_grads(tensors, dev):
+    """One zero-filled flat fp32 buffer and its per-tensor views."""
+    flat = torch.zeros(sum(t.numel() for t in tensors), dtype=torch.float32, device=dev)
+    views, o = [], 0
+    for t in tensors:
+        views.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    return views
+
+
 class March(torch.autograd.Function):
     """NeRFAll.render_rays_nonoise (models/lushnerf.py:481-583) as one differentiable op:
     z grid + jitter -> coarse MLP -> compositing -> sample_pdf + merge -> fine MLP ->
     compositing.  Differentiable w.r.t. the ray batch (columns 0..5, 8..10) and every MLP
     parameter; z_samples are detached exactly as in the reference (:546).
 
+    Forward and backward are ONE C-ABI call each (lush_march_fwd / lush_march_bwd, include/lush_march.h) working out of
+    one workspace tensor; with cfg.hooks.timer set (bench.py's kernel-group timing) the same kernels run through the
+    piecewise entry points, bracketed by HIP events.
+
     Outputs: rgb, depth, acc, density, raw, weights, z_vals [, rgb0, depth0, acc0, density0, z_std].
-    density / raw / weights / z_vals / z_std are returned non-differentiable.
+    density / raw / weights / z_vals / z_std are returned non-differentiable (raw, weights, z_vals are views of the workspace).
     """
 
     @staticmethod
@@ -279,78 +304,178 @@ class March(torch.autograd.Function):
         batch = _f32(batch)                  # outputs are all unused (the coarse net of the consistency branch) is skipped
         coarse = [_f32(p) for p in params[:n_coarse]]
         fine = [_f32(p) for p in params[n_coarse:]]
-        if not fine:
+        same = not fine
+        if same:
             fine = coarse
-        pf, pb = cfg.precision.fwd, cfg.precision.bwd
         need_grad = cfg.want_grad and any(ctx.needs_input_grad)
-        t_rand = _opt(draws.get("t_rand")) if cfg.perturb > 0 else None
-        noise_c = _opt(draws.get("noise_c")) if cfg.raw_noise_std > 0 else None
-        zc = zgrid(batch, cfg.N_samples, cfg.lindisp, t_rand)
-        pk_c = mlp_pack(NET_NERF, pf, coarse)
-        var = cfg.precision.variant
-        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb), var)
-        rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, noise_c, cfg,
-                                                          lib.FAULT_COARSE_SHIFT if cfg.N_importance > 0 else 0)
-        outs = [rgb, depth, acc, density]
-        saved = dict(zc=zc, raw_c=raw_c, noise_c=noise_c, stash_c=stash_c)
-        z_last, raw_last = zc, raw_c
-        if cfg.N_importance > 0:
-            u = _opt(draws.get("u")) if cfg.perturb > 0 else None
-            noise_f = _opt(draws.get("noise_f")) if cfg.raw_noise_std > 0 else None
-            zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, u, cfg.flags)
-            same = fine is coarse
-            pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
-            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb), var)
-            rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, noise_f, cfg)
-            outs = [rgb1, depth1, acc1, density1]
-            saved.update(zf=zf, raw_f=raw_f, noise_f=noise_f, stash_f=stash_f)
-            z_last, raw_last, w_last = zf, raw_f, weights1
-        else:
-            w_last = weights
-        R = batch.shape[0]
-        outs += [raw_last.view(R, -1, 4), w_last, z_last]
-        if cfg.N_importance > 0:
-            outs += [rgb, depth, acc, density, z_std]
-        if DEBUG_KEEP is not None:
-            DEBUG_KEEP.update(stash_c=saved.get("stash_c"), stash_f=saved.get("stash_f"), P_c=zc.numel(),
-                              P_f=saved["zf"].numel() if "zf" in saved else 0, batch=batch)
-        if pf == pb:      # the packed buffer holds forward and transposed fragments: the backward reuses it
-            saved.update(pk_c=pk_c, pk_f=pk_f if cfg.N_importance > 0 else None)
-        ctx.cfg, ctx.n_coarse, ctx.n_params = cfg, n_coarse, len(params)
-        ctx.batch, ctx.coarse, ctx.fine, ctx.saved = batch, coarse, fine, saved
+        d = {}
+        if cfg.perturb > 0:
+            d["t_rand"] = _opt(draws.get("t_rand"))
+            d["u"] = _opt(draws.get("u")) if cfg.N_importance > 0 else None
+        if cfg.raw_noise_std > 0:
+            d["noise_c"] = _opt(draws.get("noise_c"))
+            d["noise_f"] = _opt(draws.get("noise_f")) if cfg.N_importance > 0 else None
+        ctx.cfg, ctx.n_coarse, ctx.n_params, ctx.same, ctx.need_grad = cfg, n_coarse, len(params), same, need_grad
+        ctx.n_c = len(coarse)
+        fwd = March._forward_piecewise if cfg.hooks.timer is not None else March._forward_fused
+        outs, saved = fwd(ctx, batch, cfg, d, coarse, fine, same, need_grad)
+        ctx.draw_keys = [k for k in ("t_rand", "noise_c", "u", "noise_f") if d.get(k) is not None]
+        ctx.n_saved = len(saved)
+        ctx.save_for_backward(batch, *saved, *[d[k] for k in ctx.draw_keys], *coarse, *([] if same else fine))
         nd = [outs[3], outs[4], outs[5], outs[6]] + ([outs[10], outs[11]] if cfg.N_importance > 0 else [])
         ctx.mark_non_differentiable(*nd)
         return tuple(outs)
 
+    # ------------------------------------------------------------------ one call per direction
     @staticmethod
-    def backward(ctx, *g):
-        cfg, batch, sv = ctx.cfg, ctx.batch, ctx.saved
+    def _c_cfg(cfg: MarchCfg, R: int, same: bool, need_grad: bool):
         pf, pb = cfg.precision.fwd, cfg.precision.bwd
+        return lib.MarchCfgC(R, cfg.N_samples, cfg.N_importance, float(cfg.perturb), float(cfg.raw_noise_std), int(cfg.white_bkgd),
+                             int(cfg.lindisp), float(cfg.near_mask), pf, pb if need_grad else 0, int(cfg.precision.variant), int(same))
+
+    @staticmethod
+    def _view(ws, c, which, shape):
+        off, nbytes = C.c_size_t(), C.c_size_t()
+        lib.call("lush_march_view", C.byref(c), which, C.byref(off), C.byref(nbytes))
+        return ws[off.value:off.value + nbytes.value].view(torch.float32).view(*shape)
+
+    @staticmethod
+    def _forward_fused(ctx, batch, cfg, d, coarse, fine, same, need_grad):
+        R, S, Ni, dev = batch.shape[0], cfg.N_samples, cfg.N_importance, batch.device
+        Sl = S + Ni
+        c = March._c_cfg(cfg, R, same, need_grad)
+        nbytes = lib.load().lush_march_workspace_bytes(C.byref(c))
+        if nbytes == 0:
+            raise RuntimeError("lush_march_workspace_bytes: bad configuration")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        rgb, depth, acc, density = f(R, 3), f(R), f(R), f(R, Sl - 1)
+        o = lib.MarchOut(rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), density.data_ptr())
+        if Ni > 0:
+            rgb0, depth0, acc0, density0, z_std = f(R, 3), f(R), f(R), f(R, S - 1), f(R)
+            o.rgb0, o.depth0, o.acc0, o.density0, o.z_std = (t.data_ptr() for t in (rgb0, depth0, acc0, density0, z_std))
+        dr = lib.MarchDraws(*(None if d.get(k) is None else d[k].data_ptr() for k in ("t_rand", "noise_c", "u", "noise_f")))
+        stc, stf = lib.mlp_struct(coarse, _NL[NET_NERF]), lib.mlp_struct(fine, _NL[NET_NERF])
+        lib.call("lush_march_fwd", C.byref(c), lib.ptr(batch), C.byref(stc), C.byref(stf), C.byref(dr), C.byref(o), lib.ptr(ws),
+                 lib.ptr(cfg.flags), _stream())
+        outs = [rgb, depth, acc, density, March._view(ws, c, lib.VIEW_RAW, (R, Sl, 4)), March._view(ws, c, lib.VIEW_WEIGHTS, (R, Sl)),
+                March._view(ws, c, lib.VIEW_Z, (R, Sl))]
+        if Ni > 0:
+            outs += [rgb0, depth0, acc0, density0, z_std]
+        if cfg.hooks.keep is not None and need_grad:
+            def raw_view(which):
+                off, nb = C.c_size_t(), C.c_size_t()
+                lib.call("lush_march_view", C.byref(c), which, C.byref(off), C.byref(nb))
+                return ws[off.value:off.value + nb.value]
+            cfg.hooks.keep.update(stash_c=raw_view(lib.VIEW_STASH_COARSE), stash_f=raw_view(lib.VIEW_STASH_FINE) if Ni > 0 else None,
+                                  P_c=R * S, P_f=R * Sl if Ni > 0 else 0, batch=batch)
+        ctx.fused = True
+        return outs, [ws]
+
+    @staticmethod
+    def _backward_fused(ctx, g, batch, saved, d, coarse, fine):
+        cfg = ctx.cfg
+        (ws,) = saved
+        R, fine_on = batch.shape[0], cfg.N_importance > 0
+        c = March._c_cfg(cfg, R, ctx.same, True)
+        gp = [_opt(g[0]), _opt(g[1]), _opt(g[2])] + ([_opt(g[7]), _opt(g[8]), _opt(g[9])] if fine_on else [None, None, None])
+        go = lib.MarchGout(*(None if t is None else t.data_ptr() for t in gp))
+        any_main = any(t is not None for t in gp[:3])
+        any_c = any(t is not None for t in gp[3:]) if fine_on else any_main
+        ran_f, ran_c = fine_on and any_main, any_c
+
+        def grads_for(tensors, ran):
+            if not ran:
+                return None, [None] * len(tensors)
+            sink = grad_sink(tensors, cfg.hooks)
+            if sink is not None:
+                return sink, [None] * len(tensors)
+            v = _flat_grads(tensors, batch.device)
+            return v, v
+        if ctx.same:
+            buf_c, ret_c = grads_for(coarse, ran_f or ran_c)
+            buf_f, ret_f = None, []
+        else:
+            buf_c, ret_c = grads_for(coarse, ran_c)
+            buf_f, ret_f = grads_for(fine, ran_f)
+        drays = torch.zeros_like(batch)
+        dr = lib.MarchDraws(*(None if d.get(k) is None else d[k].data_ptr() for k in ("t_rand", "noise_c", "u", "noise_f")))
+        stc, stf = lib.mlp_struct(coarse, _NL[NET_NERF]), lib.mlp_struct(fine, _NL[NET_NERF])
+        gc = lib.mlp_struct(buf_c, _NL[NET_NERF]) if buf_c is not None else None
+        gf = lib.mlp_struct(buf_f, _NL[NET_NERF]) if buf_f is not None else None
+        lib.call("lush_march_bwd", C.byref(c), lib.ptr(batch), C.byref(stc), C.byref(stf), C.byref(dr), C.byref(go), lib.ptr(ws),
+                 None if gc is None else C.byref(gc), None if gf is None else C.byref(gf), lib.ptr(drays), _stream())
+        return drays, ret_c, ret_f
+
+    # ------------------------------------------------------------------ kernel group by kernel group (bench.py's timing pass)
+    @staticmethod
+    def _forward_piecewise(ctx, batch, cfg, d, coarse, fine, same, need_grad):
+        pf, pb, var, tm = cfg.precision.fwd, cfg.precision.bwd, cfg.precision.variant, cfg.hooks.timer
+        zc = zgrid(batch, cfg.N_samples, cfg.lindisp, d.get("t_rand"))
+        pk_c = mlp_pack(NET_NERF, pf, coarse)
+        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb), var, tm)
+        rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, d.get("noise_c"), cfg,
+                                                          lib.FAULT_COARSE_SHIFT if cfg.N_importance > 0 else 0)
+        outs = [rgb, depth, acc, density]
+        z_last, raw_last, w_last = zc, raw_c, weights
+        saved = [zc, raw_c, stash_c if stash_c is not None else torch.empty(0, device=batch.device)]
+        if cfg.N_importance > 0:
+            zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, d.get("u"), cfg.flags)
+            pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
+            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb), var, tm)
+            rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, d.get("noise_f"), cfg)
+            outs = [rgb1, depth1, acc1, density1]
+            saved += [zf, raw_f, stash_f if stash_f is not None else torch.empty(0, device=batch.device)]
+            z_last, raw_last, w_last = zf, raw_f, weights1
+        R = batch.shape[0]
+        outs += [raw_last.view(R, -1, 4), w_last, z_last]
+        if cfg.N_importance > 0:
+            outs += [rgb, depth, acc, density, z_std]
+        if cfg.hooks.keep is not None:
+            cfg.hooks.keep.update(stash_c=saved[2], stash_f=saved[5] if cfg.N_importance > 0 else None, P_c=zc.numel(),
+                                  P_f=saved[3].numel() if cfg.N_importance > 0 else 0, batch=batch)
+        ctx.fused = False
+        return outs, saved
+
+    @staticmethod
+    def _backward_piecewise(ctx, g, batch, saved, d, coarse, fine):
+        cfg = ctx.cfg
+        pf, pb, tm = cfg.precision.fwd, cfg.precision.bwd, cfg.hooks.timer
         drays = torch.zeros_like(batch)
         fine_on = cfg.N_importance > 0
         g_main = (_opt(g[0]), _opt(g[1]), _opt(g[2]))
         g_c = (_opt(g[7]), _opt(g[8]), _opt(g[9])) if fine_on else g_main
-        grads_c: List[Optional[torch.Tensor]] = [None] * len(ctx.coarse)
+        grads_c: List[Optional[torch.Tensor]] = [None] * len(coarse)
         grads_f: List[Optional[torch.Tensor]] = []
 
-        def run(tensors, z, raw, noise, stash, gg, pk=None):
+        def run(tensors, z, raw, noise, stash, gg):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
-            if pk is None:
-                pk = mlp_pack(NET_NERF, pb, tensors)
+            pk = mlp_pack(NET_NERF, pb, tensors)
             gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash,
-                                    sink=grad_sink(tensors), variant=cfg.precision.variant)
-            lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays),
-                     _stream())
+                                    sink=grad_sink(tensors, cfg.hooks), variant=cfg.precision.variant, timer=tm)
+            lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays), _stream())
             return gr
 
         if fine_on and any(x is not None for x in g_main):
-            grads_f = run(ctx.fine, sv["zf"], sv["raw_f"], sv["noise_f"], sv["stash_f"], g_main, sv.get("pk_f"))
+            grads_f = run(fine, saved[3], saved[4], d.get("noise_f"), saved[5], g_main)
         if any(x is not None for x in g_c):
-            grads_c = run(ctx.coarse, sv["zc"], sv["raw_c"], sv["noise_c"], sv["stash_c"], g_c, sv.get("pk_c"))
-        ctx.saved = None
-        if fine_on and ctx.fine is ctx.coarse and grads_f:
+            grads_c = run(coarse, saved[0], saved[1], d.get("noise_c"), saved[2], g_c)
+        if fine_on and ctx.same and grads_f:
             grads_c = [(a + b if b is not None else a) if a is not None else b for a, b in zip(grads_c, grads_f)]
             grads_f = []
+        return drays, grads_c, (grads_f if not ctx.same else [])
+
+    @staticmethod
+    def backward(ctx, *g):
+        t = ctx.saved_tensors
+        batch, saved = t[0], list(t[1:1 + ctx.n_saved])
+        o = 1 + ctx.n_saved
+        d = {k: t[o + i] for i, k in enumerate(ctx.draw_keys)}
+        o += len(ctx.draw_keys)
+        coarse = list(t[o:o + ctx.n_c])
+        fine = coarse if ctx.same else list(t[o + ctx.n_c:])
+        bwd = March._backward_fused if ctx.fused else March._backward_piecewise
+        drays, grads_c, grads_f = bwd(ctx, g, batch, saved, d, coarse, fine)
         n_fine = ctx.n_params - ctx.n_coarse
         out_f = list(grads_f) if grads_f else [None] * n_fine
         return (drays, None, None, None, *grads_c, *out_f[:n_fine])
@@ -362,7 +487,7 @@ class NoiseMlp(torch.autograd.Function):
     ray batch is detached in the reference (:614), so only parameters receive gradients."""
 
     @staticmethod
-    def forward(ctx, batch, N_samples, index, lindisp, precision: Precision, want_grad, *params):
+    def forward(ctx, batch, N_samples, index, lindisp, precision: Precision, want_grad, hooks: Optional[Hooks], *params):
         batch = _f32(batch)
         tensors = [_f32(p) for p in params]
         R = batch.shape[0]
@@ -371,25 +496,29 @@ class NoiseMlp(torch.autograd.Function):
         pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
         need = bool(want_grad) and any(ctx.needs_input_grad)
         raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, stash_code(precision.fwd, precision.bwd),
-                                 precision.variant)
-        if DEBUG_KEEP is not None:
-            DEBUG_KEEP.update(stash_noise=stash, P_noise=R)
-        ctx.batch, ctx.z, ctx.tensors, ctx.stash, ctx.precision = batch, z, tensors, stash, precision
+                                 precision.variant, hooks.timer if hooks is not None else None)
+        if hooks is not None and hooks.keep is not None:
+            hooks.keep.update(stash_noise=stash, P_noise=R)
+        ctx.save_for_backward(batch, z, *([stash] if stash is not None else []), *tensors)
+        ctx.has_stash, ctx.precision, ctx.hooks = stash is not None, precision, hooks
         return raw[:, :3].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         pr = ctx.precision
+        t = ctx.saved_tensors
+        batch, z = t[0], t[1]
+        stash = t[2] if ctx.has_stash else None
+        tensors = list(t[3 if ctx.has_stash else 2:])
         draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
         draw[:, :3] = g
-        pk = mlp_pack(NET_NOISE, pr.bwd, ctx.tensors)
-        grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, ctx.tensors, pk, ctx.batch, ctx.z, draw, ctx.stash,
-                                sink=grad_sink(ctx.tensors), variant=pr.variant)
-        ctx.stash = None
+        pk = mlp_pack(NET_NOISE, pr.bwd, tensors)
+        grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, tensors, pk, batch, z, draw, stash,
+                                sink=grad_sink(tensors, ctx.hooks), variant=pr.variant)
         o = 2 * _NL[NET_NOISE] + 4   # alpha_linear is dead in NeRF_Noise (helpers:496,505,512): grad None
         grads[o] = None
         grads[o + 1] = None
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 # ----------------------------------------------------------------------------- blur kernel
@@ -403,7 +532,7 @@ class RbkWarp(torch.autograd.Function):
     the image index only, so it runs once per image; the SE(3) warp runs per ray."""
 
     @staticmethod
-    def forward(ctx, rays, idx, num_motion, window, mask, *params):
+    def forward(ctx, rays, idx, num_motion, window, mask, hooks: Optional[Hooks], *params):
         rays = _f32(rays).reshape(-1, 3, 2)
         idx = idx.reshape(-1).to(torch.int64).contiguous()
         tensors = [_f32(p) for p in params]
@@ -419,28 +548,33 @@ class RbkWarp(torch.autograd.Function):
                  lib.ptr(ccw), _stream())
         if mask is not None:
             mask = mask.reshape(-1).to(torch.uint8).contiguous()
-        ctx.rays, ctx.idx, ctx.tensors, ctx.acts, ctx.mask = rays, idx, tensors, acts, mask
+        ctx.save_for_backward(rays, idx, acts, *([mask] if mask is not None else []), *tensors)
+        ctx.has_mask, ctx.hooks = mask is not None, hooks
         ctx.cfg = (N, M, num_img, float(window))
         return new_rays, ccw
 
     @staticmethod
     def backward(ctx, g_rays, g_ccw):
         N, M, num_img, window = ctx.cfg
-        dev = ctx.rays.device
+        t = ctx.saved_tensors
+        rays, idx, acts = t[0], t[1], t[2]
+        mask = t[3] if ctx.has_mask else None
+        tensors = list(t[4 if ctx.has_mask else 3:])
+        dev = rays.device
         d_rvw = torch.zeros(num_img, RBK_RVW, dtype=torch.float32, device=dev)
-        drays = torch.empty_like(ctx.rays) if ctx.needs_input_grad[0] else None
-        lib.call("lush_rbk_warp_bwd", lib.ptr(ctx.rays), lib.ptr(ctx.idx), N, M, lib.ptr(ctx.acts),
-                 lib.ptr(_opt(g_rays)), lib.ptr(_opt(g_ccw)), lib.ptr(ctx.mask), lib.ptr(d_rvw), lib.ptr(drays),
+        drays = torch.empty_like(rays) if ctx.needs_input_grad[0] else None
+        lib.call("lush_rbk_warp_bwd", lib.ptr(rays), lib.ptr(idx), N, M, lib.ptr(acts),
+                 lib.ptr(_opt(g_rays)), lib.ptr(_opt(g_ccw)), lib.ptr(mask), lib.ptr(d_rvw), lib.ptr(drays),
                  _stream())
-        sink = grad_sink(ctx.tensors)          # the trainer's flat gradient: add straight into it
-        grads = list(sink) if sink is not None else [torch.empty_like(t) for t in ctx.tensors]
+        sink = grad_sink(tensors, ctx.hooks)          # the trainer's flat gradient: add straight into it
+        grads = list(sink) if sink is not None else [torch.empty_like(x) for x in tensors]
         scratch = torch.empty(num_img, RBK_ACT, dtype=torch.float32, device=dev)
-        st, gs = lib.rbk_struct(ctx.tensors), lib.rbk_struct(grads)
-        lib.call("lush_rbk_mlp_bwd", C.byref(st), num_img, M, window, lib.ptr(ctx.acts), lib.ptr(d_rvw),
+        st, gs = lib.rbk_struct(tensors), lib.rbk_struct(grads)
+        lib.call("lush_rbk_mlp_bwd", C.byref(st), num_img, M, window, lib.ptr(acts), lib.ptr(d_rvw),
                  C.byref(gs), lib.ptr(scratch), int(sink is not None), _stream())
         if sink is not None:
             grads = [None] * len(grads)
-        return (drays, None, None, None, None, *grads)
+        return (drays, None, None, None, None, None, *grads)
 
 
 class WSum(torch.autograd.Function):
@@ -479,15 +613,18 @@ class ToneMap(torch.autograd.Function):
         nraw = None if nraw is None else _f32(nraw)
         y = torch.empty_like(x)
         lib.call("lush_tonemap_fwd", lib.ptr(x), lib.ptr(nraw), x.numel() // 3, int(gamma), lib.ptr(y), _stream())
-        ctx.x, ctx.nraw, ctx.gamma = x, nraw, int(gamma)
+        ctx.save_for_backward(x, *([nraw] if nraw is not None else []))
+        ctx.gamma = int(gamma)
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = _f32(g)
-        dx = torch.zeros_like(ctx.x)
-        dn = None if ctx.nraw is None else torch.zeros_like(ctx.nraw)
-        lib.call("lush_tonemap_bwd", lib.ptr(ctx.x), lib.ptr(ctx.nraw), ctx.x.numel() // 3, ctx.gamma, lib.ptr(g),
+        x = ctx.saved_tensors[0]
+        nraw = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
+        dx = torch.zeros_like(x)
+        dn = None if nraw is None else torch.zeros_like(nraw)
+        lib.call("lush_tonemap_bwd", lib.ptr(x), lib.ptr(nraw), x.numel() // 3, ctx.gamma, lib.ptr(g),
                  lib.ptr(dx), lib.ptr(dn), _stream())
         return dx, dn, None
 
@@ -500,13 +637,14 @@ class NoiseAct(torch.autograd.Function):
         x = _f32(x)
         y = torch.empty_like(x)
         lib.call("lush_noise_act_fwd", lib.ptr(x), x.numel(), lib.ptr(y), _stream())
-        ctx.x = x
+        ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        dx = torch.zeros_like(ctx.x)
-        lib.call("lush_noise_act_bwd", lib.ptr(ctx.x), ctx.x.numel(), lib.ptr(_f32(g)), lib.ptr(dx), _stream())
+        (x,) = ctx.saved_tensors
+        dx = torch.zeros_like(x)
+        lib.call("lush_noise_act_bwd", lib.ptr(x), x.numel(), lib.ptr(_f32(g)), lib.ptr(dx), _stream())
         return dx
 
 
@@ -612,17 +750,18 @@ class ConsistLoss(torch.autograd.Function):
         return grad * g, None, None
 
 
-_DRAW_OFFSET = [0]
-
-
-def march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, seed=None, stream_id=0):
+def march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, seed=None, stream_id=0, hooks: Optional[Hooks] = None, offset=None):
     """The random draws of one march, in the reference's shapes (models/lushnerf.py:515, :322;
     utils/run_lushnerf_helpers.py:578), from ONE Philox launch (lush_draws) instead of four torch RNG kernels.
-    seed defaults to torch's CUDA seed (so torch.manual_seed governs it); every call takes the next offset;
-    stream_id separates data-parallel ranks that share a seed."""
+    seed defaults to torch's CUDA seed (so torch.manual_seed governs it); every call takes the next offset of `hooks`
+    (the model's own counter; an explicit `offset` overrides it); stream_id separates data-parallel ranks that share a seed."""
     if seed is None:
         seed = torch.cuda.initial_seed()
-    _DRAW_OFFSET[0] += 1
+    if offset is None:
+        if hooks is None:
+            raise ValueError("march_draws: give the model's ops.Hooks (its draw counter) or an explicit offset")
+        hooks.draw_offset += 1
+        offset = hooks.draw_offset
     d = {}
     if perturb > 0:
         d["t_rand"] = torch.empty(R, N_samples, dtype=torch.float32, device=device)
@@ -636,6 +775,6 @@ def march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, seed
     if d:
         g = lambda k: (lib.ptr(d.get(k)), d[k].numel() if k in d else 0)
         lib.call("lush_draws", C.c_ulonglong(int(seed) & (2 ** 64 - 1)),
-                 C.c_ulonglong((int(stream_id) << 40) + _DRAW_OFFSET[0]), *g("t_rand"), *g("noise_c"), *g("u"), *g("noise_f"),
+                 C.c_ulonglong((int(stream_id) << 40) + int(offset)), *g("t_rand"), *g("noise_c"), *g("u"), *g("noise_f"),
                  _stream())
     return d

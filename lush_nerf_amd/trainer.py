@@ -171,7 +171,8 @@ class Trainer:
         N = batch["target"].shape[0]
         mb = self.micro_batch if 0 < self.micro_batch < N else N
         loss = None
-        sink_before, ops.ACCUMULATE_INTO_PARAM_GRAD = ops.ACCUMULATE_INTO_PARAM_GRAD, True
+        hooks = self.model.hooks
+        sink_before, hooks.sink = hooks.sink, True
         try:      # dW kernels add straight into the flat gradient (p.grad are views of it)
             for a in range(0, N, mb):
                 b = min(a + mb, N)
@@ -182,7 +183,7 @@ class Trainer:
                 w = 1e-2 if i > self.noisenerf_start_iter else 0.0
                 loss = loss + w * self._consistency(consist, w)
         finally:
-            ops.ACCUMULATE_INTO_PARAM_GRAD = sink_before
+            hooks.sink = sink_before
         if self.distributed:
             dist.all_reduce(self.flat.grad)          # RCCL sum over xGMI; the 1/world mean is folded into Adam
         lr = self.lr() if self._lr_next is None else self._lr_next

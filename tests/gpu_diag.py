@@ -305,7 +305,7 @@ def t_rbk():
     tens = [gpu(t.detach()).requires_grad_(True) for t in rbk_tensors(p)]
     rg = gpu(b["rays"]).requires_grad_(True)
     mask = b["fq_mask"]
-    got_rays, got_ccw = ops.RbkWarp.apply(rg, gpu(b["images_idx"]), 4, 0.1, gpu(mask), *tens)
+    got_rays, got_ccw = ops.RbkWarp.apply(rg, gpu(b["images_idx"]), 4, 0.1, gpu(mask), None, *tens)
     rep("rbk new_rays vs golden", got_rays, g["new_rays"], 2e-5)
     rep("rbk ccw vs golden", got_ccw, g["ccw"], 2e-5)
     gr = torch.from_numpy(synth.normal(tuple(ref_rays.shape), 61))
@@ -331,7 +331,7 @@ def t_rbk():
     rr, cc = O.rbk_forward(pw, rays2, idx2)
     tens2 = [gpu(t.detach()).requires_grad_(True) for t in rbk_tensors(pw)]
     rg2 = gpu(bb["rays"]).requires_grad_(True)
-    gr2, gc2 = ops.RbkWarp.apply(rg2, gpu(idx2), 4, 0.1, None, *tens2)
+    gr2, gc2 = ops.RbkWarp.apply(rg2, gpu(idx2), 4, 0.1, None, None, *tens2)
     rep(f"rbk ({n_img} images, global tables) new_rays", gr2, rr, 2e-5)
     rep(f"rbk ({n_img} images, global tables) ccw", gc2, cc, 2e-5)
     g1 = torch.from_numpy(synth.normal(tuple(rr.shape), 63))
@@ -460,13 +460,12 @@ def t_lindisp_white():
     batch = nondc_batch(n, seed)
     cpu_draws = util.tdraws(n, Ns, Ni, seed)
     bg = gpu(batch).requires_grad_(True)
-    ops.DEBUG_KEEP = {}
+    keep = net.hooks.keep = {}
     try:
         ret, ret_noise = net.render_rays(bg, N_samples=Ns, retraw=True, lindisp=True, perturb=1., N_importance=Ni,
                                          white_bkgd=True, raw_noise_std=1., draws={k: v.to(dev) for k, v in cpu_draws.items()})
-        keep = ops.DEBUG_KEEP
     finally:
-        ops.DEBUG_KEEP = None
+        net.hooks.keep = None
     for k, tol in (("rgb_map", 1e-4), ("rgb0", 1e-4), ("acc_map", 1e-4), ("acc0", 1e-4), ("depth_map", 1e-3), ("depth0", 1e-3),
                    ("z_std", 2e-3)):
         rep(f"lindisp+white {k}", ret[k], g[k], tol)
@@ -551,14 +550,13 @@ def t_consistency():
     rk = dict(perturb=False, N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.,
               inference=True, save_warped_ray_img=False, near=0., far=1.)
     poses = torch.from_numpy(synth.poses(V, seed))
-    ops.DEBUG_KEEP = {}
+    keep = net.hooks.keep = {}
     try:     # the tables are indexed by the anchor only: {anchor: [V, HW, ...]} stands in for the [V, V, HW, ...] tensors
         rgb_align, cert = net(H, W, K, 1 << 20, poses=gpu(poses), render_kwargs=rk, render_factor=0,
                               rays_info=torch.arange(V), consist_loss=True, Align_matrix={anchor: gpu(am)},
                               Align_mask={anchor: gpu(cm)}, anchor_pose=anchor, samples=st)
-        keep = ops.DEBUG_KEEP
     finally:
-        ops.DEBUG_KEEP = None
+        net.hooks.keep = None
     rep("consistency rgb_align", rgb_align, g["rgb_align"], 1e-4)
     rep("consistency align_certainty", cert, g["certainty"], 0.0)
     loss = ops.ConsistLoss.apply(rgb_align, cert, 0.8)
@@ -600,10 +598,10 @@ def t_consistency():
 def t_draws():
     """lush_draws: the four draws of a march from one Philox launch -- ranges, moments, independence, determinism."""
     R, Ns, Ni = 4096, 64, 64
-    d1 = ops.march_draws(R, Ns, Ni, 1., 1., dev, seed=1234)
-    ops._DRAW_OFFSET[0] -= 1
-    d1b = ops.march_draws(R, Ns, Ni, 1., 1., dev, seed=1234)
-    d2 = ops.march_draws(R, Ns, Ni, 1., 1., dev, seed=1234)
+    hk = ops.Hooks()
+    d1 = ops.march_draws(R, Ns, Ni, 1., 1., dev, seed=1234, hooks=hk)
+    d1b = ops.march_draws(R, Ns, Ni, 1., 1., dev, seed=1234, offset=hk.draw_offset)
+    d2 = ops.march_draws(R, Ns, Ni, 1., 1., dev, seed=1234, hooks=hk)
     shapes_ok = d1["t_rand"].shape == (R, Ns) and d1["noise_c"].shape == (R, Ns - 1) and d1["u"].shape == (R, Ni) and \
         d1["noise_f"].shape == (R, Ns + Ni - 1)
     RESULTS.append(("draws: reference shapes", 0. if shapes_ok else 1., 0, shapes_ok))
@@ -729,7 +727,7 @@ def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
 
 
 def _gpu_masks(keep, precision):
-    """ReLU decisions of the coarse / fine / noise MLP evaluations of the last forward (ops.DEBUG_KEEP)."""
+    """ReLU decisions of the coarse / fine / noise MLP evaluations of the last forward (the model's hooks.keep)."""
     pf, pb = precision.fwd, precision.bwd
     f16 = pf == ops.PLANES_F16
     sp = ops.nplanes(ops.stash_code(pf, pb))
@@ -764,15 +762,14 @@ def t_train_e2e():
         cpu_draws = util.tdraws(n * (1 if naive else 5), Ns, Ni, seed)
         draws = {k: v.to(dev) for k, v in cpu_draws.items()}
         rays = gpu(b["rays"]).requires_grad_(True)
-        ops.DEBUG_KEEP = {}
+        keep = net.hooks.keep = {}
         try:
             out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": gpu(b["images_idx"])}, retraw=True,
                       force_naive=bool(naive), allkernel=bool(allk), kernel_pixel=gpu(b["fq_mask"]), perturb=1.,
                       N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
                       inference=False, near=0., far=1., draws=draws)
-            keep = ops.DEBUG_KEEP
         finally:
-            ops.DEBUG_KEEP = None
+            net.hooks.keep = None
         loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
         loss.backward()
         rep(f"train {name} rgb_blur", out[0], g["rgb_blur"], 1e-4)
@@ -833,14 +830,13 @@ def t_train_bench_regime(n=512, seed=21):
     cpu_draws = util.tdraws(n * 5, Ns, Ni, seed)
     draws = {k: v.to(dev) for k, v in cpu_draws.items()}
     rays = gpu(b["rays"]).requires_grad_(True)
-    keep = {}
-    ops.DEBUG_KEEP = keep
+    keep = net.hooks.keep = {}
     try:
         out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": gpu(b["images_idx"])}, retraw=True,
                   force_naive=False, allkernel=True, kernel_pixel=gpu(b["fq_mask"]), perturb=1., N_importance=Ni, N_samples=Ns,
                   use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., draws=draws)
     finally:
-        ops.DEBUG_KEEP = None
+        net.hooks.keep = None
     loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
     loss.backward()
     fw = net.read_faults()

@@ -559,6 +559,78 @@ def test_variants_agree(tmp_path, planes, variant):
         # 4e-7 absolute; the others: Cody-Waite + fdlibm, 7e-8): the same fp16 operand grid, but a few encodings round to
         # the neighbouring fp16 value -- raw outputs within 1.4e-4 of each other, both within 6e-4 of the fp32 oracle
         # (t_mlp_fwd gates 4e-3), gradients accordingly.
+        # d(point) is per point: where a ReLU decision differs between two fp16 forwards that point's gradient moves as a
+        # whole (3.3e-2 of the largest entry seen); parameter gradients average over the points (gated 1e-2).
         fwd_variant = variant.startswith("FWD")
-        assert np.isfinite(a[k]).all() and err < ((1e-3 if fwd_variant else 2e-6) if k == "raw" else (1e-2 if fwd_variant else 2e-3)), (variant, k, err)
+        tol = (1e-3 if fwd_variant else 2e-6) if k == "raw" else ((1e-1 if k == "dpts" else 1e-2) if fwd_variant else 2e-3)
+        assert np.isfinite(a[k]).all() and err < tol, (variant, k, err)
     print(f"variant {variant} ({planes}): outputs differ by {worst.get('raw', 0.0):.1e}, gradients by {worst.get('grads', 0.0):.1e}")
+
+
+def test_march_through_the_c_abi_alone(diag):
+    """the march is ONE C-ABI call per direction.  This test drives include/lush_march.h with ctypes and torch
+    memory only -- lush_pack_rays_fwd, lush_march_workspace_bytes, lush_march_fwd, lush_march_view, lush_march_bwd -- without
+    lush_nerf_amd.ops / model, on the reference fixture rays_6464_train_sharp (models/lushnerf.py:481-583 through
+    render_infer :679-763): outputs at the fixture's bounds, and the backward's gradients equal to the autograd op's
+    (which makes the same call) on the same inputs."""
+    import ctypes as C
+    import numpy as np
+    from lush_nerf_amd import lib, synth
+    L = lib.load()
+    dev = torch.device("cuda:0")
+    g = diag.util.golden("rays_6464_train_sharp")
+    n, Ns, Ni, train, sharp, seed = (int(x) for x in g["meta"])
+    w = synth.all_weights(diag.util.NUM_IMG, seed, sharp=bool(sharp))
+    names = lambda net: [f"{net}.pts_linears.{l}.{s}" for l in range(8) for s in ("weight", "bias")] + \
+        [f"{net}.{m}.{s}" for m in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear") for s in ("weight", "bias")]
+    coarse = [torch.from_numpy(w[k].copy()).to(dev) for k in names("mlp_coarse")]
+    fine = [torch.from_numpy(w[k].copy()).to(dev) for k in names("mlp_fine")]
+    b = synth.ray_batch(n, seed, diag.util.NUM_IMG)
+    rays = torch.from_numpy(b["rays"]).to(dev).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    H, W, F = synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF
+    cx = float(torch.tensor(-1. / (W / (2. * F)), dtype=torch.float32))
+    cy = float(torch.tensor(-1. / (H / (2. * F)), dtype=torch.float32))
+    batch = torch.empty(n, 11, device=dev)
+    lib.call("lush_pack_rays_fwd", lib.ptr(rays), n, 1, cx, cy, 0.0, 1.0, lib.ptr(batch), stream)
+    d = {k: torch.from_numpy(v).to(dev).contiguous() for k, v in synth.draws(n, Ns, Ni, seed).items()}
+    for planes, tol in (((2, 2), 1e-4), ((lib.MarchCfgC.planes_fwd and 17, 17), 1e-4)):
+        cfg = lib.MarchCfgC(n, Ns, Ni, 1.0, 1.0, 0, 0, -1.0, planes[0], planes[1], 0, 0)
+        nbytes = L.lush_march_workspace_bytes(C.byref(cfg))
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        f = lambda *s: torch.empty(*s, device=dev)
+        o = dict(rgb=f(n, 3), depth=f(n), acc=f(n), density=f(n, Ns + Ni - 1), rgb0=f(n, 3), depth0=f(n), acc0=f(n),
+                 density0=f(n, Ns - 1), z_std=f(n))
+        out = lib.MarchOut(*(o[k].data_ptr() for k in ("rgb", "depth", "acc", "density", "rgb0", "depth0", "acc0", "density0", "z_std")))
+        dr = lib.MarchDraws(*(d[k].data_ptr() for k in ("t_rand", "noise_c", "u", "noise_f")))
+        pc, pfn = lib.mlp_struct(coarse, 8), lib.mlp_struct(fine, 8)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib.call("lush_march_fwd", C.byref(cfg), lib.ptr(batch), C.byref(pc), C.byref(pfn), C.byref(dr), C.byref(out), lib.ptr(ws),
+                 lib.ptr(flags), stream)
+        assert int(flags.item()) == 0
+        assert diag.util.relerr(o["rgb"], g["rgb_map"]) < tol and diag.util.relerr(o["rgb0"], g["rgb0"]) < tol
+        assert diag.util.relerr(o["acc"], g["acc_map"]) < 1e-4 and diag.util.relerr(o["depth"], g["depth_map"]) < 1e-3
+        off, nb = C.c_size_t(), C.c_size_t()
+        lib.call("lush_march_view", C.byref(cfg), lib.VIEW_Z, C.byref(off), C.byref(nb))
+        z = ws[off.value:off.value + nb.value].view(torch.float32).view(n, Ns + Ni)
+        assert bool((z[:, 1:] >= z[:, :-1]).all())
+        # backward: d (sum rgb + sum rgb0) / d parameters, against the autograd op on the same inputs
+        gc = [torch.zeros_like(t) for t in coarse]
+        gf = [torch.zeros_like(t) for t in fine]
+        ones = torch.ones(n, 3, device=dev)
+        go = lib.MarchGout(ones.data_ptr(), None, None, ones.data_ptr(), None, None)
+        drays = torch.zeros(n, 11, device=dev)
+        sgc, sgf = lib.mlp_struct(gc, 8), lib.mlp_struct(gf, 8)
+        lib.call("lush_march_bwd", C.byref(cfg), lib.ptr(batch), C.byref(pc), C.byref(pfn), C.byref(dr), C.byref(go), lib.ptr(ws),
+                 C.byref(sgc), C.byref(sgf), lib.ptr(drays), stream)
+        from lush_nerf_amd import ops
+        cp = [t.clone().requires_grad_(True) for t in coarse]
+        fp = [t.clone().requires_grad_(True) for t in fine]
+        bq = batch.clone().requires_grad_(True)
+        mc = ops.MarchCfg(Ns, Ni, 1., 1., precision=ops.Precision(*planes))
+        res = ops.March.apply(bq, mc, d, len(cp), *cp, *fp)
+        (res[0].sum() + res[7].sum()).backward()
+        worst = max(diag.util.relerr(a, t.grad) for a, t in zip(gc + gf + [drays], cp + fp + [bq]))
+        print(f"C ABI alone, planes {planes}: rgb_map {diag.util.relerr(o['rgb'], g['rgb_map']):.1e}; gradients vs the autograd op {worst:.1e}")
+        assert worst < 2e-4, worst        # the same kernels: only the order of the fp32 atomics differs
