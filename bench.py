@@ -262,11 +262,14 @@ def main():
         for i in range(warmup):
             tr.step(batches[i % n_batches], i)
         sync()
+        tr.allreduce_events = []
         t0 = time.perf_counter()
         for i in range(steps):
             tr.step(batches[(warmup + i) % n_batches], warmup + i)
         sync()
         dt = time.perf_counter() - t0
+        ar_ms = sum(a_.elapsed_time(b_) for a_, b_ in tr.allreduce_events) / max(len(tr.allreduce_events), 1)
+        tr.allreduce_events = None
         # kernel groups: the SAME steps once more with HIP events around each MLP kernel group on the launch stream.  The
         # timed region above runs the march as one C-ABI call per direction (lush_march_fwd / lush_march_bwd); with the
         # timer set the same kernels are launched group by group through the piecewise entry points.
@@ -283,7 +286,9 @@ def main():
             raise SystemExit(f"numerical fault during the timed steps: {net.fault_names(fault)}")
         del tr, net, batches
         torch.cuda.empty_cache()
-        return dt, timer.summary()
+        summ = timer.summary()
+        summ["_allreduce_ms"] = ar_ms
+        return dt, summ
 
     def run_c1(pf, pb, steps, warmup):
         """BASELINE config 1 (N_rand 256, 32+0, naive): NeRFAll.forward cannot take N_importance = 0 (it indexes
@@ -446,6 +451,11 @@ def main():
             "step_frac_mfma": round(flop_step * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
             "step_frac_hbm_survey_stash": round(2 * 4352 * evals_step * a.steps / dt / 1e9 / PEAK_HBM_GBS, 4),
             "kernels": kern, "roofline": roof,
+            # the one collective of a step (HIP events around dist.all_reduce of the 5.2 MB flat gradient on the launch
+            # stream, mean over the timed steps): what an N > 1 run adds to the N = 1 step
+            "allreduce_ms": round(groups.get("_allreduce_ms", 0.0), 4),
+            "kernel_timing": "HIP events around each MLP kernel group on the launch stream, over the same steps run once more "
+                             "group by group (the timed region makes one lush_march_fwd / lush_march_bwd call per march)",
         }
         notes = {"2,h": "forward 2 bf16 planes, backward ONE loss-scaled fp16 plane (11-bit operands at the bf16 backward's cost)",
                  "h,h": "forward ONE fp16 plane (outputs within 3e-5 of fp32), backward ONE loss-scaled fp16 plane",

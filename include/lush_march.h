@@ -76,7 +76,9 @@ int lush_composite_bwd(const float* raw, const float* z, const float* rays, int 
  * weights[1:-1], followed by sort(cat(z, z_samples)) (models/lushnerf.py:435-440,
  * 544-549).  u [R][Ni] U[0,1) draws, or NULL for the deterministic linspace.
  * z_out [R][S+Ni] sorted; z_samples [R][Ni] (may be NULL); z_std [R] =
- * std(z_samples, unbiased=False) (:465). */
+ * std(z_samples, unbiased=False) (:465).
+ * LIMITS: 3 <= S <= 256 and S + Ni <= 512 (one wavefront per ray: the CDF and the merged sort live in fixed LDS
+ * arrays); anything larger is REFUSED with an error, nothing is launched.  BASELINE's largest config is 128 + 128. */
 int lush_sample_merge(const float* z, const float* weights, int R, int S, int Ni, const float* u,
                       float* z_out, float* z_samples, float* z_std, int* flags, lush_stream_t stream);
 

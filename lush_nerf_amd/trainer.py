@@ -103,6 +103,7 @@ class Trainer:
         # test seam: the CPU (gloo) tests replace the HIP forward+backward of one slice by injected gradients
         self._fwd_bwd = step_fn or self._hip_forward_backward
         self._adam = ops.adam_step
+        self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
         self.sync_replicas()
 
     # ------------------------------------------------------------------ data parallel plumbing
@@ -185,7 +186,14 @@ class Trainer:
         finally:
             hooks.sink = sink_before
         if self.distributed:
+            ev = None
+            if self.allreduce_events is not None and self.flat.grad.is_cuda:      # bench.py: HIP events around the one collective
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat.grad)          # RCCL sum over xGMI; the 1/world mean is folded into Adam
+            if ev is not None:
+                ev[1].record()
+                self.allreduce_events.append(ev)
         lr = self.lr() if self._lr_next is None else self._lr_next
         self._lr_next = None
         active = [True, not force_naive, False]

@@ -401,8 +401,62 @@ def case_trajectory(seed=41, n_rand=32, steps=40):
          final_rgb_w=sd["mlp_fine.rgb_linear.weight"].numpy().copy())
 
 
+
+def case_trajectory_long(seed=43, n_rand=32, steps=300):
+    """A LONGER training run of the reference itself (run_lushnerf.py:603-685), on a problem whose loss can actually fall:
+    the targets are what a second, fixed weight set ("teacher", seed + 100) renders for the same rays -- its blurred,
+    tone-mapped colour NeRFAll.forward()[0] without jitter or density noise -- instead of U(0,1) colours.  Same optimizer
+    set-up and learning-rate rule as case_trajectory, fresh rays and draws every step.  Stores the targets (so the GPU
+    test needs no teacher), the loss curve and the final fine rgb head."""
+    Ns = Ni = 64
+    net = build_ref(Ni, synth.all_weights(NUM_IMG, seed, sharp=True, rbk_scale=2.0e4))
+    teacher = build_ref(Ni, synth.all_weights(NUM_IMG, seed + 100, sharp=True, rbk_scale=2.0e4))
+    net.train()
+    teacher.train()
+    noise = list(net.mlp_noise_coarse.parameters())
+    ids = set(map(id, noise))
+    base = [p for p in net.parameters() if id(p) not in ids]
+    lrate, decay = 5e-4, 250
+    opt = torch.optim.Adam([{"params": base}, {"params": noise, "lr": lrate}], lr=lrate)
+    kw = dict(perturb=1., N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
+              inference=False, near=0., far=1.)
+    kw_t = dict(kw, perturb=0., raw_noise_std=0.)
+    losses, targets, global_step = [], [], 0
+    for s in range(steps):
+        b = synth.ray_batch(n_rand, seed, NUM_IMG, step=s)
+        d = synth.draws(n_rand * 5, Ns, Ni, seed, step=s)
+        rays = torch.from_numpy(b["rays"])
+        info = {"images_idx": torch.from_numpy(b["images_idx"])}
+        mask = torch.from_numpy(b["fq_mask"]).bool()
+        with torch.no_grad():
+            target = teacher(H, W, K, chunk=1 << 20, rays=rays, rays_info=info, retraw=True, force_naive=False, allkernel=False,
+                             kernel_pixel=mask, **kw_t)[0].clone()
+        with ServeDraws([d["t_rand"], d["noise_c"], d["u"], d["noise_f"]]):
+            out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info=info, retraw=True, force_naive=False, allkernel=False,
+                      kernel_pixel=mask, **kw)
+        loss = ref_helpers.img2mse(out[0], target) * 0.5 + ref_helpers.img2l1(out[0], target) * 0.5 \
+            + ref_helpers.img2mse(out[1], target) * 0.5 + ref_helpers.img2l1(out[1], target) * 0.5
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        new_lrate = lrate * (0.1 ** (global_step / (decay * 1000)))
+        for g in opt.param_groups:
+            g["lr"] = new_lrate
+        global_step += 1
+        losses.append(loss.item())
+        targets.append(target.numpy().copy())
+        if s % 10 == 0:
+            print("long traj step", s, loss.item(), flush=True)
+    sd = {canon_name(k): v for k, v in net.state_dict().items()}
+    save("train_trajectory_long", meta=np.array([n_rand, Ns, Ni, seed, steps]), losses=np.array(losses),
+         targets=np.stack(targets).astype(np.float32),
+         final_norms=np.array([float(sd[k].double().norm()) for k in sorted(sd)]), final_keys=np.array(sorted(sd)),
+         final_rgb_w=sd["mlp_fine.rgb_linear.weight"].numpy().copy(),
+         final_rgb_b=sd["mlp_fine.rgb_linear.bias"].numpy().copy())
+
+
 NEW_CASES = {"sample_pdf_z": case_sample_pdf_z, "lindisp_white": case_lindisp_white, "eval_forward": case_eval_forward,
-             "consistency": case_consistency, "trajectory": case_trajectory}
+             "consistency": case_consistency, "trajectory": case_trajectory, "trajectory_long": case_trajectory_long}
 
 
 if __name__ == "__main__":

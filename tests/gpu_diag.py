@@ -713,6 +713,24 @@ def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
     RESULTS.append((f"{tag} MASKED grads vs float64 [{worst[0]}] (e_gpu / allowed)", worst_excess, 1.0, ok))
     print(f"{'ok  ' if ok else 'FAIL'} {tag} masked oracle: worst tensor {worst[0]}: e_gpu {worst[1]:.2e}, fp32 oracle {worst[2]:.2e}, "
           f"allowed max({floor:.0e}, min({MASKED_CAP:.0e}, {factor:.0f} x fp32)) -> {worst_excess:.2f} of the allowance", flush=True)
+    # direction of every gradient tensor: cosine with the float64 oracle's.  A gate that does not scale with the mode's
+    # element-wise allowance: whatever the operand width, a parameter tensor must be pushed the way float64 pushes it --
+    # 0.999 with 16-bit operands in the backward, 0.999999 fp32-equivalent; tensors on which the fp32 oracle itself
+    # is off by more than (1 - cos) / 4 (cancelling sums such as a 1-element bias) get that much slack.
+    def cosine(a, b):
+        a, b = torch.as_tensor(a).detach().double().cpu().reshape(-1), torch.as_tensor(b).detach().double().cpu().reshape(-1)
+        na, nb = float(a.norm()), float(b.norm())
+        return 1.0 if na == 0.0 and nb == 0.0 else float(a @ b) / max(na * nb, 1e-300)
+    cos_gate = 1e-6 if tuple(E2E_PLANES) in ((2, 2), (3, 3)) else 1e-3
+    worst_cos, worst_k, worst_f32 = 0.0, "", 0.0
+    for k, got, t64, t32 in items:
+        miss, miss32 = 1.0 - cosine(got, t64), 1.0 - cosine(t32, t64)
+        if miss - 4.0 * miss32 > worst_cos:
+            worst_cos, worst_k, worst_f32 = miss - 4.0 * miss32, k, miss32
+    okc = bool(worst_cos <= cos_gate)
+    RESULTS.append((f"{tag} MASKED grads: 1 - cosine with float64 [{worst_k}]", worst_cos, cos_gate, okc))
+    print(f"{'ok  ' if okc else 'FAIL'} {tag} gradient directions: worst 1 - cos(g_gpu, g_f64) beyond the fp32 oracle's own = {worst_cos:.2e} "
+          f"({worst_k}; fp32 oracle {worst_f32:.1e}); gate {cos_gate:.0e}", flush=True)
     # informational: the largest plain error among well-conditioned tensors (fp32 oracle within 1e-5 of float64)
     wc = [(util.relerr(got, t64), k) for k, got, t64, t32 in items if util.relerr(t32, t64) < 1e-5]
     if wc:

@@ -180,7 +180,7 @@ def torch_adam(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gr
     denom = v.sqrt() / (1 - beta2 ** step) ** 0.5 + eps
     param.sub_((lr / (1 - beta1 ** step)) * m / denom)
 
-tr = Trainer(net, 640, 1120, 1000.0, kernel_start_iter=1, distributed=True, micro_batch=16, step_fn=fake_fwd_bwd)
+tr = Trainer(net, 640, 1120, 1000.0, kernel_start_iter=1, distributed=True, micro_batch=8, step_fn=fake_fwd_bwd)
 tr._adam = torch_adam
 assert tr.world == 2 and tr.distributed
 # construction broadcast: both ranks now hold rank 0's weights
@@ -194,11 +194,11 @@ for i in range(3):                         # i = 0 is the naive phase (kernel_st
     before = tr.flat.param.clone()
     lr_used = tr.lr()
     loss = tr.step(batch, i)
-    assert [c[:2] for c in calls[-3:]] == [(0, 16), (16, 32), (32, 40)], calls[-3:]      # micro-batches of 16 input rays
+    assert [c[:2] for c in calls[-5:]] == [(0, 8), (8, 16), (16, 24), (24, 32), (32, 40)], calls[-5:]      # micro-batches of 8 input rays
     # what the reference's DataParallel computes: gradient of the mean loss over the global batch = mean of rank grads
     gsum = torch.zeros(tr.flat.numel)
     for r in range(world):
-        for a, b in ((0, 16), (16, 32), (32, 40)):
+        for a, b in ((0, 8), (8, 16), (16, 24), (24, 32), (32, 40)):
             g = torch.from_numpy(synth.normal((tr.flat.numel,), 7000 + 10 * i + r, a)) * ((b - a) / 40)
             gsum += g
     if i < 1:
@@ -210,7 +210,11 @@ for i in range(3):                         # i = 0 is the naive phase (kernel_st
         if active[s]:
             steps[s] += 1
             torch_adam(ref_p[a:b], gsum[a:b], ref_m[a:b], ref_v[a:b], lr_used, steps[s], grad_scale=1.0 / world)
-    assert torch.allclose(tr.flat.param, ref_p, rtol=1e-5, atol=1e-7), f"step {i}: parameters != Adam on the mean gradient"
+    # Adam's first steps move a parameter by ~lr * g / |g|: on the one-in-a-million element whose summed gradient is within
+    # fp32 summation-order noise of zero that is ill-conditioned (the sum is taken in another order here than in the
+    # trainer), so a handful of the 1.3 M elements may differ; every other one must match
+    bad = ~torch.isclose(tr.flat.param, ref_p, rtol=1e-5, atol=1e-7)
+    assert int(bad.sum()) <= 8 and float((tr.flat.param - ref_p).abs().max()) < 2e-3, f"step {i}: parameters != Adam on the mean gradient ({int(bad.sum())} elements)"
     s1, s2 = tr.flat.segments[1], tr.flat.segments[2]
     assert torch.equal(tr.flat.param[s2[0]:s2[1]], before[s2[0]:s2[1]]), "dead segment was stepped"
     if i < 1:
@@ -222,6 +226,30 @@ for i in range(3):                         # i = 0 is the naive phase (kernel_st
     dist.all_gather(chk, tr.flat.param)
     assert torch.equal(chk[0], chk[1])
 assert tr.steps == [3, 2, 0] and tr.global_step == 3
+# The reference's DataParallel semantics, stated directly: two ranks of N rays == ONE rank stepping the concatenated 2N batch
+# (run_lushnerf.py:348, 652-661: the loss is a mean over the gathered batch).  Global slice [a, b) of the 80-ray batch is
+# rank a // 40's slice [a % 40, b % 40): the injected gradient of that slice, weighted by its share of 80 rays.
+if rank == 0:
+    net1 = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4))
+    M.load_reference_weights(net1, synth.all_weights(30, 50))
+
+    def fake_single(batch, a, b, i, draws, frac, force_naive):
+        g = torch.from_numpy(synth.normal((tr1.flat.numel,), 7000 + 10 * i + a // 40, a % 40)) * frac
+        if force_naive:
+            s1 = tr1.flat.segments[1]
+            g[s1[0]:s1[1]] = 0
+        s2 = tr1.flat.segments[2]
+        g[s2[0]:s2[1]] = 0
+        tr1.flat.grad += g
+        return torch.tensor(frac)
+    tr1 = Trainer(net1, 640, 1120, 1000.0, kernel_start_iter=1, distributed=False, micro_batch=8, step_fn=fake_single)
+    tr1._adam = torch_adam
+    for i in range(3):
+        tr1.step({"target": torch.zeros(80, 3)}, i)
+        if i == 2:      # gradient of the last step: sum over ranks / world == the single rank's gradient
+            assert torch.allclose(tr.flat.grad / world, tr1.flat.grad, rtol=2e-4, atol=2e-6), "2-rank gradient != 1-rank gradient on the concatenated batch"
+    bad = ~torch.isclose(tr.flat.param, tr1.flat.param, rtol=1e-5, atol=1e-7)
+    assert int(bad.sum()) <= 8 and float((tr.flat.param - tr1.flat.param).abs().max()) < 2e-3, "2 ranks x N rays != 1 rank x 2N rays"
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], f"trainer_rank{rank}.ok"), "w").write("ok")
 '''
@@ -333,3 +361,15 @@ def test_checkpoint_interop_with_reference_layout(tmp_path):
     tr3.m.fill_(1.0); tr3.steps = [4, 4, 0]
     assert CK.load_checkpoint(path2, net3, tr3) == 9
     assert tr3.global_step == 9 and tr3.steps == [0, 0, 0] and float(tr3.m.abs().max()) == 0.0
+
+
+def test_sample_merge_refuses_sizes_beyond_its_lds_arrays():
+    """include/lush_march.h states the limits of lush_sample_merge (3 <= S <= 256, S + Ni <= 512: fixed LDS arrays of the
+    one-wavefront-per-ray kernel); beyond them the entry point must refuse BEFORE launching anything (checked here
+    without a GPU: the refusal happens on the host) and say why."""
+    from lush_nerf_amd import lib
+    l = lib.load()
+    for S, Ni in ((257, 64), (2, 64), (256, 257), (300, 300), (64, 0)):
+        rc = l.lush_sample_merge(None, None, 4, S, Ni, None, None, None, None, None, None)
+        assert rc != 0, (S, Ni)
+        assert b"lush_sample_merge" in l.lush_last_error(), l.lush_last_error()
