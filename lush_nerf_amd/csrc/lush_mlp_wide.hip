@@ -209,20 +209,15 @@ struct WdPass {
         unsigned dma_dst, dma_off;
     };
 
-    // ---- stash pipeline over the layer's 16 positions P = 4 PQ + I: job j = (column block j % 2, k-blocks 4 (j/2) ..):
-    // LDS writes in P = 2j (gaps 12..15), read-backs in P = 2j + 1 (gaps 12..15), row stores in P = 2j + 2 (gaps 4..7);
-    // the last job's stores follow position 15 directly.
-    static constexpr int st_kind(int g) {          // 0 none, 1 LDS write, 2 read-back, 3 row store
-        if (!STASH) return 0;
-        const int P = 4 * PQ + g / 16, m = g % 16;
-        if (m >= 12) return P % 2 == 0 ? 1 : 2;
-        if (m >= 4 && m < 8 && P % 2 == 0 && P >= 2) return 3;
-        return 0;
-    }
-    static constexpr int st_job(int g) {
-        const int P = 4 * PQ + g / 16, m = g % 16;
-        return m >= 12 ? P / 2 : P / 2 - 1;
-    }
+    // ---- stash pipeline over the layer's 16 positions P = 4 PQ + I.  Job J = (column block J / 4, k-blocks 4 (J % 4) ..)
+    // = 32 rows x 128 bytes: LDS writes in position J (gaps 12..15, tile J % 2), read-backs in position J + 1 (gaps 12..15),
+    // row stores in position J + 2 (gaps 4..7).  The four 128-byte pieces of a 512-byte row are four consecutive jobs, so
+    // they reach memory within a few microseconds of each other: with the pieces of a row spread over the whole layer
+    // (round-3 first version) the stash-writing forward took 6 % longer -- the memory side merges what arrives together.
+    static constexpr int ST_JOBS = 8;
+    static constexpr bool st_write(int g) { return STASH && g % 16 >= 12 && (4 * PQ + g / 16) < ST_JOBS; }
+    static constexpr bool st_read(int g) { return STASH && g % 16 >= 12 && (4 * PQ + g / 16) >= 1 && (4 * PQ + g / 16) <= ST_JOBS; }
+    static constexpr bool st_store(int g) { return STASH && g % 16 >= 4 && g % 16 < 8 && (4 * PQ + g / 16) >= 2 && (4 * PQ + g / 16) <= ST_JOBS + 1; }
 
     // ---- the list scheduler ----
     static constexpr int item_weight(int k) {      // issue slots of item k
@@ -242,9 +237,9 @@ struct WdPass {
         if (m == 4 || m == 5) w += 3;
         if (m == 8) w += 10;
         if (m >= 9 && m <= 11) w += 1;
-        const int sk = st_kind(g);
-        if (sk == 1 || sk == 2) w += 1;
-        if (sk == 3) w += 2;
+        if (st_write(g)) w += 1;
+        if (st_read(g)) w += 1;
+        if (st_store(g)) w += 2;
         return w;
     }
     struct Sched {
@@ -365,7 +360,7 @@ struct WdPass {
 
     template <int JOB, int I4>
     static __device__ __forceinline__ void stash_store(const WdCarry& cr, const WdRt& rt) {
-        constexpr int c = JOB % 2, j = JOB / 2;      // uniform row-block base + ONE per-lane offset
+        constexpr int c = JOB / 4, j = JOB % 4;      // uniform row-block base + ONE per-lane offset
 #ifndef LUSH_ABL_NOSTORE
         __builtin_nontemporal_store(cr.sb[I4], reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off));
 #else
@@ -374,19 +369,20 @@ struct WdPass {
     }
     template <int G>
     static __device__ __forceinline__ void stash(const u32x4 (&xin)[2][16], WdCarry& cr, const WdRt& rt, int lane) {
-        if constexpr (st_kind(G) != 0) {
-            constexpr int job = st_job(G), c = job % 2, j = job / 2, m = G % 16;
-            if constexpr (st_kind(G) == 1) {
-                constexpr int o = m - 12;
-                const int n = lane & 31, hh = lane >> 5;
-                *reinterpret_cast<u32x4*>(rt.tile + n * 128 + (((2 * o + hh) ^ (n & 7)) << 4)) = xin[c][4 * j + o];
-            } else if constexpr (st_kind(G) == 2) {
-                constexpr int i = m - 12;
-                const int row = 8 * i + (lane >> 3);
-                cr.sb[i] = *reinterpret_cast<const u32x4*>(rt.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-            } else {
-                stash_store<job, m - 4>(cr, rt);
-            }
+#ifdef LUSH_ABL_NOSTASH      // timing ablation only (wrong results): no LDS transposition, no row stores
+        return;
+#endif
+        constexpr int P = 4 * PQ + G / 16, m = G % 16;
+        if constexpr (st_store(G)) stash_store<P - 2, m - 4>(cr, rt);
+        if constexpr (st_write(G)) {
+            constexpr int job = P, c = job / 4, j = job % 4, o = m - 12;
+            const int n = lane & 31, hh = lane >> 5;
+            *reinterpret_cast<u32x4*>(rt.tile + (job % 2) * 4096 + n * 128 + (((2 * o + hh) ^ (n & 7)) << 4)) = xin[c][4 * j + o];
+        }
+        if constexpr (st_read(G)) {
+            constexpr int job = P - 1, i = m - 12;
+            const int row = 8 * i + (lane >> 3);
+            cr.sb[i] = *reinterpret_cast<const u32x4*>(rt.tile + (job % 2) * 4096 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
         }
     }
 
@@ -394,7 +390,7 @@ struct WdPass {
     static constexpr int stores_in(int g0, int g1) {
         int n = 0;
         for (int g = g0 < 0 ? 0 : g0; g < g1 && g < NG; ++g) {
-            if (st_kind(g) == 3) ++n;
+            if (st_store(g)) ++n;
             if (CK == WC_ACT && MASK)
                 for (int k = SC.first[g]; k < SC.first[g + 1]; ++k)
                     if (k % IPB == CV::UPB) ++n;
@@ -463,12 +459,7 @@ struct WdPass {
         wd_unroll<0, NPOS>([&](auto ic) __attribute__((always_inline)) {
             position<BMAIN, NRQ, decltype(ic)::value, true>(cx, act, pend, xin, xout, r, cr, peimg, row0, rt, alpha);
         });
-        if constexpr (STASH && PQ == 3) {     // the layer's last job: its read-backs were this position's last fillers
-            stash_store<7, 0>(cr, rt);
-            stash_store<7, 1>(cr, rt);
-            stash_store<7, 2>(cr, rt);
-            stash_store<7, 3>(cr, rt);
-        }
+
     }
 };
 
@@ -555,8 +546,8 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
     // behind the images every distinct bias address became a register of its own, hoisted out of the tile loop and spilled).
     float* biasl = reinterpret_cast<float*>(smem);             // [NBIAS] fp32
     char* ring = smem + NBIAS * 4;                             // [WD_S][8 KiB]
-    char* stage = ring + WD_S * WD_SLOT;                       // [4 waves][4 KiB] stash transposition tiles (SPK > 0)
-    char* peimg = stage + 4 * 4096;                            // [256 points][272 B]
+    char* stage = ring + WD_S * WD_SLOT;                       // [4 waves][2][4 KiB] stash transposition tiles (SPK > 0)
+    char* peimg = stage + 8 * 4096;                            // [256 points][272 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -586,7 +577,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
 
     const int row0 = w * 64;
     WdRt rt;
-    rt.tile = stage + w * 4096;
+    rt.tile = stage + w * 8192;
     rt.pre_on = false;
     rt.srows = nullptr;
 #pragma unroll
@@ -759,7 +750,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
 // host side
 // ---------------------------------------------------------------------------------------------
 static_assert((NetNerf::f32_w_rgb * 4) % 16 == 0, "the ring behind the bias block stays 16-byte aligned");
-size_t mlp_wide_fwd_lds_bytes() { return (size_t)WD_S * WD_SLOT + (size_t)WD_PE_PLANE + (size_t)NetNerf::f32_w_rgb * 4 + 4 * 4096; }
+size_t mlp_wide_fwd_lds_bytes() { return (size_t)WD_S * WD_SLOT + (size_t)WD_PE_PLANE + (size_t)NetNerf::f32_w_rgb * 4 + 8 * 4096; }
 
 template <int SPK>
 static int launch_wide_sp(const MlpFwdArgs& a, hipStream_t s) {
