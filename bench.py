@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=0, help="input rays per forward+backward slice (0 = whole batch); "
                     "bounds the activation stash for the larger BASELINE configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="developer A/B: lib.VARIANT_* bits, an older kernel for the same work "
+                    "(include/lush_march.h); 0 = the product's choice, the only value a reported line may carry")
     ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
     ap.add_argument("--config", type=str, default="C2", choices=["C2", "C3", "C5"],
                     help="BASELINE config timed as the headline workload (C2 = the one the metric is quoted on)")
@@ -256,7 +258,7 @@ def main():
         """Time `steps` optimisation steps of one BASELINE config in one precision mode (max over ranks)."""
         cfg = cfg or dict(n_rand=a.n_rand, ns=a.n_samples, ni=a.n_importance, kernel=True, micro=a.micro_batch)
         batches = make_batches(cfg["n_rand"])
-        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb))
+        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb, a.variant))
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, cfg["ns"], cfg["ni"], kernel_start_iter=0,
                      allkernel_start_iter=1 << 30, distributed=True, micro_batch=cfg["micro"])
         for i in range(warmup):

@@ -77,6 +77,24 @@ __device__ __forceinline__ void lush_sincos(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -b : b;
 }
 
+// Hardware sin / cos (v_sin_f32 / v_cos_f32 take revolutions) behind an exact range reduction: the coordinate over 2 pi
+// as a double-float hi + lo (rev_split: one FMA), times the power of two (exact), v_fract (exact), + the scaled lo.
+// 4.2e-7 absolute against float64 over 2^k [-2, 2], k = 0..9 (tests/micro/sincos_hw.hip): 1/500 of the fp16 grid -- used by
+// the one-fp16-plane kernels only (the two-plane bf16 kernels carry 2^-17 and keep lush_sincos above); ~6 instructions
+// instead of ~30.
+__device__ __forceinline__ void rev_split(float x, float* hi, float* lo) {
+    constexpr float C_HI = 0.15915494309189535f;
+    constexpr float C_LO = (float)(0.15915494309189533576888 - (double)C_HI);
+    *hi = x * C_HI;
+    *lo = __builtin_fmaf(x, C_HI, -*hi) + x * C_LO;
+}
+__device__ __forceinline__ void sincos_rev(float hi, float lo, int k, float* sn, float* cs) {
+    const float s = (float)(1 << k);
+    const float r = __builtin_amdgcn_fractf(hi * s) + lo * s;
+    *sn = __builtin_amdgcn_sinf(r);
+    *cs = __builtin_amdgcn_cosf(r);
+}
+
 // (not inlined on purpose: the inlined sincosf bodies otherwise leave dozens of loop-invariant
 // values live across the MFMA loops of the whole tile)
 template <int NS, int MT, int NTHREADS, int DT>

@@ -468,23 +468,12 @@ struct WdPass {
 // ---------------------------------------------------------------------------------------------
 // gamma(x), gamma(d) of the tile's 256 points as fp16 into the padded image, one point per thread
 // (utils/run_lushnerf_helpers.py:334-361).  With ONE workgroup per CU nothing hides this prologue, so it is built for
-// speed: sin / cos on the hardware unit (v_sin_f32 / v_cos_f32 take revolutions) behind an exact range reduction --
-// x / (2 pi) as a double-float hi + lo (one FMA), times the power of two (exact), v_fract (exact), + the scaled lo -- and
-// the row leaves as twelve 16-byte LDS writes.  Measured against float64 over 2^k [-2, 2], k = 0..9: 4.2e-7 absolute
-// (tests/micro/sincos_hw.hip), 1/500 of the fp16 grid this kernel rounds the result to (the two-plane bf16 kernels, which
-// carry 2^-17, keep the Cody-Waite + fdlibm form of lush_mlp_dev.h).
-__device__ __forceinline__ void wd_sincos_rev(float hi, float lo, int k, float* sn, float* cs) {
-    const float s = (float)(1 << k);
-    const float r = __builtin_amdgcn_fractf(hi * s) + lo * s;
-    *sn = __builtin_amdgcn_sinf(r);
-    *cs = __builtin_amdgcn_cosf(r);
-}
+// speed: hardware sin / cos behind an exact range reduction (sincos_rev, lush_mlp_dev.h: 4.2e-7 absolute, 1/500 of the
+// fp16 grid this kernel rounds the result to), and the row leaves as twelve 16-byte LDS writes.
 __device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid) {
     const long long gpt = tile_pt0 + tid;
     float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (gpt < P) point_of(rays, z, S, gpt, x, d);
-    constexpr float C_HI = 0.15915494309189535f;
-    constexpr float C_LO = (float)(0.15915494309189533576888 - (double)C_HI);
     float v[PE_X + PE_D];
 #pragma unroll
     for (int c = 0; c < PE_X + PE_D; ++c) v[c] = 0.f;      // (col 63 and cols 91..95: zero padding the K loops do read)
@@ -492,12 +481,13 @@ __device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const fl
     for (int i = 0; i < 3; ++i) {
         v[i] = x[i];
         v[PE_X + i] = d[i];
-        const float hx = x[i] * C_HI, lx = __builtin_fmaf(x[i], C_HI, -hx) + x[i] * C_LO;
-        const float hd = d[i] * C_HI, ld = __builtin_fmaf(d[i], C_HI, -hd) + d[i] * C_LO;
+        float hx, lx, hd, ld;
+        rev_split(x[i], &hx, &lx);
+        rev_split(d[i], &hd, &ld);
 #pragma unroll
-        for (int k = 0; k < L_X; ++k) wd_sincos_rev(hx, lx, k, &v[3 + 6 * k + i], &v[3 + 6 * k + 3 + i]);
+        for (int k = 0; k < L_X; ++k) sincos_rev(hx, lx, k, &v[3 + 6 * k + i], &v[3 + 6 * k + 3 + i]);
 #pragma unroll
-        for (int k = 0; k < L_D; ++k) wd_sincos_rev(hd, ld, k, &v[PE_X + 3 + 6 * k + i], &v[PE_X + 3 + 6 * k + 3 + i]);
+        for (int k = 0; k < L_D; ++k) sincos_rev(hd, ld, k, &v[PE_X + 3 + 6 * k + i], &v[PE_X + 3 + 6 * k + 3 + i]);
     }
     char* row = peimg + tid * WD_PE_PITCH;
 #pragma unroll
