@@ -217,8 +217,9 @@ typedef struct {
  * that the variants agree; nothing in the library reads the environment. */
 #define LUSH_VARIANT_FWD_HALF 1      /* one fp16 plane forward: two 128-point workgroups per CU (round 2) instead of 64 points per wave */
 #define LUSH_VARIANT_FWD_512 2       /* ... the one-workgroup 32-points-per-wave kernel (round 1) */
-#define LUSH_VARIANT_BWD_512 4       /* fp16 gradient chain: the one-workgroup kernel instead of two workgroups per CU */
+#define LUSH_VARIANT_BWD_512 4       /* fp16 gradient chain: the one-workgroup 32-points-per-wave kernel (round 1) */
 #define LUSH_VARIANT_HEAD_KERNEL 8   /* one-plane backward: K<=3 head gradients by their own kernel instead of riding in the grouped launch */
+#define LUSH_VARIANT_BWD_HALF 16     /* fp16 gradient chain: two 128-point workgroups per CU (round 2) instead of 64 points per wave */
 
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */

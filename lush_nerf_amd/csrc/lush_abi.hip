@@ -194,6 +194,33 @@ void build_pack_table_wide(const lush_mlp_params* p, PackTable& T, int& blocks) 
     add(p->w_rgb, HV, 3, HV, 1, N::KKV);
 }
 
+// Fourth transposed copy (NetT::bwd4_base): quarter-row stream of mlp_wide_bwd_kernel (lush_mlp_wide_bwd.hip).
+template <class N>
+void build_pack_table_wide_bwd(const lush_mlp_params* p, PackTable& T, int& blocks) {
+    constexpr int HW = N::HW, HV = N::HV, NL = N::NL, SK = N::SKIP, QR = 64;
+    T.n = 0;
+    blocks = 0;
+    int dst = N::bwd4_base;
+    // element (row, k) = W[k][c0 + row]: src = W + c0, row stride 1, k stride = W's row length
+    auto add = [&](const float* src, int sk, int rows, int cols, int nrb, int kk) {
+        PackJob& j = T.j[T.n++];
+        j.src = src; j.sr = 1; j.sk = sk; j.rows = rows; j.cols = cols; j.nrb = nrb; j.kk = kk; j.perm = 1;
+        j.dst_entry = dst; j.first_block = blocks;
+        blocks += nrb * kk;
+        dst += nrb * kk;
+    };
+    const int XV = PE_X_VALID, DV = PE_D_VALID;
+    for (int q = 0; q < HW / QR; ++q) add(p->w_views + q * QR, HW + DV, QR, HV, 2, N::KKV);
+    add(p->w_views + HW, HW + DV, DV, HV, 1, N::KKV);
+    for (int q = 0; q < HW / QR; ++q) add(p->w_feat + q * QR, HW, QR, HW, 2, N::KKH);
+    for (int l = NL - 1; l >= 1; --l) {
+        const int ld = l == SK ? XV + HW : HW;
+        for (int q = 0; q < HW / QR; ++q) add(p->w[l] + (l == SK ? XV : 0) + q * QR, ld, QR, HW, 2, N::KKH);
+        if (l == SK) add(p->w[l], ld, XV, HW, 2, N::KKH);
+    }
+    add(p->w[0], XV, XV, HW, 2, N::KKH);
+}
+
 // Third transposed copy (NetT::bwd3_base): half-row stream of mlp_chain_bwd_half_kernel.
 template <class N>
 void build_pack_table_half_bwd(const lush_mlp_params* p, PackTable& T, int& blocks) {
@@ -262,6 +289,10 @@ int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed,
             if (rc) return rc;
             build_pack_table_wide<NetNerf>(prm, T, blocks);     // quarter-row forward stream (64 points per wave)
             if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
+            rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+            if (rc) return rc;
+            build_pack_table_wide_bwd<NetNerf>(prm, T, blocks);     // ... and its transposed twin
+            if (blocks != NetNerf::bwd4_len) return set_error("lush_mlp_pack: transposed quarter-row stream length");
             rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
             if (rc) return rc;
         }

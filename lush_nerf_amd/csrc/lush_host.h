@@ -29,6 +29,8 @@ int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, int variant, 
 // lush_mlp_wide.hip
 size_t mlp_wide_fwd_lds_bytes();
 int launch_mlp_wide_fwd(const MlpFwdArgs& a, hipStream_t s);
+// lush_mlp_wide_bwd.hip
+int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s);
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
 int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s);
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);

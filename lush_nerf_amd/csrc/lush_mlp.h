@@ -16,7 +16,7 @@ namespace lush {
 enum { NET_MAX_LAYERS = 8 };
 enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
 // kernel-variant bits of the C ABI (include/lush_march.h LUSH_VARIANT_*): 0 = the product's choice
-enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8 };
+enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16 };
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -79,7 +79,12 @@ struct NetT {
     // feature part]; RGB one position of 8 k-blocks.
     static constexpr int fwd4_base = bwd3_base + (bwd_END - bwd_VAT);
     static constexpr int fwd4_len = fwd_ALPHA + KKH + (HV / 64) * (8 + 2 * KKH) + KKV;
-    static constexpr int total_entries = fwd4_base + fwd4_len;
+    // ... and of the transposed segments for mlp_wide_bwd_kernel (lush_mlp_wide_bwd.hip), in execution order: VAT per 64-row
+    // quarter (K = HV: 2 positions) | VBT (one position of 8 k-blocks x 1 row block) | FEATT per quarter (4 positions) |
+    // per layer NL-1..1: its four quarters, then (skip layer) the 64 gamma(x) rows as one more quarter | L0T (64 rows).
+    static constexpr int bwd4_base = fwd4_base + fwd4_len;
+    static constexpr int bwd4_len = (HW / 64) * 2 * KKV + KKV + (HW / 64) * 2 * KKH * NL + (SKIP > 0 ? 2 * KKH : 0) + 2 * KKH;
+    static constexpr int total_entries = bwd4_base + bwd4_len;
 
     static constexpr int n_mask_layers = NL + 1;   // h_0..h_{NL-1}, hv
 

@@ -1543,7 +1543,11 @@ static int launch_chain_bwd_half(const MlpBwdArgs& a, hipStream_t s) {
 int launch_mlp_chain_bwd(int net, int planes, const MlpBwdArgs& a, int variant, hipStream_t s) {
     if (planes == PLANES_F16) {
         if (a.scale == nullptr) return set_error("launch_mlp_chain_bwd: the fp16 chain needs its loss scale");
-        if (net == 0) return !(variant & LUSH_VARIANT_BWD_512) ? launch_chain_bwd_half<NetNerf, true, DT_F16>(a, s) : launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
+        if (net == 0) {     // the headline backward: 64 points per wave unless a variant bit selects an older kernel
+            if (variant & LUSH_VARIANT_BWD_512) return launch_chain_bwd_k<NetNerf, 1, true, DT_F16>(a, s);
+            if (variant & LUSH_VARIANT_BWD_HALF) return launch_chain_bwd_half<NetNerf, true, DT_F16>(a, s);
+            return launch_mlp_wide_bwd(a, s);
+        }
         return launch_chain_bwd_k<NetNoise, 1, false, DT_F16>(a, s);
     }
     if (net == 0) {

@@ -18,9 +18,7 @@
 //
 // The schedule is written out: after every MFMA a fixed list of fillers (fragment read / DMA, conversion units of the
 // pending accumulator set, bias re-loads, stash traffic), pinned with sched_barrier.
-#include "lush_common.h"
-#include "lush_mlp.h"
-#include "lush_mlp_dev.h"
+#include "lush_mlp_wide.h"
 #include "lush_host.h"
 
 #include <cstdio>
@@ -29,48 +27,17 @@
 
 namespace lush {
 
-constexpr int WD_MT = 256, WD_NT = 256;     // points per tile, threads (4 waves x 64 points)
-#ifndef LUSH_WD_S
-#define LUSH_WD_S 6
-#endif
-constexpr int WD_S = LUSH_WD_S;             // ring slots = prefetch distance in positions
-constexpr int WD_SLOT = 8192;               // one position: 8 one-KiB fragments
 // PE image of this kernel: rows of 272 bytes (256 + 16), no XOR swizzle.  A 16-lane group of a ds_read_b128 reads 16 different
 // rows at the same chunk: with a pitch of 68 dwords their 4-dword pieces fall on 16 disjoint bank quads (68 r mod 64 = 4 r), so
 // the fragment reads are conflict-free AND chunk offsets are immediates of the instruction (one address register per column
 // block instead of one per (column block, chunk): the XOR-swizzled addresses were hoisted out of the tile loop and spilled).
 constexpr int WD_PE_PITCH = PE_ROW * 2 + 16;
 constexpr int WD_PE_PLANE = WD_MT * WD_PE_PITCH;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-
 enum { WB_NONE = 0, WB_REG = 1, WB_PEX = 2, WB_PED = 3 };     // B operand of a position
 enum { WC_NONE = 0, WC_ACT = 1, WC_ALPHA = 2 };               // what happens to the pending accumulator set
 
 constexpr int WD_WRAP = NetNerf::fwd4_len / 8;      // stream positions per tile
 static_assert(NetNerf::fwd4_len % 8 == 0, "the quarter-row stream is whole positions");
-
-// compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E-1>)
-template <int B, int E, class F>
-__device__ __forceinline__ void wd_unroll(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        wd_unroll<B + 1, E>(f);
-    }
-}
-
-// Two 1-KiB LDS-DMA pieces 4 KiB apart under one M0 save/restore with ONE per-lane offset register: two scalar bases.
-// (The instruction's immediate offset is no help: measured in rounds 2 and 3, it does not move the global address of an
-// LDS-DMA -- `offset:-4096` from base + 4096 fetched the wrong bytes.)
-__device__ __forceinline__ void wd_dma_pair(const void* sbase0, const void* sbase1, unsigned voff, unsigned lds0, unsigned lds1) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase0), "s"(sbase1), "s"(lds0), "s"(lds1) : "memory");
-}
-
-template <int N_>
-__device__ __forceinline__ void wd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 #ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back through lush_debug_prof_wide
 __device__ unsigned long long lush_prof_wide[16];
@@ -80,20 +47,6 @@ __device__ unsigned long long lush_prof_wide[16];
 #define WPROF_T(var)
 #define WPROF_ADD(slot, t0)
 #endif
-
-struct WdCtx {
-#ifdef LUSH_PROF
-    unsigned long long prof[16];
-#endif
-    const char* ring;      // LDS ring (generic pointer, fragment reads)
-    unsigned ring_lds;     // its LDS byte address (DMA destination)
-    const char* gbase;     // stream base (wave-uniform)
-    unsigned slot_off;     // ring byte offset of the slot being consumed (0, SLOT, .. (S-1) SLOT)
-    unsigned fetch_off;    // stream byte offset of the position the next refill DMA fetches (consumed position + S, wrapped)
-    unsigned dma_base;     // ring_lds + 1 KiB x wave: LDS address of this wave's first DMA piece in slot 0
-    int w, lane;
-    unsigned voff;         // per-lane byte offset of this wave's first DMA piece of a position (the second: + 4 KiB)
-};
 
 // Per-pass runtime parameters (wave-uniform unless noted)
 struct WdRt {
@@ -185,10 +138,6 @@ struct WdConv {
 // and the items of the pending accumulator set -- per block its conversion units, its decision-word store and its four
 // bias re-loads, in dependency order -- are poured into the gaps up to a cap of issue slots per gap (raised only if the
 // pass's deadline D could not be met otherwise).
-struct WdCarry {             // registers that live from pass to pass
-    bf16x8 a0[4];            // first-half fragments of the coming position
-    u32x4 sb[4];             // stash rows read back from the LDS tile, waiting to be stored
-};
 
 template <int NRQ, int NPOS, int BMAIN, int KB0, int PRE, int CK, int NRQP, int CKB0, bool MASK, int NRQN, int D, int PQ, bool STASH, int LD>
 struct WdPass {

@@ -14,8 +14,8 @@ from typing import Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("LUSH_SO") or os.path.join(HERE, "liblush_march.so")   # LUSH_SO: developer ablation builds
-SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_mlp_wide.hip", "lush_abi.hip", "lush_march_abi.hip"]
-HEADERS = ["lush_common.h", "lush_mlp.h", "lush_mlp_dev.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
+SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_mlp_wide.hip", "lush_mlp_wide_bwd.hip", "lush_abi.hip", "lush_march_abi.hip"]
+HEADERS = ["lush_common.h", "lush_mlp.h", "lush_mlp_dev.h", "lush_mlp_wide.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
 
 _lib = None
 
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *os.environ.get("LUSH_HIPCC_FLAGS", "").split()]
     # per file: the 64-points-per-wave kernels keep their accumulators in VGPRs (the VALU converts them; AGPR-resident
     # accumulators cost one v_accvgpr_read per value) and let the B-operand buffers, which only MFMAs read, go to AGPRs
-    per_file = {"lush_mlp_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    per_file = {"lush_mlp_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lush_mlp_wide_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     with tempfile.TemporaryDirectory(prefix="lush_build_") as tmp:
         def compile_one(f):
             obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
@@ -149,7 +149,7 @@ _SIGS = {
 EXPORTS = ["lush_last_error"] + list(_SIGS)
 ABI_VERSION = 5
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
-VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL = 1, 2, 4, 8
+VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF = 1, 2, 4, 8, 16
 # include/lush_march.h: LUSH_FAULT_*
 FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
                128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}

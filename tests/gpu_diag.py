@@ -286,8 +286,8 @@ def t_mlp_bwd():
                 e = util.relerr(g, ref)
                 if e > worst:
                     worst, wname = e, n
-                if nf == 3:
-                    rep(f"  dW net={net} {n}", g, ref, tol)
+                if nf == 3 or os.environ.get("LUSH_DIAG_ALL"):
+                    rep(f"  dW net={net} ({nf},{nb}) {n}", g, ref, tol)
             RESULTS.append((f"mlp bwd net={net} ({nf},{nb}) worst [{wname}]", worst, tol, worst <= tol))
             print(f"{'ok  ' if worst <= tol else 'FAIL'} mlp bwd net={net} planes=({nf},{nb}) worst param grad {wname}: {worst:.3e} tol={tol:.1e}")
             drays = torch.zeros(R, 11, device=dev)
