@@ -26,6 +26,7 @@ constexpr int WB_WRAP = NetNerf::bwd4_len / 8;      // stream positions per tile
 static_assert(NetNerf::bwd4_len % 8 == 0, "the transposed quarter-row stream is whole positions");
 constexpr int WB_DPE_LD = 104;                      // 16-bit elements per point in the d(gamma) image (96 used; rows stay 16-byte aligned;
                                                     // 52 dwords: 16 rows at one chunk fall on 16 disjoint bank quads)
+constexpr int WB_SB = 2;                            // stash rows in flight between their LDS read-back and their store
 enum { WK_NONE = 0, WK_ACT = 1, WK_ID = 2 };        // pending set: nothing / ReLU mask + fp16 / fp16 only
 
 // Per-pass runtime parameters
@@ -37,34 +38,70 @@ struct WbRt {
     unsigned mdst;           // uniform: their LDS address (column block 0; block 1: + 1 KiB)
     unsigned mvoff;          // per-lane: 16 lane
     char* tile;              // this wave's two 4-KiB LDS transposition tiles
+    const char* lut;         // LDS: [256][4] dwords, entry of byte b: dword i = halfword masks of bits 2i, 2i+1 (0xFFFF where the bit is set)
     char* srows;             // uniform: stash rows of this wave's first point
     unsigned srow_off;       // per-lane: byte offset of (row lane>>3, 16-byte chunk lane&7) in a [point][HW] array
 };
 
 struct WbConvTmp {
-    unsigned w;              // decision word of the current block
-    unsigned X;              // its byte t as 0/1 halfword pairs: bit 2i = value 2i, bit 2i+16 = value 2i+1
+    unsigned w[4];           // decision words of the pending set's four blocks (read in gap 0)
+    u32x4 Y[2];              // halfword masks of the 8 values of (block, t): table entry of the word's byte t
     unsigned o[4];           // packed pairs of the current (block, t)
 };
+
+// item kinds of a pending set's stream
+enum { WI_L = 0, WI_P = 1, WI_ID = 2, WI_IA = 3, WI_IB = 4 };
+struct WbItem { int kind, b, t, i; };
 
 // ---------------------------------------------------------------------------------------------
 // one quarter pass
 // ---------------------------------------------------------------------------------------------
 // NRQ = 2: position = 4 k-blocks x 2 row blocks, unit u = (k-block u/2, row block u%2); NRQ = 1: 8 k-blocks x 1 row block.
-// Pending set (NRQP = 2 row blocks x 2 column blocks; block b = rbl * 2 + c), items per block in dependency order:
-//   WK_ACT: [decision word] then per t = 0, 1: [X of byte t] and per pair i: [v_cvt_pk_f16_f32] [shift, and, v_pk_mul_lo_u16]
-//   WK_ID : per t, per pair: [v_cvt_pk_f16_f32]
-//   INIT  : four [ds_read_b128 of w_alpha, 4 v_mul] that pre-load the set for its next pass
-// poured into the MFMA gaps by the same list scheduler as the forward (a cap of issue slots per gap, deadline D).
+// Pending set (2 row blocks x 2 column blocks; block b = rbl * 2 + c; (b, t) = its accumulators 8t .. 8t+7 = one k-block of
+// the next operand).  The ReLU decisions of (b, t) are one byte; a 4-KiB LDS table turns it into the four halfword-mask
+// dwords of its pairs with ONE ds_read_b128, so a pair costs [v_cvt_pk_f16_f32, v_and_b32] (bit tests on the VALU cost
+// [shift, and, v_pk_mul_lo_u16] more per pair: -x % measured).  Items:
+//   WI_L (b,t)   : table read of (b, t) -- issued one (b, t) ahead of its use, two mask registers sets in ping-pong
+//   WI_P (b,t,i) : convert + mask pair i (i = 3 completes the k-block)         WI_ID: convert only (no activation)
+//   WI_IA/IB (b,j): pre-load of the set for its next pass: ds_read_b128 of w_alpha into the accumulators / 4 v_mul in place
+// poured into the MFMA gaps by the same list scheduler as the forward (a cap of issue slots per gap, deadline D); the four
+// decision words are read in gap 0 and the items start in gap 2.
 template <int NRQ, int NPOS, int CK, int CKB0, bool INIT, bool ZERO, int D, int PQ, bool STASH, int LD, bool MDMA>
 struct WbPass {
     static constexpr int KBPP = 8 / NRQ;
     static constexpr int NG = NPOS * 16;
     static constexpr int DG = D < NG ? D : NG;
-    static constexpr int NBLK = (CK != WK_NONE || INIT) ? 4 : 0;
-    static constexpr int NVB = CK == WK_ACT ? 19 : (CK == WK_ID ? 8 : 0);     // conversion items per block
-    static constexpr int IPB = NVB + (INIT ? 4 : 0);
-    static constexpr int NIT = NBLK * IPB;
+    struct Seq { WbItem it[128]; int n; };
+    static constexpr Seq make_seq() {
+        Seq q{};
+        q.n = 0;
+        auto put = [&](int kind, int b, int t, int i) { q.it[q.n].kind = kind; q.it[q.n].b = b; q.it[q.n].t = t; q.it[q.n].i = i; ++q.n; };
+        auto init = [&](int b) {
+            if (INIT) {
+                for (int j = 0; j < 4; ++j) put(WI_IA, b, 0, j);
+                for (int j = 0; j < 4; ++j) put(WI_IB, b, 0, j);
+            }
+        };
+        if (CK == WK_ACT) {
+            put(WI_L, 0, 0, 0);
+            for (int bt = 0; bt < 8; ++bt) {          // (b, t) in order; the table read of the next (b, t) goes first
+                if (bt + 1 < 8) put(WI_L, (bt + 1) / 2, (bt + 1) % 2, 0);
+                for (int i = 0; i < 4; ++i) put(WI_P, bt / 2, bt % 2, i);
+                if (bt % 2 == 1) init(bt / 2);
+            }
+        } else if (CK == WK_ID) {
+            for (int bt = 0; bt < 8; ++bt) {
+                for (int i = 0; i < 4; ++i) put(WI_ID, bt / 2, bt % 2, i);
+                if (bt % 2 == 1) init(bt / 2);
+            }
+        } else {
+            for (int b = 0; b < 4; ++b) init(b);
+        }
+        return q;
+    }
+    static constexpr Seq SQ = make_seq();
+    static constexpr int NIT = SQ.n;
+    static constexpr int START = CK == WK_ACT ? 2 : 0;      // first gap that takes items
     static_assert(!STASH || NPOS == 4, "the stash pipeline is laid out over the 16 positions of a layer");
 
     struct Regs {
@@ -78,18 +115,22 @@ struct WbPass {
     static constexpr int ST_JOBS = 8;
     static constexpr bool st_write(int g) { return STASH && g % 16 >= 12 && (4 * PQ + g / 16) < ST_JOBS; }
     static constexpr bool st_read(int g) { return STASH && g % 16 >= 12 && (4 * PQ + g / 16) >= 1 && (4 * PQ + g / 16) <= ST_JOBS; }
-    static constexpr bool st_store(int g) { return STASH && g % 16 >= 4 && g % 16 < 8 && (4 * PQ + g / 16) >= 2 && (4 * PQ + g / 16) <= ST_JOBS + 1; }
+    // row i of job J is stored two gaps behind its read-back: gaps 14, 15 of position J + 1 and 0, 1 of position J + 2
+    static constexpr int st_store_job(int g) {       // job whose row leaves in gap g, or -1
+        const int P = 4 * PQ + g / 16, m = g % 16;
+        const int J = m >= 14 ? P - 1 : (m < 2 ? P - 2 : -1);
+        return (STASH && J >= 0 && J < ST_JOBS) ? J : -1;
+    }
+    static constexpr bool st_store(int g) { return st_store_job(g) >= 0; }
     static constexpr bool mdma_at(int g) { return MDMA && g == 6; }
 
     static constexpr int item_weight(int k) {
-        const int r = k % (IPB > 0 ? IPB : 1);
-        if (r >= NVB) return 5;                        // init: read + 4 multiplies
-        if (CK == WK_ID) return 3;
-        if (r == 0) return 1;                          // decision word
-        const int u = (r - 1) % 9;
-        if (u == 0) return 2;                          // X
-        if (u % 2 == 1) return 3;                      // convert (8 cycles once the gap is full)
-        return u == 2 ? 2 : 3;                         // mask
+        const int kind = SQ.it[k].kind;
+        if (kind == WI_L) return 3;                    // byte -> table address (2), ds_read_b128
+        if (kind == WI_P) return 3;                    // convert (8 cycles once the gap is full) + and
+        if (kind == WI_ID) return 3;
+        if (kind == WI_IA) return 1;
+        return 4;
     }
     static constexpr int fixed_load(int g) {
         const int m = g % 16;
@@ -102,6 +143,7 @@ struct WbPass {
         if (st_read(g)) w += 1;
         if (st_store(g)) w += 2;
         if (mdma_at(g)) w += 8;
+        if (CK == WK_ACT && g == 0) w += 4;
         return w;
     }
     struct Sched {
@@ -117,6 +159,7 @@ struct WbPass {
                 int load = fixed_load(g);
                 if (g < DG || g == NG - 1) {
                     while (k < NIT) {
+                        if (g < (k == 0 && CK == WK_ACT ? START - 1 : START)) break;     // (the first table read goes one gap ahead)
                         const int w = item_weight(k);
                         if (load + w > cap && !(g == NG - 1)) break;
                         load += w;
@@ -151,10 +194,16 @@ struct WbPass {
         }
     }
 
+    static __device__ __forceinline__ void load_words(Regs& r, const WbRt& rt) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r.ct.w[b] = *reinterpret_cast<const unsigned short*>(rt.mrd + (b % 2) * 1024 + (b / 2) * 128);
+    }
+
     template <int I, int M>
     static __device__ __forceinline__ void fixed(WdCtx& cx, Regs& r, WdCarry& cr, const char* rd, const char* rd_next, const WbRt& rt) {
         if constexpr (M < 4) {
             r.a1[M] = *reinterpret_cast<const bf16x8*>(rd + (4 + M) * 1024 + cx.lane * 16);
+            if constexpr (CK == WK_ACT && I == 0 && M == 0) load_words(r, rt);
         } else if constexpr (M == 4) {
             r.dma_dst = cx.dma_base + cx.slot_off;              // refill the slot this position frees ...
             r.dma_off = cx.fetch_off;                           // ... with stream position +S
@@ -175,46 +224,37 @@ struct WbPass {
     // filler slot (the compiler gathers it at the head of the basic block, where nothing hides it).
     template <int K>
     static __device__ __forceinline__ void item(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], Regs& r, const WbRt& rt) {
-        constexpr int b = K / IPB, rr = K % IPB, c = b % 2, rbl = b / 2;
-        if constexpr (rr >= NVB) {
-            constexpr int j = rr - NVB;       // 0..3: accumulators 4j .. 4j+3 = rows (0, 4, 16, 20)[j] + 8 h + e of the block
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rt.initw + rbl * 32 + (j == 0 ? 0 : j == 1 ? 4 : j == 2 ? 16 : 20));
-            // Four plain v_mul_f32 as one volatile statement.  Written as C++ the compiler pairs them into v_pk_mul_f32, and with the
-            // last v_pk_mul_f32 of a block directly in front of a run of MFMAs its result was lost in lanes 48..63 (measured:
-            // d_alpha's share missing in accumulators 14 / 15 of those lanes, in whichever waves ran that way; ab/dbg_wb.py
-            // history in DESIGN.md section 5) -- the plain form is right and stays where the schedule puts it.
-            asm volatile("v_mul_f32 %0, %4, %8\n\tv_mul_f32 %1, %5, %8\n\tv_mul_f32 %2, %6, %8\n\tv_mul_f32 %3, %7, %8"
-                         : "=&v"(pend[c][rbl][4 * j]), "=&v"(pend[c][rbl][4 * j + 1]), "=&v"(pend[c][rbl][4 * j + 2]), "=&v"(pend[c][rbl][4 * j + 3])
-                         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(rt.dalpha[c]));
-        } else if constexpr (CK == WK_ID) {
-            constexpr int t = rr / 4, i = rr % 4;
-            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.ct.o[i]) : "v"(pend[c][rbl][8 * t + 2 * i]), "v"(pend[c][rbl][8 * t + 2 * i + 1]));
-            if constexpr (i == 3) {
+        constexpr WbItem it = SQ.it[K];
+        constexpr int b = it.b, t = it.t, c = b % 2, rbl = b / 2;
+        if constexpr (it.kind == WI_L) {
+            unsigned a;
+            asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(a) : "v"(r.ct.w[b]), "n"(8 * t));
+            r.ct.Y[(2 * b + t) % 2] = *reinterpret_cast<const u32x4*>(rt.lut + a * 16);
+        } else if constexpr (it.kind == WI_P || it.kind == WI_ID) {
+            constexpr int i = it.i;
+            if constexpr (it.kind == WI_P)
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_and_b32 %0, %0, %3"
+                             : "=&v"(r.ct.o[i]) : "v"(pend[c][rbl][8 * t + 2 * i]), "v"(pend[c][rbl][8 * t + 2 * i + 1]), "v"(r.ct.Y[(2 * b + t) % 2][i]));
+            else
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.ct.o[i]) : "v"(pend[c][rbl][8 * t + 2 * i]), "v"(pend[c][rbl][8 * t + 2 * i + 1]));
+            if constexpr (i == 3) {      // the k-block leaves as one 128-bit value
                 const u32x4 v = {r.ct.o[0], r.ct.o[1], r.ct.o[2], r.ct.o[3]};
                 xout[c][CKB0 + 2 * rbl + t] = v;
             }
-        } else if constexpr (CK == WK_ACT) {
-            if constexpr (rr == 0) {
-                r.ct.w = *reinterpret_cast<const unsigned short*>(rt.mrd + c * 1024 + rbl * 128);
+        } else {
+            constexpr int j = it.i;       // accumulators 4j .. 4j+3 = rows (0, 4, 16, 20)[j] + 8 h + e of the block
+            if constexpr (it.kind == WI_IA) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rt.initw + rbl * 32 + (j == 0 ? 0 : j == 1 ? 4 : j == 2 ? 16 : 20));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pend[c][rbl][4 * j + e] = v[e];
             } else {
-                constexpr int t = (rr - 1) / 9, u = (rr - 1) % 9;
-                if constexpr (u == 0) {
-                    asm volatile("v_bfe_u32 %0, %1, %2, 8\n\tv_lshl_or_b32 %0, %0, 15, %0" : "=&v"(r.ct.X) : "v"(r.ct.w), "n"(8 * t));
-                } else if constexpr (u % 2 == 1) {
-                    constexpr int i = (u - 1) / 2;
-                    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.ct.o[i]) : "v"(pend[c][rbl][8 * t + 2 * i]), "v"(pend[c][rbl][8 * t + 2 * i + 1]));
-                } else {
-                    constexpr int i = (u - 2) / 2;
-                    unsigned y;     // x * {0,1} per halfword: zero where the ReLU was off
-                    if constexpr (i == 0)
-                        asm volatile("v_and_b32 %1, 0x10001, %2\n\tv_pk_mul_lo_u16 %0, %0, %1" : "+v"(r.ct.o[i]), "=&v"(y) : "v"(r.ct.X));
-                    else
-                        asm volatile("v_lshrrev_b32 %1, %3, %2\n\tv_and_b32 %1, 0x10001, %1\n\tv_pk_mul_lo_u16 %0, %0, %1" : "+v"(r.ct.o[i]), "=&v"(y) : "v"(r.ct.X), "n"(2 * i));
-                    if constexpr (i == 3) {
-                        const u32x4 v = {r.ct.o[0], r.ct.o[1], r.ct.o[2], r.ct.o[3]};
-                        xout[c][CKB0 + 2 * rbl + t] = v;
-                    }
-                }
+                // Four plain v_mul_f32 as one volatile statement.  Written as C++ the compiler pairs them into v_pk_mul_f32, and with
+                // the last v_pk_mul_f32 of a block directly in front of a run of MFMAs its result was lost in lanes 48..63
+                // (measured: d_alpha's share missing in accumulators 14 / 15 of those lanes, in whichever waves ran that way;
+                // DESIGN.md section 5) -- the plain form is right and stays where the schedule puts it.
+                asm volatile("v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4"
+                             : "+v"(pend[c][rbl][4 * j]), "+v"(pend[c][rbl][4 * j + 1]), "+v"(pend[c][rbl][4 * j + 2]), "+v"(pend[c][rbl][4 * j + 3])
+                             : "v"(rt.dalpha[c]));
             }
         }
     }
@@ -227,13 +267,18 @@ struct WbPass {
         wd_unroll<SC.first[G], SC.first[G + 1]>([&](auto kc) __attribute__((always_inline)) { item<decltype(kc)::value>(pend, xout, r, rt); });
     }
 
+    // one 16-byte piece per lane: scalar row base + ONE per-lane offset register (as C++ the four rows of a job, 4 KiB apart, each
+    // held a 64-bit per-lane address: 8 registers this kernel does not have -- the loop then spilled, and every scratch reload
+    // waits vmcnt(0), i.e. for every stash store in flight)
     template <int JOB, int I4>
     static __device__ __forceinline__ void stash_store(const WdCarry& cr, const WbRt& rt) {
         constexpr int c = JOB / 4, j = JOB % 4;
 #ifndef LUSH_ABL_NOSTORE
-        __builtin_nontemporal_store(cr.sb[I4], reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off));
+        // (s_nop 1: a store of more than 8 bytes reads its data registers for two more cycles -- the hazard the compiler covers for its
+        // own stores; without it the conversion's VALU code, which re-uses the row's registers at once, reached memory in some lanes)
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(rt.srow_off), "v"(cr.sb[I4 % WB_SB]), "s"(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2) : "memory");
 #else
-        asm volatile("" ::"v"(cr.sb[I4]));
+        asm volatile("" ::"v"(cr.sb[I4 % WB_SB]));
 #endif
     }
     template <int G>
@@ -242,7 +287,7 @@ struct WbPass {
         return;
 #endif
         constexpr int P = 4 * PQ + G / 16, m = G % 16;
-        if constexpr (st_store(G)) stash_store<P - 2, m - 4>(cr, rt);
+        if constexpr (st_store(G)) stash_store<st_store_job(G), (m >= 14 ? m - 14 : m + 2)>(cr, rt);
         if constexpr (st_write(G)) {
             constexpr int job = P, c = job / 4, j = job % 4, o = m - 12;
             const int n = lane & 31, hh = lane >> 5;
@@ -251,7 +296,7 @@ struct WbPass {
         if constexpr (st_read(G)) {
             constexpr int job = P - 1, i = m - 12;
             const int row = 8 * i + (lane >> 3);
-            cr.sb[i] = *reinterpret_cast<const u32x4*>(rt.tile + (job % 2) * 4096 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+            cr.sb[i % WB_SB] = *reinterpret_cast<const u32x4*>(rt.tile + (job % 2) * 4096 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
         }
     }
 
@@ -307,6 +352,7 @@ struct WbPass {
     // the pending set's whole item stream with no MFMAs to hide behind (tile prologue)
     static __device__ __forceinline__ void convert_now(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], const WbRt& rt) {
         Regs r;
+        if constexpr (CK == WK_ACT) load_words(r, rt);
         wd_unroll<0, NIT>([&](auto kc) __attribute__((always_inline)) { item<decltype(kc)::value>(pend, xout, r, rt); });
     }
 };
@@ -327,6 +373,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     char* stage = ring + WD_S * WD_SLOT;                       // [4 waves][2][4 KiB] stash transposition tiles
     char* maskbuf = stage + 8 * 4096;                          // [4 waves][2 parities][2 column blocks][1 KiB]
     __bf16* dpe = reinterpret_cast<__bf16*>(maskbuf + 4 * 4096);   // [256 points][WB_DPE_LD] d(gamma), fp16
+    unsigned* lut = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dpe) + WD_MT * WB_DPE_LD * 2);   // [256][4]: halfword masks of a decision byte
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -335,6 +382,10 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     {
         const float* f32 = reinterpret_cast<const float*>(wbase + (long long)N::total_entries * 1024);
         for (int i = tid; i < 3 * HV + HW; i += WD_NT) wtab[i] = f32[N::f32_w_rgb + i];
+    }
+    for (int i = threadIdx.x; i < 1024; i += WD_NT) {
+        const int b = i >> 2, p2 = 2 * (i & 3);
+        lut[i] = (((b >> p2) & 1) ? 0x0000FFFFu : 0u) | (((b >> (p2 + 1)) & 1) ? 0xFFFF0000u : 0u);
     }
     const float* w_rgb = wtab;
     const float* w_alpha = wtab + 3 * HV;
@@ -362,6 +413,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     rt.srows = nullptr;
     rt.srow_off = (unsigned)(((lane >> 3) * HW + (lane & 7) * 8) * 2);
     rt.mvoff = (unsigned)lane * 16u;
+    rt.lut = reinterpret_cast<const char*>(lut);
     rt.initw = w_alpha + 8 * h;
     rt.mrd = mbuf_w + 2 * lane;
     // d(gamma) columns 32 b + 16 t + 8 h + (0..7) of this lane's point in column block c
@@ -424,10 +476,6 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             dr[c].x *= gscale; dr[c].y *= gscale; dr[c].z *= gscale; dr[c].w *= gscale;
             rt.dalpha[c] = dr[c].w;
         }
-        // the point this THREAD differentiates the encoding at in the tile's epilogue (point row0 + lane): loaded here, so that
-        // no load waits behind the tile's stash stores
-        float px[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
-        if (wpt + lane < A.P) point_of(A.rays, A.z, A.S, wpt + lane, px, pd);
         wd_wait_vm<0>();
         lds_barrier();         // the first position's pieces of every wave have landed (and wtab, first tile)
 
@@ -523,7 +571,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         auto layer = [&](int l, u32x4 (&xin)[2][16], u32x4 (&xout)[2][16]) __attribute__((always_inline)) {
             const char* ml = mbuf_w + (l % 2) * 2048 + 2 * lane;            // decisions of h_l (the pending last quarter of dZ_l)
             const char* mo = mbuf_w + ((l - 1) % 2) * 2048 + 2 * lane;      // decisions of h_{l-1}
-            rt.srows = reinterpret_cast<char*>(A.dz0 + (long long)l * A.dz_stride + wpt * HW);
+            rt.srows = const_cast<char*>(wd_uniform(reinterpret_cast<const char*>(A.dz0 + (long long)l * A.dz_stride + wpt * HW)));
             rt.mrd = ml + 6 * 128;
             WbPass<2, 4, WK_ACT, 12, false, true, 48, 0, true, HW, false>::run(cx, accA, accB, xin, xin, a0, rt);
             rt.mrd = mo;
@@ -552,6 +600,10 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         // ---- layer 0: d gamma(x) += W_0^T dZ_0; set B (last quarter of dZ_0) -> k-blocks 12..15 ----
         rt.mrd = mbuf_w + 2 * lane + 6 * 128;              // h_0: parity 0
         WbPass<2, 4, WK_ACT, 12, false, true, 48, 0, false, HW, false>::run(cx, accA, accB, B0, B0, a0, rt);
+        // the point this THREAD differentiates the encoding at (point row0 + lane): loaded in front of the dZ_0 row stores, so the
+        // wait for it counts them as younger instead of draining them
+        float px[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
+        if (wpt + lane < A.P) point_of(A.rays, A.z, A.S, wpt + lane, px, pd);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             dpe_add(accA[c][0], c, 0); dpe_add(accA[c][1], c, 1);
@@ -613,7 +665,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
 int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s) {
     using N = NetNerf;
     auto k = mlp_wide_bwd_kernel<N>;
-    const size_t lds = (size_t)(3 * N::HV + N::HW) * 4 + (size_t)WD_S * WD_SLOT + 8 * 4096 + 4 * 4096 + (size_t)WD_MT * WB_DPE_LD * 2;
+    const size_t lds = (size_t)(3 * N::HV + N::HW) * 4 + (size_t)WD_S * WD_SLOT + 8 * 4096 + 4 * 4096 + (size_t)WD_MT * WB_DPE_LD * 2 + 4096;
     if (a.scale == nullptr) return set_error("launch_mlp_wide_bwd: the fp16 chain needs its loss scale");
     int dev = 0, n_cu = 0;
     LUSH_HIP(hipGetDevice(&dev));
