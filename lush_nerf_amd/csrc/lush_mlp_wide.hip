@@ -33,6 +33,7 @@ namespace lush {
 // block instead of one per (column block, chunk): the XOR-swizzled addresses were hoisted out of the tile loop and spilled).
 constexpr int WD_PE_PITCH = PE_ROW * 2 + 16;
 constexpr int WD_PE_PLANE = WD_MT * WD_PE_PITCH;
+constexpr int WD_SB = 2;                // stash rows in flight between their LDS read-back and their store
 enum { WB_NONE = 0, WB_REG = 1, WB_PEX = 2, WB_PED = 3 };     // B operand of a position
 enum { WC_NONE = 0, WC_ACT = 1, WC_ALPHA = 2 };               // what happens to the pending accumulator set
 
@@ -134,7 +135,7 @@ struct WdConv {
 // main-position gap g = 16 I + m starts with its FIXED load
 //   m 0..3  : fragment read of the position's second half        m 4, 5 : the scalar slot arithmetic of the coming refill
 //   m 8     : the refill DMA pair + a fragment of the next position   m 9..11 : fragments of the next position
-//   stash   : (layers that stash their input) LDS writes / read-backs in m 12..15, the row stores in m 4..7
+//   stash   : (layers that stash their input) LDS writes / read-backs in m 12..15, each row stored two gaps behind its read-back
 // and the items of the pending accumulator set -- per block its conversion units, its decision-word store and its four
 // bias re-loads, in dependency order -- are poured into the gaps up to a cap of issue slots per gap (raised only if the
 // pass's deadline D could not be met otherwise).
@@ -160,13 +161,21 @@ struct WdPass {
 
     // ---- stash pipeline over the layer's 16 positions P = 4 PQ + I.  Job J = (column block J / 4, k-blocks 4 (J % 4) ..)
     // = 32 rows x 128 bytes: LDS writes in position J (gaps 12..15, tile J % 2), read-backs in position J + 1 (gaps 12..15),
-    // row stores in position J + 2 (gaps 4..7).  The four 128-byte pieces of a 512-byte row are four consecutive jobs, so
+    // each row stored two gaps behind its read-back.  The four 128-byte pieces of a 512-byte row are four consecutive jobs, so
     // they reach memory within a few microseconds of each other: with the pieces of a row spread over the whole layer
     // (round-3 first version) the stash-writing forward took 6 % longer -- the memory side merges what arrives together.
     static constexpr int ST_JOBS = 8;
     static constexpr bool st_write(int g) { return STASH && g % 16 >= 12 && (4 * PQ + g / 16) < ST_JOBS; }
     static constexpr bool st_read(int g) { return STASH && g % 16 >= 12 && (4 * PQ + g / 16) >= 1 && (4 * PQ + g / 16) <= ST_JOBS; }
-    static constexpr bool st_store(int g) { return STASH && g % 16 >= 4 && g % 16 < 8 && (4 * PQ + g / 16) >= 2 && (4 * PQ + g / 16) <= ST_JOBS + 1; }
+    // row i of job J is stored two gaps behind its read-back: gaps 14, 15 of position J + 1 and 0, 1 of position J + 2 (two rows in
+    // flight instead of four; with the stores a position later, in gaps 4..7, the stash-writing forward took 4 % longer)
+    static constexpr int st_store_job(int g) {       // job whose row leaves in gap g, or -1
+        const int P = 4 * PQ + g / 16, m = g % 16;
+        const int J = m >= 14 ? P - 1 : (m < 2 ? P - 2 : -1);
+        return (STASH && J >= 0 && J < ST_JOBS) ? J : -1;
+    }
+    static constexpr int st_store_row(int g) { return g % 16 >= 14 ? g % 16 - 14 : g % 16 + 2; }
+    static constexpr bool st_store(int g) { return st_store_job(g) >= 0; }
 
     // ---- the list scheduler ----
     static constexpr int item_weight(int k) {      // issue slots of item k
@@ -311,9 +320,9 @@ struct WdPass {
     static __device__ __forceinline__ void stash_store(const WdCarry& cr, const WdRt& rt) {
         constexpr int c = JOB / 4, j = JOB % 4;      // uniform row-block base + ONE per-lane offset
 #ifndef LUSH_ABL_NOSTORE
-        __builtin_nontemporal_store(cr.sb[I4], reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off));
+        __builtin_nontemporal_store(cr.sb[I4 % WD_SB], reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off));
 #else
-        asm volatile("" ::"v"(cr.sb[I4]));
+        asm volatile("" ::"v"(cr.sb[I4 % WD_SB]));
 #endif
     }
     template <int G>
@@ -322,7 +331,7 @@ struct WdPass {
         return;
 #endif
         constexpr int P = 4 * PQ + G / 16, m = G % 16;
-        if constexpr (st_store(G)) stash_store<P - 2, m - 4>(cr, rt);
+        if constexpr (st_store(G)) stash_store<st_store_job(G), st_store_row(G)>(cr, rt);
         if constexpr (st_write(G)) {
             constexpr int job = P, c = job / 4, j = job % 4, o = m - 12;
             const int n = lane & 31, hh = lane >> 5;
@@ -331,7 +340,7 @@ struct WdPass {
         if constexpr (st_read(G)) {
             constexpr int job = P - 1, i = m - 12;
             const int row = 8 * i + (lane >> 3);
-            cr.sb[i] = *reinterpret_cast<const u32x4*>(rt.tile + (job % 2) * 4096 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+            cr.sb[i % WD_SB] = *reinterpret_cast<const u32x4*>(rt.tile + (job % 2) * 4096 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
         }
     }
 
