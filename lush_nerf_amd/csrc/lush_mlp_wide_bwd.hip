@@ -23,20 +23,33 @@
 namespace lush {
 
 constexpr int WB_WRAP = NetNerf::bwd4_len / 8;      // stream positions per tile
+#ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back through lush_debug_prof_wbwd
+__device__ unsigned long long lush_prof_wbwd[16];
+#define BPROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define BPROF_ADD(slot, t0) cx.prof[slot] += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define BPROF_T(var)
+#define BPROF_ADD(slot, t0)
+#endif
 static_assert(NetNerf::bwd4_len % 8 == 0, "the transposed quarter-row stream is whole positions");
 constexpr int WB_DPE_LD = 104;                      // 16-bit elements per point in the d(gamma) image (96 used; rows stay 16-byte aligned;
                                                     // 52 dwords: 16 rows at one chunk fall on 16 disjoint bank quads)
+// vector-memory operations every tile boundary issues between the last position of one tile and the first of the next: the prefetch
+// (2 DMA pairs, 2 loads), the 32 row stores of dZ_0, the 2 head-gradient stores and the 16 row stores of dZv (the d(point) stores of
+// a wave that lies beyond P are skipped: not counted)
+constexpr int WB_TILE_OPS = 6 + 32 + 2 + 16;
 constexpr int WB_SB = 2;                            // stash rows in flight between their LDS read-back and their store
 enum { WK_NONE = 0, WK_ACT = 1, WK_ID = 2 };        // pending set: nothing / ReLU mask + fp16 / fp16 only
 
 // Per-pass runtime parameters
 struct WbRt {
-    const char* mrd;         // per-lane LDS pointer: decision word of (column block 0, first row block of the pending set); + c KiB + rbl 128
+    unsigned mrd;            // uniform part of the LDS address of the pending set's decision words (column block 0, its first row block;
+                             // + c KiB + rbl 128; the per-lane part, 2 lane, comes from the DMA offset register at the point of use)
     const float* initw;      // per-lane LDS pointer: w_alpha of the rows the pending set accumulates next (row block 0, 8 h applied)
     float dalpha[2];         // per-lane: scaled d_alpha of this lane's point in column block c
-    const char* msrc[2];     // uniform: the decision words the pass's mask DMA fetches (column block c)
+    const char* msrc[2];     // uniform: the decision words the pass's mask DMA fetches (column block c), minus 1 KiB x wave (the per-lane
+                             // offset register of the DMAs is voff = 16 lane + 1024 w)
     unsigned mdst;           // uniform: their LDS address (column block 0; block 1: + 1 KiB)
-    unsigned mvoff;          // per-lane: 16 lane
     char* tile;              // this wave's two 4-KiB LDS transposition tiles
     const char* lut;         // LDS: [256][4] dwords, entry of byte b: dword i = halfword masks of bits 2i, 2i+1 (0xFFFF where the bit is set)
     char* srows;             // uniform: stash rows of this wave's first point
@@ -66,7 +79,7 @@ struct WbItem { int kind, b, t, i; };
 //   WI_IA/IB (b,j): pre-load of the set for its next pass: ds_read_b128 of w_alpha into the accumulators / 4 v_mul in place
 // poured into the MFMA gaps by the same list scheduler as the forward (a cap of issue slots per gap, deadline D); the four
 // decision words are read in gap 0 and the items start in gap 2.
-template <int NRQ, int NPOS, int CK, int CKB0, bool INIT, bool ZERO, int D, int PQ, bool STASH, int LD, bool MDMA>
+template <int NRQ, int NPOS, int CK, int CKB0, bool INIT, bool ZERO, int D, int PQ, bool STASH, int LD, bool MDMA, int XP = 0>
 struct WbPass {
     static constexpr int KBPP = 8 / NRQ;
     static constexpr int NG = NPOS * 16;
@@ -137,8 +150,8 @@ struct WbPass {
         int w = 0;
         if (m < 4) w += 1;
         if (m == 4 || m == 5) w += 3;
-        if (m == 8) w += 10;
-        if (m >= 9 && m <= 11) w += 1;
+        if (m == 8) w += 9;
+        if (m >= 12) w += 1;
         if (st_write(g)) w += 1;
         if (st_read(g)) w += 1;
         if (st_store(g)) w += 2;
@@ -194,16 +207,21 @@ struct WbPass {
         }
     }
 
-    static __device__ __forceinline__ void load_words(Regs& r, const WbRt& rt) {
+    // (2 lane + 128 w = voff / 8, formed here and dead after the four reads: as a per-lane pointer held through the tile it was
+    // the value the register allocator spilled, and a scratch reload waits vmcnt(0))
+    static __device__ __forceinline__ void load_words(Regs& r, const WbRt& rt, unsigned voff) {
+        unsigned a;
+        asm volatile("v_lshrrev_b32 %0, 3, %1\n\tv_add_u32 %0, %0, %2" : "=&v"(a) : "v"(voff), "s"(rt.mrd));
+        typedef const __attribute__((address_space(3))) unsigned short* lds_u16;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) r.ct.w[b] = *reinterpret_cast<const unsigned short*>(rt.mrd + (b % 2) * 1024 + (b / 2) * 128);
+        for (int b = 0; b < 4; ++b) r.ct.w[b] = *reinterpret_cast<lds_u16>(a + (b % 2) * 1024 + (b / 2) * 128);
     }
 
     template <int I, int M>
     static __device__ __forceinline__ void fixed(WdCtx& cx, Regs& r, WdCarry& cr, const char* rd, const char* rd_next, const WbRt& rt) {
         if constexpr (M < 4) {
-            r.a1[M] = *reinterpret_cast<const bf16x8*>(rd + (4 + M) * 1024 + cx.lane * 16);
-            if constexpr (CK == WK_ACT && I == 0 && M == 0) load_words(r, rt);
+            r.a1[M] = *reinterpret_cast<const bf16x8*>(rd + (4 + M) * 1024 + cx.voff);
+            if constexpr (CK == WK_ACT && I == 0 && M == 0) load_words(r, rt, cx.voff);
         } else if constexpr (M == 4) {
             r.dma_dst = cx.dma_base + cx.slot_off;              // refill the slot this position frees ...
             r.dma_off = cx.fetch_off;                           // ... with stream position +S
@@ -211,12 +229,11 @@ struct WbPass {
             cx.fetch_off = cx.fetch_off + WD_SLOT == (unsigned)WB_WRAP * WD_SLOT ? 0u : cx.fetch_off + WD_SLOT;
             cx.slot_off = cx.slot_off + WD_SLOT == (unsigned)WD_S * WD_SLOT ? 0u : cx.slot_off + WD_SLOT;
         } else if constexpr (M == 6) {
-            if constexpr (MDMA && I == 0) wd_dma_pair(wd_uniform(rt.msrc[0]), wd_uniform(rt.msrc[1]), rt.mvoff, __builtin_amdgcn_readfirstlane(rt.mdst), __builtin_amdgcn_readfirstlane(rt.mdst + 1024u));
+            if constexpr (MDMA && I == 0) wd_dma_pair(wd_uniform(rt.msrc[0]), wd_uniform(rt.msrc[1]), cx.voff, __builtin_amdgcn_readfirstlane(rt.mdst), __builtin_amdgcn_readfirstlane(rt.mdst + 1024u));
         } else if constexpr (M == 8) {
             wd_dma_pair(cx.gbase + r.dma_off, cx.gbase + r.dma_off + 4096u, cx.voff, r.dma_dst, r.dma_dst + 4096u);
-            cr.a0[0] = *reinterpret_cast<const bf16x8*>(rd_next + cx.lane * 16);
-        } else if constexpr (M >= 9 && M <= 11) {
-            cr.a0[M - 8] = *reinterpret_cast<const bf16x8*>(rd_next + (M - 8) * 1024 + cx.lane * 16);
+        } else if constexpr (M >= 12) {      // (four gaps ahead of their first MFMA, not eight: 8 fewer live registers at the peak)
+            cr.a0[M - 12] = *reinterpret_cast<const bf16x8*>(rd_next + (M - 12) * 1024 + cx.voff);
         }
     }
 
@@ -314,7 +331,7 @@ struct WbPass {
     template <int I>
     static __device__ __forceinline__ void position(WdCtx& cx, f32x16 (&act)[2][2], f32x16 (&pend)[2][2], const u32x4 (&xin)[2][16],
                                                     u32x4 (&xout)[2][16], Regs& r, WdCarry& cr, const WbRt& rt) {
-        const char* rd = cx.ring + cx.slot_off;
+        const char* rd = cx.ring + cx.slot_off;           // (cx.ring is the ring minus 1 KiB x wave: the per-lane part is the DMA offset)
         __builtin_amdgcn_sched_barrier(0);
         wd_unroll<0, 8>([&](auto mc) __attribute__((always_inline)) {
             constexpr int M = decltype(mc)::value;
@@ -326,11 +343,20 @@ struct WbPass {
         });
         // mid-step: my pieces of position +1 have landed (the DMAs of +2 .. +S-1 and what was issued since are younger);
         // after the barrier everyone's have, and nobody reads this position's slot any more
-        constexpr int younger = 2 * (WD_S - 2) + others_in(16 * (I + 1 - WD_S) + 8, 16 * I + 8);
+        // (XP: the pass's first XP positions are among the first S - 1 of a tile: the piece awaited was requested in the previous
+        // tile, in front of everything the tile boundary issues)
+        constexpr int younger = 2 * (WD_S - 2) + others_in(16 * (I + 1 - WD_S) + 8, 16 * I + 8) + (I < XP ? WB_TILE_OPS : 0);
+        BPROF_T(t_w0);
 #ifndef LUSH_ABL_NOVMWAIT
         wd_wait_vm<(younger < 63 ? younger : 63)>();
 #endif
+        BPROF_T(t_w1);
         lds_barrier();
+#ifdef LUSH_PROF
+        cx.prof[5] += t_w1 - t_w0;
+        cx.prof[6] += __builtin_amdgcn_s_memtime() - t_w1;
+        cx.prof[7] += 1;
+#endif
         const char* rd_next = cx.ring + cx.slot_off;        // (slot_off already names the next slot: gap 5)
         __builtin_amdgcn_sched_barrier(0);
         wd_unroll<8, 16>([&](auto mc) __attribute__((always_inline)) {
@@ -350,9 +376,9 @@ struct WbPass {
     }
 
     // the pending set's whole item stream with no MFMAs to hide behind (tile prologue)
-    static __device__ __forceinline__ void convert_now(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], const WbRt& rt) {
+    static __device__ __forceinline__ void convert_now(f32x16 (&pend)[2][2], u32x4 (&xout)[2][16], const WbRt& rt, unsigned voff) {
         Regs r;
-        if constexpr (CK == WK_ACT) load_words(r, rt);
+        if constexpr (CK == WK_ACT) load_words(r, rt, voff);
         wd_unroll<0, NIT>([&](auto kc) __attribute__((always_inline)) { item<decltype(kc)::value>(pend, xout, r, rt); });
     }
 };
@@ -392,7 +418,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     const float gscale = A.scale[0], ginv = A.scale[1];
 
     WdCtx cx;
-    cx.ring = ring;
+    cx.ring = ring - w * 1024;      // fragment reads add voff = 16 lane + 1024 w: one per-lane register serves the DMAs and the reads
     cx.ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
     cx.gbase = wbase + (long long)N::bwd4_base * 1024;
     cx.slot_off = 0;
@@ -412,10 +438,10 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     rt.tile = stage + w * 8192;
     rt.srows = nullptr;
     rt.srow_off = (unsigned)(((lane >> 3) * HW + (lane & 7) * 8) * 2);
-    rt.mvoff = (unsigned)lane * 16u;
     rt.lut = reinterpret_cast<const char*>(lut);
     rt.initw = w_alpha + 8 * h;
-    rt.mrd = mbuf_w + 2 * lane;
+    const unsigned mrd0 = mbuf_lds - (unsigned)w * 128u;      // + 2 lane + 128 w (= voff / 8) = this lane's word in the wave's buffer
+    rt.mrd = mrd0;
     // d(gamma) columns 32 b + 16 t + 8 h + (0..7) of this lane's point in column block c
     __bf16* const grow0 = dpe + (row0 + n) * WB_DPE_LD + 8 * h;
     auto dpe_put = [&](const f32x16& a, int c, int b) __attribute__((always_inline)) {
@@ -439,52 +465,83 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             for (int i = 0; i < 8; ++i) a[8 * t + i] += elem_to_f32<DT_F16>(v[i]);
         }
     };
-    // 4 k-blocks of one column block -> 32 rows x 128 bytes of a [point][LD_] array, through the wave's LDS tile
-    auto stash_now = [&](const u32x4 (&x)[2][16], int c, int j, char* rows, int LD_) __attribute__((always_inline)) {
+    // 4 k-blocks of one column block -> 32 rows x 128 bytes of a [point][LD_] array, through the wave's LDS tile; the stores go out
+    // through a scalar row base + one per-lane offset (as C++ every row held a 64-bit per-lane address, spilled and reloaded
+    // with vmcnt(0) at the head of every tile)
+    auto stash_now = [&](const u32x4 (&x)[2][16], int c, int j, const char* rows, int LD_) __attribute__((always_inline)) {
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq)
             *reinterpret_cast<u32x4*>(rt.tile + n * 128 + (((2 * kq + h) ^ (n & 7)) << 4)) = x[c][4 * j + kq];
+        const unsigned voff_row = (unsigned)(((lane >> 3) * LD_ + (lane & 7) * 8) * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + (lane >> 3);
             const u32x4 v = *reinterpret_cast<const u32x4*>(rt.tile + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(rows + (((c * 32 + row) * LD_ + j * 64 + (lane & 7) * 8) * 2)));
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff_row), "v"(v), "s"(rows + ((c * 32 + 8 * i) * LD_ + j * 64) * 2) : "memory");
         }
     };
+
+    // What a tile needs before its first MFMA -- d_raw of the lane's two points and the decision words of the views hidden and of
+    // h_{NL-1} -- is fetched while the PREVIOUS tile runs its epilogue (first tile: here), as volatile asm so that this kernel,
+    // not the compiler, places the wait: the tile start then waits for these loads with the dZ_0 rows of the previous tile
+    // still in flight behind them, instead of draining the queue (measured: prologue + epilogue were 20 % of the launch).
+    f32x4 drn[2];
+    auto prefetch = [&](int t) __attribute__((always_inline)) {
+        const long long wp = (long long)t * WD_MT + row0;
+        const char* mb0 = wd_uniform(reinterpret_cast<const char*>(A.mask) + (wp / 32) * CB_BYTES - w * 1024);
+        wd_dma_pair(mb0 + NL * 1024, mb0 + CB_BYTES + NL * 1024, cx.voff, mbuf_lds + (NL % 2) * 2048u, mbuf_lds + (NL % 2) * 2048u + 1024u);
+        wd_dma_pair(mb0 + (NL - 1) * 1024, mb0 + CB_BYTES + (NL - 1) * 1024, cx.voff, mbuf_lds + ((NL - 1) % 2) * 2048u, mbuf_lds + ((NL - 1) % 2) * 2048u + 1024u);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            long long gpt = wp + c * 32 + n;
+            if (gpt >= A.P) gpt = A.P - 1;                    // (zeroed when consumed)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(drn[c]) : "v"((unsigned)(gpt * 16)), "s"(A.draw) : "memory");
+        }
+    };
+    if ((int)blockIdx.x < A.n_tiles) prefetch(blockIdx.x);
+#ifdef LUSH_PROF
+    for (int i = 0; i < 16; ++i) cx.prof[i] = 0;
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * WD_MT;
         const long long wpt = pt0 + row0;
+        BPROF_T(t_tile);
         {   // opaque per tile (keeps the static stream addresses from being hoisted out of the tile loop)
             unsigned long long gb = (unsigned long long)cx.gbase;
             asm volatile("" : "+s"(gb));
             cx.gbase = (const char*)gb;
         }
-        // decision words of (this wave's column block c, mask layer ml): mbase[c] + ml KiB
+        // decision words of (this wave's column block c, mask layer ml): mbase[c] + ml KiB (+ 1 KiB x wave: DMA sources only)
         const char* mbase[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) mbase[c] = wd_uniform(reinterpret_cast<const char*>(A.mask) + (wpt / 32 + c) * CB_BYTES);
-        // mask layer ml lives in parity ml % 2 of the wave's buffer: the views hidden (ml = NL) and h_{NL-1} are needed first
-        wd_dma_pair(mbase[0] + NL * 1024, mbase[1] + NL * 1024, rt.mvoff, mbuf_lds + (NL % 2) * 2048u, mbuf_lds + (NL % 2) * 2048u + 1024u);
-        wd_dma_pair(mbase[0] + (NL - 1) * 1024, mbase[1] + (NL - 1) * 1024, rt.mvoff, mbuf_lds + ((NL - 1) % 2) * 2048u, mbuf_lds + ((NL - 1) % 2) * 2048u + 1024u);
+        for (int c = 0; c < 2; ++c) mbase[c] = wd_uniform(reinterpret_cast<const char*>(A.mask) + (wpt / 32 + c) * CB_BYTES - w * 1024);
+        // the prefetch has landed.  First tile: nothing was issued behind it; later tiles: the 32 row stores of dZ_0 were (and the two
+        // d(point) stores, unless the whole wave lies beyond P: not counted -- an undercount is safe)
+        if (tile == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
+        else asm volatile("s_waitcnt vmcnt(32)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
         float4 dr[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const long long gpt = wpt + c * 32 + n;
-            dr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gpt < A.P) dr[c] = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
-            dr[c].x *= gscale; dr[c].y *= gscale; dr[c].z *= gscale; dr[c].w *= gscale;
+            const bool in = wpt + c * 32 + n < A.P;
+            dr[c].x = in ? drn[c][0] * gscale : 0.f; dr[c].y = in ? drn[c][1] * gscale : 0.f;
+            dr[c].z = in ? drn[c][2] * gscale : 0.f; dr[c].w = in ? drn[c][3] * gscale : 0.f;
             rt.dalpha[c] = dr[c].w;
         }
-        wd_wait_vm<0>();
+        BPROF_ADD(1, t_tile);      // wait for the prefetch
+        BPROF_T(t_bar);
         lds_barrier();         // the first position's pieces of every wave have landed (and wtab, first tile)
+        BPROF_ADD(2, t_bar);
+        BPROF_T(t_pro);
 
         f32x16 accA[2][2], accB[2][2];
         u32x4 B0[2][16], B1[2][16];
         WdCarry a0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a0.a0[i] = *reinterpret_cast<const bf16x8*>(cx.ring + cx.slot_off + i * 1024 + lane * 16);
+        for (int i = 0; i < 4; ++i) a0.a0[i] = *reinterpret_cast<const bf16x8*>(cx.ring + cx.slot_off + i * 1024 + cx.voff);
 
+#ifndef LUSH_ABL_NOPRO      // timing ablation only (wrong results)
         // ---- dZv = (Wrgb^T d_rgb) * relu'(hv): K = 3, a rank-3 update on the VALU; rows 0..63 -> set A, 64..127 -> set B ----
         {
             auto rank3 = [&](f32x16 (&acc)[2][2], int r0) __attribute__((always_inline)) {
@@ -504,11 +561,11 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             };
             rank3(accA, 0);
             rank3(accB, 64);
-            const char* m8 = mbuf_w + (NL % 2) * 2048 + 2 * lane;
+            const unsigned m8 = mrd0 + (NL % 2) * 2048;
             rt.mrd = m8;
-            WbPass<2, 1, WK_ACT, 0, false, true, 16, 0, false, HW, false>::convert_now(accA, B1, rt);
+            WbPass<2, 1, WK_ACT, 0, false, true, 16, 0, false, HW, false>::convert_now(accA, B1, rt, cx.voff);
             rt.mrd = m8 + 2 * 128;
-            WbPass<2, 1, WK_ACT, 4, false, true, 16, 0, false, HW, false>::convert_now(accB, B1, rt);
+            WbPass<2, 1, WK_ACT, 4, false, true, 16, 0, false, HW, false>::convert_now(accB, B1, rt, cx.voff);
         }
         // the four head gradients of the lane's points as a hi and a lo 16-bit plane in the 8 extra columns of their dZv rows
         if (h == 0) {
@@ -530,16 +587,21 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             }
         }
         {   // dZv rows
-            char* rows = reinterpret_cast<char*>(A.dzv + wpt * LDV);
+            const char* rows = wd_uniform(reinterpret_cast<const char*>(A.dzv + wpt * LDV));
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < N::KKV / 4; ++j) stash_now(B1, c, j, rows, LDV);
         }
+#endif
         // ---- d_feature = Wva^T dZv (four quarters of 2 positions); d gamma(d) = Wvb^T dZv (one position, one row block) ----
-        WbPass<2, 2, WK_NONE, 0, false, true, 32, 0, false, HW, false>::run(cx, accA, accB, B1, B0, a0, rt);
-        WbPass<2, 2, WK_ID, 0, false, true, 28, 0, false, HW, false>::run(cx, accB, accA, B1, B0, a0, rt);
-        WbPass<2, 2, WK_ID, 4, false, true, 28, 0, false, HW, false>::run(cx, accA, accB, B1, B0, a0, rt);
+        BPROF_ADD(3, t_pro);       // rank-3 update, conversion, dZv rows
+        BPROF_T(t_body);
+        if (tile == (int)blockIdx.x) wd_wait_vm<0>();      // (first tile: no previous tile issued what the counts below assume)
+        static_assert(WD_S - 1 == 5, "the first S - 1 positions of a tile: VA0, VA1 and the first of VA2");
+        WbPass<2, 2, WK_NONE, 0, false, true, 32, 0, false, HW, false, 2>::run(cx, accA, accB, B1, B0, a0, rt);
+        WbPass<2, 2, WK_ID, 0, false, true, 28, 0, false, HW, false, 2>::run(cx, accB, accA, B1, B0, a0, rt);
+        WbPass<2, 2, WK_ID, 4, false, true, 28, 0, false, HW, false, 1>::run(cx, accA, accB, B1, B0, a0, rt);
         WbPass<2, 2, WK_ID, 8, false, true, 28, 0, false, HW, false>::run(cx, accB, accA, B1, B0, a0, rt);
         WbPass<1, 1, WK_ID, 12, false, true, 16, 0, false, HW, false>::run(cx, accA, accB, B1, B0, a0, rt);
 #pragma unroll
@@ -556,7 +618,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
                     for (int e = 0; e < 4; ++e) accA[c][rbl][4 * j + e] = v[e] * rt.dalpha[c];
                 }
         {
-            const char* m7 = mbuf_w + ((NL - 1) % 2) * 2048 + 2 * lane;
+            const unsigned m7 = mrd0 + ((NL - 1) % 2) * 2048;
             rt.initw = w_alpha + 8 * h + 64;
             WbPass<2, 4, WK_NONE, 0, true, false, 60, 0, false, HW, false>::run(cx, accA, accB, B0, B1, a0, rt);
             rt.initw = w_alpha + 8 * h + 128; rt.mrd = m7;
@@ -569,8 +631,8 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         }
         // ---- trunk: dZ_{l-1} = (W_l^T dZ_l) * relu'(h_{l-1}), l = NL-1 .. 1; dZ_l rows leave while they are the B operand ----
         auto layer = [&](int l, u32x4 (&xin)[2][16], u32x4 (&xout)[2][16]) __attribute__((always_inline)) {
-            const char* ml = mbuf_w + (l % 2) * 2048 + 2 * lane;            // decisions of h_l (the pending last quarter of dZ_l)
-            const char* mo = mbuf_w + ((l - 1) % 2) * 2048 + 2 * lane;      // decisions of h_{l-1}
+            const unsigned ml = mrd0 + (unsigned)(l % 2) * 2048u;            // decisions of h_l (the pending last quarter of dZ_l)
+            const unsigned mo = mrd0 + (unsigned)((l - 1) % 2) * 2048u;      // decisions of h_{l-1}
             rt.srows = const_cast<char*>(wd_uniform(reinterpret_cast<const char*>(A.dz0 + (long long)l * A.dz_stride + wpt * HW)));
             rt.mrd = ml + 6 * 128;
             WbPass<2, 4, WK_ACT, 12, false, true, 48, 0, true, HW, false>::run(cx, accA, accB, xin, xin, a0, rt);
@@ -598,24 +660,42 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             if (l > 1) layer(l - 1, B0, B1);               // 6, 4, 2
         }
         // ---- layer 0: d gamma(x) += W_0^T dZ_0; set B (last quarter of dZ_0) -> k-blocks 12..15 ----
-        rt.mrd = mbuf_w + 2 * lane + 6 * 128;              // h_0: parity 0
-        WbPass<2, 4, WK_ACT, 12, false, true, 48, 0, false, HW, false>::run(cx, accA, accB, B0, B0, a0, rt);
-        // the point this THREAD differentiates the encoding at (point row0 + lane): loaded in front of the dZ_0 row stores, so the
-        // wait for it counts them as younger instead of draining them
+        // the point this THREAD differentiates the encoding at (point row0 + lane) is loaded in front of the pass: B1 is dead, and
+        // the loads have four positions to land
         float px[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
         if (wpt + lane < A.P) point_of(A.rays, A.z, A.S, wpt + lane, px, pd);
+        rt.mrd = mrd0 + 6 * 128;                           // h_0: parity 0
+        WbPass<2, 4, WK_ACT, 12, false, true, 48, 0, false, HW, false>::run(cx, accA, accB, B0, B0, a0, rt);
+        BPROF_ADD(4, t_body);      // VA .. layer 0
+        BPROF_T(t_epi);
+#ifndef LUSH_ABL_NOEPI      // timing ablation only (wrong results)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             dpe_add(accA[c][0], c, 0); dpe_add(accA[c][1], c, 1);
             dpe_put(accA[c][0], c, 0); dpe_put(accA[c][1], c, 1);
         }
-        {   // dZ_0 rows
-            char* rows = reinterpret_cast<char*>(A.dz0 + wpt * HW);
+        // (the point is consumed here, in front of the prefetch: the compiler's wait for its loads would otherwise cover the
+        // prefetch too, which it cannot count)
+        float rvh[3], rvl[3], rdh[3], rdl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rev_split(px[i], &rvh[i], &rvl[i]);
+            rev_split(pd[i], &rdh[i], &rdl[i]);
+            asm volatile("" : "+v"(rvh[i]), "+v"(rvl[i]), "+v"(rdh[i]), "+v"(rdl[i]));
+        }
+        // (parities 0 / 1 of the decision buffer are free now.  Unconditional -- the last tile fetches its own inputs once more --
+        // so that d_raw's registers are re-defined on every path and dead through the tile body, not carried across it)
+        prefetch(tile + (int)gridDim.x < A.n_tiles ? tile + (int)gridDim.x : tile);
+        {   // dZ_0 rows: behind the prefetch (the tile start counts them as younger), in front of the encoding (B0's 128 registers are
+            // free there: with B0 alive through it the allocator spilled the per-lane DMA offset for the whole kernel)
+            const char* rows = wd_uniform(reinterpret_cast<const char*>(A.dz0 + wpt * HW));
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) stash_now(B0, c, j, rows, HW);
         }
+        BPROF_ADD(9, t_epi);       // image, prefetch, dZ_0 rows
+        BPROF_T(t_enc);
         // ---- through the encoding: d/dx_i = g[i] + sum_k 2^k (cos(2^k x_i) g_sin - sin(2^k x_i) g_cos), one point per thread.
         // The rows of this wave's 64 points were written by this wave alone: LDS operations of a wave execute in order.
         {
@@ -630,9 +710,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             float gx[3], gd[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float hx, lx, hd, ld;
-                rev_split(px[i], &hx, &lx);
-                rev_split(pd[i], &hd, &ld);
+                const float hx = rvh[i], lx = rvl[i], hd = rdh[i], ld = rdl[i];
                 float sx = gv[i], sd = gv[PE_X + i];
 #pragma unroll
                 for (int k = 0; k < L_X; ++k) {
@@ -655,13 +733,32 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
                 o[1] = make_float4(gd[0], gd[1], gd[2], 0.f);
             }
         }
+#endif
+        BPROF_ADD(10, t_enc);
+#ifdef LUSH_PROF
+        cx.prof[8] += 1;
+#endif
     }
+#ifdef LUSH_PROF
+    if (blockIdx.x == 0 && tid == 0) {
+        cx.prof[0] = __builtin_amdgcn_s_memtime() - t_kernel;
+        for (int i = 0; i < 16; ++i) lush_prof_wbwd[i] = cx.prof[i];
+    }
+#endif
     wd_wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+#ifdef LUSH_PROF
+extern "C" int lush_debug_prof_wbwd(unsigned long long* out) {
+    LUSH_HIP(hipDeviceSynchronize());
+    LUSH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lush_prof_wbwd), sizeof(unsigned long long) * 16));
+    return 0;
+}
+#endif
+
 int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s) {
     using N = NetNerf;
     auto k = mlp_wide_bwd_kernel<N>;

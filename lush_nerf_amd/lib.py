@@ -50,12 +50,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with tempfile.TemporaryDirectory(prefix="lush_build_") as tmp:
         def compile_one(f):
             obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
-            cmd = [_hipcc(), *flags, *per_file.get(f, []), "-c", os.path.join(CSRC, f), "-o", obj]
+            guarded = f in per_file      # the 512-register kernels: refuse a build whose scalar registers spilled (see below)
+            cmd = [_hipcc(), *flags, *per_file.get(f, []), *(["-Rpass-analysis=kernel-resource-usage"] if guarded else []),
+                   "-c", os.path.join(CSRC, f), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            if guarded:
+                # Measured twice in round 3 (a forward with scalar-base stash stores: 113 SGPR spills; a profiling build of the
+                # backward: 134): with SGPRs spilled, these kernels -- every register of the file in use, scalar operands in
+                # inline asm -- ran with a wrong scalar base and faulted on the GPU.  Such a build must not reach the GPU.
+                import re
+                spills = [int(m) for m in re.findall(r"SGPRs Spill: (\d+)", r.stderr)]
+                if any(spills) and not os.environ.get("LUSH_ALLOW_SGPR_SPILLS"):
+                    raise RuntimeError(f"{f}: the compiler spilled scalar registers ({spills}); this build is known to fault on the GPU")
             return obj
         with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
             objs = list(ex.map(compile_one, SOURCES))
