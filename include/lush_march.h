@@ -28,7 +28,8 @@ extern "C" {
 typedef void* lush_stream_t;
 
 const char* lush_last_error(void);
-int lush_abi_version(void);   /* 5 (round 3: explicit kernel-variant argument instead of environment switches) */
+int lush_abi_version(void);   /* 6 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
+                             * backward entry points write their outputs instead of accumulating) */
 
 /* ------------------------------------------------------------------ sampling
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
@@ -170,16 +171,16 @@ int lush_rbk_warp_bwd(const float* rays, const int64_t* idx, int N, int M, const
  * rbk_weighted_sum (models/lushnerf.py:100-116): x [N*M][C], ccw [N][M] -> y [N][C]. */
 int lush_wsum_fwd(const float* x, const float* ccw, int N, int M, int C, float* y, lush_stream_t stream);
 int lush_wsum_bwd(const float* x, const float* ccw, int N, int M, int C, const float* dy,
-                  float* dx, float* dccw, lush_stream_t stream);          /* dccw accumulate */
+                  float* dx, float* dccw, lush_stream_t stream);          /* every element of dx, dccw written (no accumulation: ABI 6) */
 /* y = (add ? x + 0.1*sigmoid(nraw) : x) ** (1/2.2) when gamma, else without the
  * power (ToneMapping 'gamma'/'none', utils/run_lushnerf_helpers.py:164-174, and
  * models/lushnerf.py:649, 654).  x [n][3]; nraw [n][3] or NULL. */
 int lush_tonemap_fwd(const float* x, const float* nraw, int n, int gamma, float* y, lush_stream_t stream);
 int lush_tonemap_bwd(const float* x, const float* nraw, int n, int gamma, const float* dy,
-                     float* dx, float* dnraw, lush_stream_t stream);      /* dx, dnraw accumulate */
+                     float* dx, float* dnraw, lush_stream_t stream);      /* every element written */
 /* y = 0.1*sigmoid(x), models/lushnerf.py:649, 660. */
 int lush_noise_act_fwd(const float* x, int n, float* y, lush_stream_t stream);
-int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_stream_t stream); /* accumulate */
+int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_stream_t stream); /* every element written */
 /* Training loss of run_lushnerf.py:652-661: sum over the two colours of
  * 0.5*MSE + 0.5*L1 against target [n][3], times `scale` (the share of a micro-batch in the step's
  * mean; 1 for the plain loss).  loss[0] accumulate (zero it first); ga / gb = d loss / d a, d loss / d b

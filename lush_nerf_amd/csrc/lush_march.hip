@@ -917,7 +917,7 @@ __global__ void wsum_bwd_kernel(const float* __restrict__ x, const float* __rest
         s += g * x[t * C + c];
         if (dx) dx[t * C + c] = g * w;
     }
-    if (dccw) dccw[t] += s;
+    if (dccw) dccw[t] = s;
 }
 
 constexpr float INV_GAMMA = (float)(1.0 / 2.2);
@@ -936,8 +936,8 @@ __global__ void tonemap_bwd_kernel(const float* __restrict__ x, const float* __r
     float v = x[t], sg = 0.f;
     if (nraw) { sg = 1.f / (1.f + expf(-nraw[t])); v += 0.1f * sg; }
     const float gv = gamma ? dy[t] * INV_GAMMA * powf(v, INV_GAMMA - 1.f) : dy[t];
-    if (dx) dx[t] += gv;
-    if (nraw && dnraw) dnraw[t] += gv * 0.1f * sg * (1.f - sg);
+    if (dx) dx[t] = gv;
+    if (nraw && dnraw) dnraw[t] = gv * 0.1f * sg * (1.f - sg);
 }
 __global__ void noise_act_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ y) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -946,7 +946,7 @@ __global__ void noise_act_fwd_kernel(const float* __restrict__ x, int n, float* 
 __global__ void noise_act_bwd_kernel(const float* __restrict__ x, int n, const float* __restrict__ dy,
                                      float* __restrict__ dx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) { const float s = 1.f / (1.f + expf(-x[t])); dx[t] += dy[t] * 0.1f * s * (1.f - s); }
+    if (t < n) { const float s = 1.f / (1.f + expf(-x[t])); dx[t] = dy[t] * 0.1f * s * (1.f - s); }
 }
 __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ tg,
                             int n3, float scale, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
@@ -1071,7 +1071,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 5; }
+int lush_abi_version(void) { return 6; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");

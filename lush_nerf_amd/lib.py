@@ -157,7 +157,7 @@ _SIGS = {
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 5
+ABI_VERSION = 6
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
 VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF = 1, 2, 4, 8, 16
 # include/lush_march.h: LUSH_FAULT_*

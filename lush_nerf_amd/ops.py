@@ -598,7 +598,7 @@ class WSum(torch.autograd.Function):
         N, M, C_ = ctx.dims
         g = _f32(g)
         dx = torch.empty_like(x)
-        dccw = torch.zeros_like(ccw)
+        dccw = torch.empty_like(ccw)
         lib.call("lush_wsum_bwd", lib.ptr(x), lib.ptr(ccw), N, M, C_, lib.ptr(g), lib.ptr(dx), lib.ptr(dccw), _stream())
         return dx, dccw
 
@@ -622,8 +622,8 @@ class ToneMap(torch.autograd.Function):
         g = _f32(g)
         x = ctx.saved_tensors[0]
         nraw = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
-        dx = torch.zeros_like(x)
-        dn = None if nraw is None else torch.zeros_like(nraw)
+        dx = torch.empty_like(x)
+        dn = None if nraw is None else torch.empty_like(nraw)
         lib.call("lush_tonemap_bwd", lib.ptr(x), lib.ptr(nraw), x.numel() // 3, ctx.gamma, lib.ptr(g),
                  lib.ptr(dx), lib.ptr(dn), _stream())
         return dx, dn, None
@@ -643,7 +643,7 @@ class NoiseAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        dx = torch.zeros_like(x)
+        dx = torch.empty_like(x)
         lib.call("lush_noise_act_bwd", lib.ptr(x), x.numel(), lib.ptr(_f32(g)), lib.ptr(dx), _stream())
         return dx
 

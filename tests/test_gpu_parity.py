@@ -656,22 +656,29 @@ def test_march_through_the_c_abi_alone(diag):
         assert worst < 2e-4, worst        # the same kernels: only the order of the fp32 atomics differs
 
 
-# Bands of the long-trajectory test.  Over 300 steps the run is chaotic: the fp32-EQUIVALENT mode (2,2) itself ends up 0.14
-# away from the reference's curve in 25-step window means (0.58 on single steps; the reference is fp32 torch on a CPU, other
-# summation orders, ReLU kinks, Adam's m / sqrt(v)), (2,h) 0.18, (h,h) 0.13 -- the modes cannot be told apart by the curve, which
-# is the point: they train alike.  What is gated: the window means inside 0.35 (twice the largest seen), the loss must fall by
-# the reference's factor within 25 %, and the fine rgb head must have moved the way the reference's moved (cosine of the two
-# 300-step updates > 0.95; seen 0.973 .. 0.984).  The precise per-tensor statement about the gradients is the masked float64
-# check with its cosine gate (gpu_diag.masked_grad_check), which every mode passes on every fixture.
-LONG_TRAJ_BAND = 0.35
+# Bands of the long-trajectory test.  Over 300 steps the run is chaotic (the reference is fp32 torch on a CPU; here other
+# summation orders, fp32 atomics in another order every run, ReLU kinks, Adam's m / sqrt(v)), so every quantity is a
+# distribution.  Measured in round 3 (tests/traj_dist.py: 24 runs per kernel variant of (h,h), 12 of (2,2) and (2,h)):
+#   cosine of the fine rgb head's 300-step update with the reference's: (h,h) mean 0.972 .. 0.976, sd 0.009 .. 0.016, min
+#     0.937 -- the SAME for the round-2 and the round-3 kernels (the four forward x backward combinations differ by less than
+#     their standard errors); (2,2) 0.982 (sd 0.008, min 0.957); (2,h) 0.983 (min 0.974)
+#   largest deviation of the 25-step window means from the reference's curve: mean 0.16 .. 0.18 in every mode, max 0.32
+#   fall of the loss relative to the reference's 12-fold fall: 0.94 .. 1.32 in every mode
+# The modes cannot be told apart by the curve, which is the point: they train alike.  Gated on REPS runs: the mean cosine
+# > 0.94 and every run > 0.88 (five standard deviations below the mean), the mean window deviation < 0.35 and every run
+# < 0.5, every run's fall within a factor 1.5.  A wrong gradient does not land in these bands (a dropped layer gradient or a
+# sign error leaves the cosine below 0.5 and the loss where it started); the precise per-tensor statement is the masked
+# float64 check with its cosine gate (gpu_diag.masked_grad_check), which every mode passes on every fixture.
+LONG_TRAJ_REPS = 4
 
 
 @pytest.mark.parametrize("planes", ["2,2", "2,h", "h,h"])
 def test_long_training_trajectory_follows_the_reference(diag, planes):
     """300 optimisation steps of the REAL reference (make_golden.case_trajectory_long) on teacher targets -- what a second
     weight set renders for the same rays, so the loss genuinely falls -- against Trainer.step in the fp32-equivalent mode,
-    the fall-back (2,h) and the bench headline (h,h): the windowed loss curve inside one band for all modes, the loss
-    must have fallen as the reference's did, and the final fine rgb head must point the way the reference's does."""
+    the fall-back (2,h) and the bench headline (h,h), LONG_TRAJ_REPS runs each: the windowed loss curve inside one band for
+    all modes, the loss must have fallen as the reference's did, and the final fine rgb head must point the way the
+    reference's does."""
     import argparse
     import numpy as np
     from lush_nerf_amd import model as M, ops, synth
@@ -682,38 +689,44 @@ def test_long_training_trajectory_follows_the_reference(diag, planes):
     args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
                               N_importance=Ni, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
                               rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma", render_rmnearplane=80)
-    net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
-                    precision=ops.Precision(*ops.parse_planes(planes)))
-    w0 = synth.all_weights(30, seed, sharp=True, rbk_scale=2.0e4)
-    M.load_reference_weights(net, w0)
-    net = net.to(dev)
-    tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni, kernel_start_iter=0, allkernel_start_iter=0)
-    targets = torch.from_numpy(g["targets"]).to(dev)
-    losses = []
-    for s in range(steps):
-        b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(n, seed, 30, step=s).items()}
-        b["target"] = targets[s]
-        d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(n * 5, Ns, Ni, seed, step=s).items()}
-        losses.append(tr.step(b, s, draws=d))
-    losses = np.asarray([float(x) for x in losses])
-    assert tr.faults() == 0
     ref = np.asarray(g["losses"], dtype=np.float64)
-    win = 25
-    mg = losses[:steps // win * win].reshape(-1, win).mean(1)
-    mr = ref[:steps // win * win].reshape(-1, win).mean(1)
-    dev_w = np.abs(mg - mr) / mr
-    step_dev = np.abs(losses - ref) / ref
-    sd = dict(net.state_dict())
-    wf = sd["mlp_fine.rgb_linear.weight"].detach().cpu().double().numpy()
     wr = np.asarray(g["final_rgb_w"], dtype=np.float64)
-    w_init = np.asarray(w0["mlp_fine.rgb_linear.weight"], dtype=np.float64)
-    du, dr = (wf - w_init).ravel(), (wr - w_init).ravel()
-    cos = float(du @ dr / (np.linalg.norm(du) * np.linalg.norm(dr)))
-    print(f"long trajectory {planes}: reference loss {ref[:win].mean():.4f} -> {ref[-win:].mean():.4f}, here {losses[:win].mean():.4f} -> "
-          f"{losses[-win:].mean():.4f}; windowed deviation max {dev_w.max():.2e} (window {int(dev_w.argmax())}), per-step max {step_dev.max():.2e}, "
-          f"first step {step_dev[0]:.1e}; cosine of the fine rgb head's 300-step update with the reference's {cos:.4f}")
-    assert step_dev[0] < 1e-4                      # step 0 is a pure forward: the 1e-4 output bound
-    assert dev_w.max() < LONG_TRAJ_BAND, (planes, dev_w)
-    fall, fall_ref = losses[-win:].mean() / losses[:win].mean(), ref[-win:].mean() / ref[:win].mean()
-    assert abs(fall / fall_ref - 1.0) < 0.25, (fall, fall_ref)          # it trains as the reference trains (0.085: a 12-fold fall)
-    assert cos > 0.95, cos
+    targets = torch.from_numpy(g["targets"]).to(dev)
+    win = 25
+    mr = ref[:steps // win * win].reshape(-1, win).mean(1)
+    fall_ref = ref[-win:].mean() / ref[:win].mean()
+    cosines, devs = [], []
+    for rep in range(LONG_TRAJ_REPS):
+        net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
+                        precision=ops.Precision(*ops.parse_planes(planes)))
+        w0 = synth.all_weights(30, seed, sharp=True, rbk_scale=2.0e4)
+        M.load_reference_weights(net, w0)
+        net = net.to(dev)
+        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni, kernel_start_iter=0, allkernel_start_iter=0)
+        losses = []
+        for s in range(steps):
+            b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(n, seed, 30, step=s).items()}
+            b["target"] = targets[s]
+            d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(n * 5, Ns, Ni, seed, step=s).items()}
+            losses.append(tr.step(b, s, draws=d))
+        losses = np.asarray([float(x) for x in losses])
+        assert tr.faults() == 0
+        mg = losses[:steps // win * win].reshape(-1, win).mean(1)
+        dev_w = np.abs(mg - mr) / mr
+        step_dev = np.abs(losses - ref) / ref
+        wf = dict(net.state_dict())["mlp_fine.rgb_linear.weight"].detach().cpu().double().numpy()
+        w_init = np.asarray(w0["mlp_fine.rgb_linear.weight"], dtype=np.float64)
+        du, dr = (wf - w_init).ravel(), (wr - w_init).ravel()
+        cos = float(du @ dr / (np.linalg.norm(du) * np.linalg.norm(dr)))
+        fall = losses[-win:].mean() / losses[:win].mean()
+        print(f"long trajectory {planes} run {rep}: reference loss {ref[:win].mean():.4f} -> {ref[-win:].mean():.4f}, here {losses[:win].mean():.4f} -> "
+              f"{losses[-win:].mean():.4f}; windowed deviation max {dev_w.max():.2e} (window {int(dev_w.argmax())}), per-step max {step_dev.max():.2e}, "
+              f"first step {step_dev[0]:.1e}; cosine of the fine rgb head's 300-step update with the reference's {cos:.4f}")
+        assert step_dev[0] < 1e-4                      # step 0 is a pure forward: the 1e-4 output bound
+        assert dev_w.max() < 0.5, (planes, dev_w)
+        assert 1 / 1.5 < fall / fall_ref < 1.5, (fall, fall_ref)            # it trains as the reference trains (0.085: a 12-fold fall)
+        assert cos > 0.88, cos
+        cosines.append(cos)
+        devs.append(float(dev_w.max()))
+    assert np.mean(cosines) > 0.94, cosines
+    assert np.mean(devs) < 0.35, devs
