@@ -21,7 +21,7 @@ steps = bench.get("steps", 4) * (2 if "kernel_timing" in bench else 1) + bench.g
 GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_half_kernel<lush::NetT<256": "mlp_bwd_chain",
-         "mlp_wide_fwd_kernel<lush::NetT<256": "mlp_fwd",
+         "mlp_wide_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_wide_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "dw_group_kernel": "mlp_bwd_weights", "feat_factor_kernel": "mlp_bwd_weights",
          "dw_gemm_kernel": "mlp_bwd_weights", "head_dw_kernel": "mlp_bwd_weights"}
 

@@ -12,6 +12,7 @@ KEEP = {"mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 1>": "mlp_wide_fwd_kernel (o
         "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_chain_fwd_kernel",
         "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_chain_bwd_kernel (one loss-scaled fp16 plane)",
         "mlp_chain_bwd_half_kernel<lush::NetT<256": "mlp_chain_bwd_half_kernel (one loss-scaled fp16 plane, 2 workgroups per CU)",
+        "mlp_wide_bwd_kernel<lush::NetT<256": "mlp_wide_bwd_kernel (one loss-scaled fp16 plane, 64 points per wave, 1 workgroup per CU)",
         "dw_group_kernel": "dw_group_kernel (the weight-gradient GEMMs of the fine pass in one launch)"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "p*", "*", "*_counter_collection.csv")):
