@@ -547,6 +547,68 @@ def test_trainer_over_rccl_two_ranks(diag, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_wide_backward_rows_match_the_half_row_kernel(diag):
+    """mlp_wide_bwd_kernel against mlp_chain_bwd_half_kernel (LUSH_VARIANT_BWD_HALF), element by element on what the chain
+    leaves behind: every dZ_l row the weight-gradient GEMMs read, the dZv rows with the head gradients in their extra columns,
+    and d(point) -- two tiles and a ragged third (640 points: the last 128-point block of the last 256-point tile is padding).
+    The two kernels round the same sums at the same places except that the 64-points-per-wave kernel pre-loads the alpha
+    head's share into the accumulators (instead of adding it last) and takes the encoding derivative's sin / cos from the
+    hardware: a few fp16 values land on the neighbouring grid point (measured 1.2e-4 .. 7.5e-4 of the largest entry of a layer,
+    i.e. one ulp of a mid-sized value; dZv identical).  This is the test that caught, during bring-up, a v_pk_mul_f32 result lost
+    in lanes 48..63 and stash rows overwritten before their store had read them."""
+    import ctypes as C
+    import numpy as np
+    from lush_nerf_amd import lib, ops, synth
+    from oracle import lush_oracle as O
+    dev = torch.device("cuda:0")
+    R, S = 10, 64
+    w = synth.all_weights(30, 0)
+    names = [f"mlp_fine.pts_linears.{l}.{s}" for l in range(8) for s in ("weight", "bias")] + \
+            [f"mlp_fine.{n}.{s}" for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear") for s in ("weight", "bias")]
+    tens = [torch.from_numpy(w[n]).to(dev) for n in names]
+    b = synth.ray_batch(R, 1)
+    batch = O.pack_rays(synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, torch.from_numpy(b["rays"])).to(dev)
+    g = torch.Generator().manual_seed(3)
+    z = (torch.sort(torch.rand(R, S, generator=g), -1)[0] * 4 + 2).to(dev)
+    draw = (torch.randn(R * S, 4, generator=g) * 1e-3).to(dev)
+    H = ops.PLANES_F16
+    pk = ops.mlp_pack(0, H, tens)
+    raw, stash = ops.mlp_forward(0, H, tens, pk, batch, z, True, ops.stash_code(H, H), 0)
+    P = R * S
+    Ppad = (P + 255) // 256 * 256
+    nbytes = lib.load().lush_mlp_dstash_bytes(0, H, P)
+    st = lib.mlp_struct(tens, 8)
+
+    def run(variant):
+        ds = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        dpts = torch.zeros(P, 8, device=dev)
+        lib.call("lush_mlp_bwd_chain", 0, ops.stash_code(H, H), H, lib.ptr(batch), lib.ptr(z), R, S, lib.ptr(pk), C.byref(st),
+                 lib.ptr(draw), lib.ptr(stash), lib.ptr(ds), lib.ptr(dpts), variant, ops._stream())
+        torch.cuda.synchronize()
+        return ds.cpu().numpy(), dpts.cpu().numpy()
+
+    a, da = run(lib.VARIANT_BWD_HALF)
+    bq, db = run(0)
+    al = lambda x: (x + 255) // 256 * 256
+    off = 256 + al(((128 + 8) * 257 + 8 * 129) * 4)          # (lush_abi.hip dstash_layout: scale words, feature-factor scratch)
+    assert np.array_equal(a[:8], bq[:8])                      # the same loss scale
+    worst = 0.0
+    for l in range(8):
+        A = a[off:off + Ppad * 512].view(np.float16).reshape(Ppad, 256).astype(np.float32)[:P]
+        B = bq[off:off + Ppad * 512].view(np.float16).reshape(Ppad, 256).astype(np.float32)[:P]
+        off += al(Ppad * 512)
+        assert np.isfinite(B).all() and np.abs(A).max() > 0
+        err = float(np.abs(A - B).max() / np.abs(A).max())
+        worst = max(worst, err)
+        assert err < 2e-3, (l, err)
+    A = a[off:off + Ppad * 272].view(np.float16).reshape(Ppad, 136).astype(np.float32)[:P]
+    B = bq[off:off + Ppad * 272].view(np.float16).reshape(Ppad, 136).astype(np.float32)[:P]
+    assert np.array_equal(A, B)                               # dZv and the head gradients: the same arithmetic
+    e_pts = float(np.abs(da - db).max() / np.abs(da).max())
+    assert e_pts < 2e-3, e_pts
+    print(f"wide backward against the half-row kernel: dZ rows within {worst:.1e} of a layer's largest entry, dZv identical, d(point) {e_pts:.1e}")
+
+
 @pytest.mark.parametrize("planes,variant", [("h,h", "HEAD_KERNEL"), ("h,h", "BWD_HALF"), ("h,h", "BWD_512"), ("h,h", "FWD_512"),
                                             ("h,h", "FWD_HALF"), ("2,1", "HEAD_KERNEL")])
 def test_variants_agree(tmp_path, planes, variant):
