@@ -301,18 +301,29 @@ def main():
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, c["ns"], 0, kernel_start_iter=1 << 30, distributed=True)
         K = tr.K
 
-        def one(i):
-            b = batches[i % n_batches]
+        state = torch.zeros(lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
+        static = {k: v.clone() for k, v in batches[0].items()}
+
+        def one(i, graph_body=False):
+            b = static if graph_body else batches[i % n_batches]
             tr.flat.grad.zero_()
             rays = ops.gen_rays(b["c2w"], b["view"], b["px"], b["py"], K)
+            if graph_body:      # rate, Adam step count and draw counter from the device step state (include/lush_march.h)
+                net.hooks.state, net.hooks.draw_delta = state, 0
             (rgb, depth, acc, extras), noise = net.render_infer(
                 synth.H_DEF, synth.W_DEF, K, 1 << 15, rays=rays, perturb=1., N_importance=0, N_samples=c["ns"],
                 use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., retraw=True)
             tm = net.tonemapping(rgb)
             ops.TrainLoss.apply(tm, tm, b["target"]).backward()
             a0, a1 = tr.flat.segments[0]
-            tr.steps[0] += 1
-            ops.adam_step(tr.flat.param[a0:a1], tr.flat.grad[a0:a1], tr.m[a0:a1], tr.v[a0:a1], tr.lr(), tr.steps[0])
+            if graph_body:
+                calls, net.hooks.state = net.hooks.draw_delta, None
+                ops.adam_step_state(tr.flat.param[a0:a1], tr.flat.grad[a0:a1], tr.m[a0:a1], tr.v[a0:a1], state, 0)
+                lib.call("lush_step_state_advance", lib.ptr(state), int(calls), 1, float(tr.lrate), float(tr.lrate_decay * 1000), 0.9, 0.999,
+                         ops._stream())
+            else:
+                tr.steps[0] += 1
+                ops.adam_step(tr.flat.param[a0:a1], tr.flat.grad[a0:a1], tr.m[a0:a1], tr.v[a0:a1], tr.lr(), tr.steps[0])
 
         net.hooks.sink = True
         try:
@@ -323,11 +334,32 @@ def main():
             for i in range(steps):
                 one(warmup + i)
             sync()
+            dt_eager = time.perf_counter() - t0
+            # the same step captured in a HIP graph: one launch per step, the batch copied into the graph's tensors first
+            import ctypes as C
+            adam_steps = (C.c_int * 3)(*tr.steps)
+            lib.call("lush_step_state_init", lib.ptr(state), C.c_ulonglong(net.hooks.draw_offset), int(tr.global_step), adam_steps,
+                     float(tr.lrate), float(tr.lrate_decay * 1000), 0.9, 0.999, ops._stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one(0, graph_body=True)
+
+            def replay(i):
+                for k, v in batches[i % n_batches].items():
+                    static[k].copy_(v, non_blocking=True)
+                graph.replay()
+            for i in range(warmup):
+                replay(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                replay(warmup + i)
+            sync()
         finally:
             net.hooks.sink = False
         dt = time.perf_counter() - t0
-        del tr, net
-        return dt
+        del tr, net, graph
+        return dt, dt_eager
 
     def run_eval(pf, steps):
         """NeRFAll.forward(poses=...) -> render_path, one 640x1120 pose per step, forward only."""
@@ -395,9 +427,12 @@ def main():
                               "workload": "NeRFAll.forward(poses) -> render_path, 640x1120 rays per pose, 64+64, chunk 32768"}
         elif name == "C1":
             st = 20
-            cdt = run_c1(pf, pb, st, 3)
+            cdt, cdt_eager = run_c1(pf, pb, st, 3)
             extras["C1"] = {"value": round(256 * world * st / cdt, 1), "unit": "rays/s", "ms_per_step": round(cdt / st * 1e3, 3),
-                            "workload": "N_rand=256, 32+0, naive, entry render_infer, fwd+bwd+Adam (launch-bound: 8 192 MLP evaluations)"}
+                            "ms_per_step_eager": round(cdt_eager / st * 1e3, 3),
+                            "workload": "N_rand=256, 32+0, naive, entry render_infer, fwd+bwd+Adam, 8 192 MLP evaluations: the step captured in a "
+                                        "HIP graph (rate / Adam step / draw counter in the device step state) and replayed; ms_per_step_eager = "
+                                        "the same step launched kernel by kernel from Python"}
         elif name in CONFIGS and name != a.config:
             c = CONFIGS[name]
             st = 3 if name == "C3" else 2

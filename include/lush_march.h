@@ -314,6 +314,24 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
 int lush_adam(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1,
               float beta2, float eps, int step, float grad_scale, lush_stream_t stream);
 
+/* ------------------------------------------------------------- step state on the device
+ * What a training step otherwise takes from the host as kernel arguments -- the learning rate (run_lushnerf.py:675-685), Adam's
+ * step counts (as their bias corrections) and the Philox draw counter -- in lush_step_state_bytes() of device memory, so that a step
+ * captured in a HIP graph (every entry point only enqueues on the caller's stream) advances when the graph is replayed:
+ * lush_draws_state adds the state's draw counter to `offset` (the caller passes the number of the call inside the step),
+ * lush_adam_state reads rate and bias corrections of segment 0..2, lush_step_state_advance ends the step: the draw counter moves by
+ * n_draw_calls, the segments in active_mask and global_step by one, the next rate = lrate * 0.1 ** (max(global_step - 1, 0) /
+ * decay_steps) (computed in double, as the host does). */
+size_t lush_step_state_bytes(void);
+int lush_step_state_init(void* state, unsigned long long draw_base, int global_step, const int* adam_steps /* host, 3 */, double lrate,
+                         double decay_steps, double beta1, double beta2, lush_stream_t stream);
+int lush_step_state_advance(void* state, int n_draw_calls, int active_mask, double lrate, double decay_steps, double beta1,
+                            double beta2, lush_stream_t stream);
+int lush_draws_state(unsigned long long seed, unsigned long long offset, const void* state, float* t_rand, long long n_t,
+                     float* noise_c, long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t stream);
+int lush_adam_state(float* param, const float* grad, float* m, float* v, long long n, const void* state, int segment,
+                    float beta1, float beta2, float eps, float grad_scale, lush_stream_t stream);
+
 /* Test hooks (tests/ only): raw access to a stash array for layer-wise parity. */
 int lush_debug_stash_layout(int net, int planes, long long P, long long* offsets /* host, 16 entries */);
 

@@ -984,9 +984,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
 }
 struct DrawArr { float* p; long long n; int normal; };
 struct DrawSet { DrawArr a[4]; };
-__global__ void draws_kernel(DrawSet S, unsigned long long seed, unsigned long long offset, long long total_quads) {
+__global__ void draws_kernel(DrawSet S, unsigned long long seed, unsigned long long offset, long long total_quads,
+                             const unsigned long long* __restrict__ base_dev) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= total_quads) return;
+    if (base_dev) offset += *base_dev;          // the step state's draw counter (lush_step_state): a captured launch still advances
     long long base = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1056,6 +1058,55 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// Step state on the device (include/lush_march.h lush_step_state): what a training step takes from the host as kernel
+// arguments otherwise -- learning rate, Adam's step counts (as their bias corrections), the Philox draw counter -- so that
+// a step captured in a HIP graph advances when it is replayed.
+struct StepState {
+    unsigned long long draw_base;   // draw calls made before this step
+    int global_step;                // steps taken
+    int steps[3];                   // Adam steps taken per segment
+    float lr;                       // rate of the next step: lrate * 0.1 ** (max(global_step - 1, 0) / decay_steps)
+    float bc1[3], bc2s[3];          // 1 - beta1^t, sqrt(1 - beta2^t) of the next step (t = steps + 1) per segment
+};
+__global__ void adam_state_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long long n, const StepState* __restrict__ st, int seg, float b1,
+                                  float b2, float eps, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lr = st->lr, bc1 = st->bc1[seg], bc2_sqrt = st->bc2s[seg];
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+__device__ void step_state_derive(StepState* st, double lrate, double decay_steps, double b1, double b2) {
+    const int g = st->global_step - 1 > 0 ? st->global_step - 1 : 0;
+    st->lr = (float)(lrate * pow(0.1, (double)g / decay_steps));
+    for (int s = 0; s < 3; ++s) {
+        const double t = (double)(st->steps[s] + 1);
+        st->bc1[s] = (float)(1.0 - pow(b1, t));
+        st->bc2s[s] = (float)sqrt(1.0 - pow(b2, t));
+    }
+}
+__global__ void step_state_advance_kernel(StepState* st, int n_draw_calls, int active_mask, double lrate, double decay_steps,
+                                          double b1, double b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->draw_base += (unsigned long long)n_draw_calls;
+    for (int s = 0; s < 3; ++s)
+        if ((active_mask >> s) & 1) st->steps[s] += 1;
+    st->global_step += 1;
+    step_state_derive(st, lrate, decay_steps, b1, b2);
+}
+__global__ void step_state_init_kernel(StepState* st, unsigned long long draw_base, int global_step, int s0, int s1, int s2,
+                                       double lrate, double decay_steps, double b1, double b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->draw_base = draw_base; st->global_step = global_step;
+    st->steps[0] = s0; st->steps[1] = s1; st->steps[2] = s2;
+    step_state_derive(st, lrate, decay_steps, b1, b2);
 }
 
 }  // namespace lush
@@ -1248,8 +1299,9 @@ int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n
     return 0;
 }
 
-int lush_draws(unsigned long long seed, unsigned long long offset, float* t_rand, long long n_t, float* noise_c,
-               long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t st) {
+static int draws_impl(unsigned long long seed, unsigned long long offset, const unsigned long long* base_dev, float* t_rand,
+                      long long n_t, float* noise_c, long long n_c, float* u, long long n_u, float* noise_f, long long n_f,
+                      lush_stream_t st) {
     DrawSet S{};
     S.a[0] = {t_rand, t_rand ? n_t : 0, 0};
     S.a[1] = {noise_c, noise_c ? n_c : 0, 1};
@@ -1258,9 +1310,18 @@ int lush_draws(unsigned long long seed, unsigned long long offset, float* t_rand
     long long quads = 0;
     for (int i = 0; i < 4; ++i) quads += (S.a[i].n + 3) / 4;
     if (quads == 0) return 0;
-    hipLaunchKernelGGL(draws_kernel, dim3(cdiv(quads, 256)), dim3(256), 0, S_(st), S, seed, offset, quads);
+    hipLaunchKernelGGL(draws_kernel, dim3(cdiv(quads, 256)), dim3(256), 0, S_(st), S, seed, offset, quads, base_dev);
     CHECK_LAUNCH();
     return 0;
+}
+int lush_draws(unsigned long long seed, unsigned long long offset, float* t_rand, long long n_t, float* noise_c,
+               long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t st) {
+    return draws_impl(seed, offset, nullptr, t_rand, n_t, noise_c, n_c, u, n_u, noise_f, n_f, st);
+}
+int lush_draws_state(unsigned long long seed, unsigned long long offset, const void* state, float* t_rand, long long n_t,
+                     float* noise_c, long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t st) {
+    if (!state) return set_error("lush_draws_state: the step state is required");
+    return draws_impl(seed, offset, &static_cast<const StepState*>(state)->draw_base, t_rand, n_t, noise_c, n_c, u, n_u, noise_f, n_f, st);
 }
 
 int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays, lush_stream_t st) {
@@ -1275,6 +1336,33 @@ int lush_adam(float* param, const float* grad, float* m, float* v, long long n, 
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), param, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+size_t lush_step_state_bytes(void) { return sizeof(StepState); }
+int lush_step_state_init(void* state, unsigned long long draw_base, int global_step, const int* adam_steps, double lrate,
+                         double decay_steps, double beta1, double beta2, lush_stream_t st) {
+    if (!state || !adam_steps) return set_error("lush_step_state_init: null argument");
+    hipLaunchKernelGGL(step_state_init_kernel, dim3(1), dim3(1), 0, S_(st), static_cast<StepState*>(state), draw_base, global_step,
+                       adam_steps[0], adam_steps[1], adam_steps[2], lrate, decay_steps, beta1, beta2);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_step_state_advance(void* state, int n_draw_calls, int active_mask, double lrate, double decay_steps, double beta1,
+                            double beta2, lush_stream_t st) {
+    if (!state) return set_error("lush_step_state_advance: null state");
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(1), 0, S_(st), static_cast<StepState*>(state), n_draw_calls,
+                       active_mask, lrate, decay_steps, beta1, beta2);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_adam_state(float* param, const float* grad, float* m, float* v, long long n, const void* state, int segment,
+                    float beta1, float beta2, float eps, float grad_scale, lush_stream_t st) {
+    if (n <= 0) return 0;
+    if (!state || segment < 0 || segment > 2) return set_error("lush_adam_state: bad state / segment");
+    hipLaunchKernelGGL(adam_state_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), param, grad, m, v, n,
+                       static_cast<const StepState*>(state), segment, beta1, beta2, eps, grad_scale);
     CHECK_LAUNCH();
     return 0;
 }

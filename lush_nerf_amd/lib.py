@@ -154,6 +154,11 @@ _SIGS = {
     "lush_march_bwd": ([C.POINTER(MarchCfgC), _p, C.POINTER(MlpParams), C.POINTER(MlpParams), C.POINTER(MarchDraws),
                         C.POINTER(MarchGout), _p, C.POINTER(MlpParams), C.POINTER(MlpParams), _p, _p], _i),
     "lush_adam": ([_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p], _i),
+    "lush_step_state_bytes": ([], _sz),
+    "lush_step_state_init": ([_p, C.c_ulonglong, _i, C.POINTER(_i), C.c_double, C.c_double, C.c_double, C.c_double, _p], _i),
+    "lush_step_state_advance": ([_p, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, _p], _i),
+    "lush_draws_state": ([C.c_ulonglong, C.c_ulonglong, _p, _p, _ll, _p, _ll, _p, _ll, _p, _ll, _p], _i),
+    "lush_adam_state": ([_p, _p, _p, _p, _ll, _p, _i, _f, _f, _f, _f, _p], _i),
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)

@@ -105,11 +105,16 @@ class Hooks:
       sink:  Trainer.step -- parameter gradients are accumulated by the weight-gradient kernels' own atomics straight
              into each parameter's existing .grad buffer (the trainer's flat gradient) and autograd receives None for
              them: no per-tensor temporaries, zero-fills or `grad += tmp` kernels on the step;
-      draw_offset: Philox offset of the next lush_draws call (march_draws)."""
+      draw_offset: Philox offset of the next lush_draws call (march_draws);
+      state: Trainer.step_graph -- the device step state (include/lush_march.h lush_step_state_*): draws then take the
+             state's counter plus `draw_delta`, the number of the call inside the step, so a step captured in a HIP graph
+             draws fresh numbers on every replay (the same numbers the eager step would have drawn)."""
     timer: Optional[KernelTimer] = None
     keep: Optional[dict] = None
     sink: bool = False
     draw_offset: int = 0
+    state: Optional[torch.Tensor] = None
+    draw_delta: int = 0
 
 
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0, variant: int = 0,
@@ -684,6 +689,12 @@ def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gra
              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
 
 
+def adam_step_state(param, grad, m, v, state, segment, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """The same step with rate and bias corrections read from the device step state (Trainer.step_graph)."""
+    lib.call("lush_adam_state", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), param.numel(), lib.ptr(state), int(segment),
+             float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
+
+
 def gen_rays(c2w, view, px, py, K):
     """Device-side get_rays for (view, pixel) pairs: c2w [V,3,4], view/px/py [N] -> rays [N,3,2]
     (utils/run_lushnerf_helpers.py:517-539)."""
@@ -757,11 +768,16 @@ def march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, seed
     (the model's own counter; an explicit `offset` overrides it); stream_id separates data-parallel ranks that share a seed."""
     if seed is None:
         seed = torch.cuda.initial_seed()
+    state = None
     if offset is None:
         if hooks is None:
             raise ValueError("march_draws: give the model's ops.Hooks (its draw counter) or an explicit offset")
-        hooks.draw_offset += 1
-        offset = hooks.draw_offset
+        if hooks.state is not None:        # counter on the device: offset = its value at the head of the step + this call's number
+            hooks.draw_delta += 1
+            offset, state = hooks.draw_delta, hooks.state
+        else:
+            hooks.draw_offset += 1
+            offset = hooks.draw_offset
     d = {}
     if perturb > 0:
         d["t_rand"] = torch.empty(R, N_samples, dtype=torch.float32, device=device)
@@ -774,7 +790,12 @@ def march_draws(R, N_samples, N_importance, perturb, raw_noise_std, device, seed
             d["noise_f"] = torch.empty(R, N_samples + N_importance - 1, dtype=torch.float32, device=device)
     if d:
         g = lambda k: (lib.ptr(d.get(k)), d[k].numel() if k in d else 0)
-        lib.call("lush_draws", C.c_ulonglong(int(seed) & (2 ** 64 - 1)),
-                 C.c_ulonglong((int(stream_id) << 40) + int(offset)), *g("t_rand"), *g("noise_c"), *g("u"), *g("noise_f"),
-                 _stream())
+        if state is None:
+            lib.call("lush_draws", C.c_ulonglong(int(seed) & (2 ** 64 - 1)),
+                     C.c_ulonglong((int(stream_id) << 40) + int(offset)), *g("t_rand"), *g("noise_c"), *g("u"), *g("noise_f"),
+                     _stream())
+        else:
+            lib.call("lush_draws_state", C.c_ulonglong(int(seed) & (2 ** 64 - 1)),
+                     C.c_ulonglong((int(stream_id) << 40) + int(offset)), lib.ptr(state), *g("t_rand"), *g("noise_c"), *g("u"),
+                     *g("noise_f"), _stream())
     return d

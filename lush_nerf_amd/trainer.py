@@ -104,6 +104,8 @@ class Trainer:
         self._fwd_bwd = step_fn or self._hip_forward_backward
         self._adam = ops.adam_step
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
+        self._graph = None                # step_graph: (key, torch.cuda.CUDAGraph, static batch, static loss, draw calls per step, active)
+        self._graph_eager_left = 2        # plain steps before the capture (every lazy initialisation behind the entry points has run)
         self.sync_replicas()
 
     # ------------------------------------------------------------------ data parallel plumbing
@@ -203,6 +205,81 @@ class Trainer:
                 self._adam(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
                            grad_scale=1.0 / self.world)
         self.global_step += 1
+        return loss
+
+    # ------------------------------------------------------------------ the step as one HIP graph
+    def _step_body(self, batch, i, force_naive, state):
+        """What step() enqueues, with rate / Adam step counts / draw counter taken from the device step state."""
+        self.flat.grad.zero_()
+        N = batch["target"].shape[0]
+        mb = self.micro_batch if 0 < self.micro_batch < N else N
+        loss = None
+        hooks = self.model.hooks
+        sink_before, hooks.sink = hooks.sink, True
+        hooks.state, hooks.draw_delta = state, 0
+        try:
+            for a in range(0, N, mb):
+                b = min(a + mb, N)
+                part = self._fwd_bwd(batch, a, b, i, None, (b - a) / N, force_naive)
+                loss = part if loss is None else loss + part
+        finally:
+            hooks.sink, hooks.state = sink_before, None
+        calls = hooks.draw_delta
+        active = [True, not force_naive, False]
+        for s, (a, b) in enumerate(self.flat.segments):
+            if active[s] and b > a:
+                ops.adam_step_state(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], state, s,
+                                    grad_scale=1.0 / self.world)
+        mask = sum(1 << s for s, (a, b) in enumerate(self.flat.segments) if active[s] and b > a)
+        ops.lib.call("lush_step_state_advance", ops.lib.ptr(state), int(calls), int(mask), float(self.lrate),
+                     float(self.lrate_decay * 1000), 0.9, 0.999, ops._stream())
+        return loss, calls, mask
+
+    def step_graph(self, batch: Dict[str, torch.Tensor], i: int):
+        """step() with the whole step -- ray generation, both marches, loss, backward, Adam -- captured once in a HIP graph
+        and replayed: one graph launch instead of ~50 kernel launches from Python (the launch-bound configurations: BASELINE
+        config 1 spends its step in the host's launch path).  What the host passes per step as kernel arguments -- the
+        learning rate, Adam's step counts, the Philox draw counter -- lives in the device step state (lush_step_state_*), which
+        the graph's last node advances, so replays continue exactly where eager steps would: same draws, same rates.
+        The first calls run step() itself (they are real steps); the batch is copied into the graph's static tensors before
+        every replay; the returned loss
+        is the graph's static tensor, overwritten by the next replay.  Single process only: a captured RCCL all-reduce has not
+        been validated (world size 1 skips the all-reduce, which is the identity there); explicit draws, the consistency
+        branch and a rate restored from a checkpoint fall back to step()."""
+        force_naive = i < self.kernel_start_iter
+        allk = i < self.allkernel_start_iter
+        if self.world > 1:
+            raise NotImplementedError("Trainer.step_graph: a captured RCCL all-reduce has not been validated; use step()")
+        if self._lr_next is not None or i >= self.noisenerf_start_iter or self._graph_eager_left > 0 or not self.flat.param.is_cuda:
+            self._graph_eager_left = max(self._graph_eager_left - 1, 0)
+            return self.step(batch, i)
+        key = (force_naive, allk, tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in batch.items())))
+        hooks = self.model.hooks
+        if self._graph is None or self._graph[0] != key:
+            self.model.train()
+            dev = self.flat.param.device
+            state = torch.zeros(ops.lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
+            steps = (ops.C.c_int * 3)(*self.steps)
+            ops.lib.call("lush_step_state_init", ops.lib.ptr(state), ops.C.c_ulonglong(hooks.draw_offset), int(self.global_step), steps,
+                         float(self.lrate), float(self.lrate_decay * 1000), 0.9, 0.999, ops._stream())
+            static = {k: v.clone() for k, v in batch.items()}
+            graph = torch.cuda.CUDAGraph()
+            distributed, self.distributed = self.distributed, False
+            try:
+                with torch.cuda.graph(graph):
+                    loss, calls, mask = self._step_body(static, i, force_naive, state)
+            finally:
+                self.distributed = distributed
+            self._graph = (key, graph, static, loss, calls, mask, state)
+        key, graph, static, loss, calls, mask, state = self._graph
+        for k, v in batch.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        for s in range(3):
+            if (mask >> s) & 1:
+                self.steps[s] += 1
+        self.global_step += 1
+        hooks.draw_offset += calls
         return loss
 
     def faults(self) -> int:

@@ -547,6 +547,62 @@ def test_trainer_over_rccl_two_ranks(diag, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("kernel_on", [True, False])
+def test_step_graph_matches_the_eager_step(diag, kernel_on):
+    """Trainer.step_graph -- the whole step captured in a HIP graph, with the learning rate, Adam's step counts and the Philox
+    draw counter in the device step state (lush_step_state_*) -- against Trainer.step from the same initial state over 8
+    steps (two plain steps, the capture, five replays): the same losses step by step (the same draws and rates; the fp32
+    atomics of the weight gradients in another order), the same counters on the host mirror, and parameters that differ
+    only where Adam's m / sqrt(v) turns an atomics-order difference of a near-zero gradient into a full-size step."""
+    import argparse
+    import numpy as np
+    from lush_nerf_amd import model as M, ops, synth
+    from lush_nerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+
+    def make():
+        args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+                                  N_importance=32, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                                  rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma", render_rmnearplane=80)
+        net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
+                        precision=ops.Precision(*ops.parse_planes("h,h")))
+        M.load_reference_weights(net, synth.all_weights(30, 3, sharp=True))
+        return Trainer(net.to(dev), synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 32, 32, kernel_start_iter=0 if kernel_on else 1 << 30,
+                       allkernel_start_iter=0)
+
+    n, steps = (64 if kernel_on else 256), 8
+    bs = []
+    for s in range(steps):
+        b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(n, 5, 30, step=s).items()}
+        b["target"] = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + s))
+        bs.append(b)
+    torch.manual_seed(1)
+    A = make()
+    p0 = A.flat.param.double().clone()
+    la = [float(A.step(b, s)) for s, b in enumerate(bs)]
+    torch.manual_seed(1)
+    B = make()
+    lb = [float(B.step_graph(b, s)) for s, b in enumerate(bs)]
+    assert B._graph is not None                                   # the capture happened
+    assert A.steps == B.steps and A.global_step == B.global_step and A.model.hooks.draw_offset == B.model.hooks.draw_offset
+    worst = max(abs(x - y) / abs(x) for x, y in zip(la, lb))
+    assert worst < 2e-5, (worst, la, lb)
+    pa, pb = A.flat.param.double(), B.flat.param.double()
+    moved = float((pa - p0).abs().max())
+    d = (pa - pb).abs()
+    outliers = int((d > 2e-2 * moved).sum())
+    ua, ub = pa - p0, pb - p0
+    cos = float((ua @ ub) / (ua.norm() * ub.norm()))
+    # (measured: 978 of 1.3 M parameters apart by more than 2 % of the largest move, the largest by 13 % of it -- what two eager
+    # runs differ by as well: Adam's first steps have size lr whatever the gradient's size, so the sign of a gradient that is
+    # zero up to the atomics' summation order decides a whole step)
+    assert outliers < 5e-3 * pa.numel(), (outliers, float(d.max()), moved)
+    assert cos > 0.999, cos
+    print(f"step_graph (kernel {'on' if kernel_on else 'off'}): losses within {worst:.1e} of the eager steps; {outliers} of {pa.numel()} parameters "
+          f"apart by more than 2 % of the largest 8-step move ({moved:.1e}); largest difference {float(d.max()):.1e}; cosine of the two "
+          f"8-step updates {cos:.6f}")
+
+
 def test_wide_backward_rows_match_the_half_row_kernel(diag):
     """mlp_wide_bwd_kernel against mlp_chain_bwd_half_kernel (LUSH_VARIANT_BWD_HALF), element by element on what the chain
     leaves behind: every dZ_l row the weight-gradient GEMMs read, the dZv rows with the head gradients in their extra columns,
