@@ -225,6 +225,8 @@ typedef struct {
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream);
+/* ... only the copies the kernels selected by `variant` read (variant < 0: all of them, as lush_mlp_pack). */
+int lush_mlp_pack_for(int net, int planes, const lush_mlp_params* prm, void* packed, int variant, lush_stream_t stream);
 /* Bytes of the activation stash for P points (forward -> backward) and of the
  * dZ workspace used inside lush_mlp_bwd. */
 size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P);

@@ -267,6 +267,24 @@ size_t lush_mlp_packed_bytes(int net, int planes) {
     return al256((size_t)n.total_entries * nplanes(planes) * 1024 + (size_t)n.f32_total * 4);
 }
 
+int lush_mlp_pack_for(int net, int planes, const lush_mlp_params* prm, void* packed, int variant, lush_stream_t stream) {
+    // the product's kernels for one fp16 plane on the 8x256 net read the two quarter-row streams and the fp32 block only:
+    // three launches instead of six (the launch-bound configurations pay for every one of them)
+    const int older = LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_BWD_HALF | LUSH_VARIANT_BWD_512;
+    if (net != 0 || planes != PLANES_F16 || variant < 0 || (variant & older)) return lush_mlp_pack(net, planes, prm, packed, stream);
+    PackTable T;
+    int blocks = 0;
+    build_pack_table_wide<NetNerf>(prm, T, blocks);
+    if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
+    int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+    if (rc) return rc;
+    build_pack_table_wide_bwd<NetNerf>(prm, T, blocks);
+    if (blocks != NetNerf::bwd4_len) return set_error("lush_mlp_pack: transposed quarter-row stream length");
+    rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
+}
+
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream) {
     PackTable T;
     int blocks = 0;

@@ -104,7 +104,7 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     float* zc = (float*)(w + L.zc);
     int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, st);
     if (rc) return rc;
-    rc = lush_mlp_pack(0, pf, coarse, w + L.pkc, st);
+    rc = lush_mlp_pack_for(0, pf, coarse, w + L.pkc, cfg->variant, st);
     if (rc) return rc;
     rc = lush_mlp_fwd(0, pf, sc, rays, zc, R, S, w + L.pkc, coarse, (float*)(w + L.rawc), w + L.stashc, var, st);
     if (rc) return rc;
@@ -117,7 +117,7 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     rc = lush_sample_merge(zc, (const float*)(w + L.wc), R, S, Ni, u, zf, (float*)(w + L.zs), out->z_std, flags, st);
     if (rc) return rc;
     if (!cfg->same_net) {
-        rc = lush_mlp_pack(0, pf, pfine, w + L.pkf, st);
+        rc = lush_mlp_pack_for(0, pf, pfine, w + L.pkf, cfg->variant, st);
         if (rc) return rc;
     }
     rc = lush_mlp_fwd(0, pf, sc, rays, zf, R, Sf, w + L.pkf, pfine, (float*)(w + L.rawf), w + L.stashf, var, st);
@@ -151,7 +151,7 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
                                     g_rgb, g_depth, g_acc, draw, drays, st);
         if (rc) return rc;
         if (repack) {       // the backward computes with another plane code than the forward: its own fragments
-            rc = lush_mlp_pack(0, pb, prm, w + pkboff, st);
+            rc = lush_mlp_pack_for(0, pb, prm, w + pkboff, cfg->variant, st);
             if (rc) return rc;
         }
         rc = lush_mlp_bwd(0, sc, pb, rays, z, R, Sp, w + (pb == pf ? pkoff : pkboff), prm, draw, w + stashoff, w + L.dstash, gr, dpts, var, st);

@@ -139,6 +139,7 @@ _SIGS = {
     "lush_draws": ([C.c_ulonglong, C.c_ulonglong, _p, _ll, _p, _ll, _p, _ll, _p, _ll, _p], _i),
     "lush_mlp_packed_bytes": ([_i, _i], _sz),
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
+    "lush_mlp_pack_for": ([_i, _i, C.POINTER(MlpParams), _p, _i, _p], _i),
     "lush_mlp_stash_bytes": ([_i, _i, _i, _ll], _sz),
     "lush_mlp_dstash_bytes": ([_i, _i, _ll], _sz),
     "lush_mlp_fwd": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _i, _p], _i),

@@ -65,11 +65,12 @@ class Precision:
 
 
 # ----------------------------------------------------------------------------- MLP plumbing
-def mlp_pack(net: int, planes: int, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+def mlp_pack(net: int, planes: int, tensors: Sequence[torch.Tensor], variant: int = -1) -> torch.Tensor:
+    """variant >= 0: only the copies the kernels of that variant read (lush_mlp_pack_for); default: every copy."""
     nbytes = lib.load().lush_mlp_packed_bytes(net, planes)
     out = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
     st = lib.mlp_struct(tensors, _NL[net])
-    lib.call("lush_mlp_pack", net, planes, C.byref(st), lib.ptr(out), _stream())
+    lib.call("lush_mlp_pack_for", net, planes, C.byref(st), lib.ptr(out), int(variant), _stream())
     return out
 
 
@@ -417,7 +418,7 @@ class March(torch.autograd.Function):
     def _forward_piecewise(ctx, batch, cfg, d, coarse, fine, same, need_grad):
         pf, pb, var, tm = cfg.precision.fwd, cfg.precision.bwd, cfg.precision.variant, cfg.hooks.timer
         zc = zgrid(batch, cfg.N_samples, cfg.lindisp, d.get("t_rand"))
-        pk_c = mlp_pack(NET_NERF, pf, coarse)
+        pk_c = mlp_pack(NET_NERF, pf, coarse, var)
         raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb), var, tm)
         rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, d.get("noise_c"), cfg,
                                                           lib.FAULT_COARSE_SHIFT if cfg.N_importance > 0 else 0)
@@ -426,7 +427,7 @@ class March(torch.autograd.Function):
         saved = [zc, raw_c, stash_c if stash_c is not None else torch.empty(0, device=batch.device)]
         if cfg.N_importance > 0:
             zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, d.get("u"), cfg.flags)
-            pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine)
+            pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine, var)
             raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb), var, tm)
             rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, d.get("noise_f"), cfg)
             outs = [rgb1, depth1, acc1, density1]
@@ -455,7 +456,7 @@ class March(torch.autograd.Function):
 
         def run(tensors, z, raw, noise, stash, gg):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
-            pk = mlp_pack(NET_NERF, pb, tensors)
+            pk = mlp_pack(NET_NERF, pb, tensors, cfg.precision.variant)
             gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash,
                                     sink=grad_sink(tensors, cfg.hooks), variant=cfg.precision.variant, timer=tm)
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays), _stream())
