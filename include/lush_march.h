@@ -221,6 +221,11 @@ typedef struct {
 #define LUSH_VARIANT_BWD_512 4       /* fp16 gradient chain: the one-workgroup 32-points-per-wave kernel (round 1) */
 #define LUSH_VARIANT_HEAD_KERNEL 8   /* one-plane backward: K<=3 head gradients by their own kernel instead of riding in the grouped launch */
 #define LUSH_VARIANT_BWD_HALF 16     /* fp16 gradient chain: two 128-point workgroups per CU (round 2) instead of 64 points per wave */
+#define LUSH_VARIANT_NO_OVERLAP 32   /* lush_march_bwd: the two passes one after the other on the caller's stream (no second stream) */
+/* launch widths (0 = one workgroup per CU): the weight-gradient launch / the 64-points-per-wave backward chain on at most n
+ * workgroups (n a multiple of 8), so that two kernels can share the chip */
+#define LUSH_VARIANT_DW_WGS(n) ((((n) / 8) & 0xFF) << 8)
+#define LUSH_VARIANT_CHAIN_WGS(n) ((((n) / 8) & 0xFF) << 16)
 
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */

@@ -775,7 +775,8 @@ int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s) {
     const int tiles = (a.n_tiles * 128 + WD_MT - 1) / WD_MT;      // a.n_tiles counts 128-point tiles (point arrays are padded to 256)
     MlpBwdArgs b = a;
     b.n_tiles = tiles;
-    const int grid = tiles < n_cu ? tiles : n_cu;                 // one workgroup per CU, tiles strided
+    const int cus = a.max_wgs > 0 && a.max_wgs < n_cu ? a.max_wgs : n_cu;
+    const int grid = tiles < cus ? tiles : cus;                   // one workgroup per CU, tiles strided
     hipLaunchKernelGGL(k, dim3(grid), dim3(WD_NT), lds, s, b);
     LUSH_HIP(hipGetLastError());
     return 0;
