@@ -282,6 +282,39 @@ class Trainer:
         hooks.draw_offset += calls
         return loss
 
+    def calibrate_overlap(self, batches, i0: int = 0, steps: int = 2) -> dict:
+        """lush_march_bwd runs the fine pass's weight gradients on a second stream beside the coarse pass's chain (two kernels
+        that share the chip only if the runtime gives the two streams different hardware queues -- otherwise they run one after
+        the other on part of the chip each, which is slower than not overlapping at all).  This times `steps` real steps each
+        way on THIS process's streams, keeps the faster setting in the model's precision (all ranks take the slowest rank's
+        view) and returns the two timings in ms per step.  The steps are ordinary optimisation steps."""
+        import time
+        dev = self.flat.param.device
+        if not dev.type == "cuda":
+            return {}
+        base = self.model.precision
+        out = {}
+        k = i0
+        for name, bit in (("overlap", 0), ("one_after_the_other", ops.lib.VARIANT_NO_OVERLAP)):
+            self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | bit)
+            self.step(batches[k % len(batches)], k)       # (one untimed step: lazy initialisation of the second stream)
+            k += 1
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(batches[k % len(batches)], k)
+                k += 1
+            torch.cuda.synchronize(dev)
+            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
+            if self.distributed:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[name] = float(t.item())
+        keep = 0 if out["overlap"] <= out["one_after_the_other"] else ops.lib.VARIANT_NO_OVERLAP
+        self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | keep)
+        out["chosen"] = "overlap" if keep == 0 else "one_after_the_other"
+        out["steps_taken"] = k - i0
+        return out
+
     def faults(self) -> int:
         """Numerical-fault word of the model's render calls since the last read (one device sync; the reference
         prints after every chunk, models/lushnerf.py:474-478, 578-582)."""
