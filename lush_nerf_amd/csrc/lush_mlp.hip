@@ -1160,7 +1160,14 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
 __global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ draw, long long n, float* __restrict__ out,
                                                         unsigned* __restrict__ work /* [2]: running max bits, finished blocks */) {
     float m = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(draw[i]));
+    // 16 bytes per lane and trip (d_raw is [P][4]: n is a multiple of 4 and the rows are 16-byte aligned); with 4-byte loads the
+    // fine pass's 42 MB took 34 us
+    const float4* d4 = reinterpret_cast<const float4*>(draw);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = d4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long i = n / 4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(draw[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     __shared__ float sm[4];
@@ -1323,9 +1330,15 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
     int t = blockIdx.x * 256 + threadIdx.x;
     if (t < n0) {
         const int i = t / HW, k = t % HW;
-        float acc = 0.f;
-        for (int v = 0; v < HV; ++v) acc += a.w_views[(long long)v * a.ldv + i] * a.G[v * HW + k];
-        a.g_w_feat[t] += acc;
+        // (four independent partial sums, eight products in flight: as one dependent chain of HV L2 loads the kernel was
+        // latency-bound, 38-46 us for 0.1 MFLOP)
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int v = 0; v < HV; v += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc4[u] += a.w_views[(long long)(v + u) * a.ldv + i] * a.G[(v + u) * HW + k];
+        }
+        a.g_w_feat[t] += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         return;
     }
     t -= n0;
@@ -1333,12 +1346,16 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
         const int v = t / HW, i = t % HW;
         const float4* g4 = reinterpret_cast<const float4*>(a.G + v * HW);      // scratch: 256-byte aligned
         const float* wr = a.w_feat + (long long)i * HW;                        // a parameter: only 4-byte alignment is promised
-        float acc = 0.f;
-        for (int k = 0; k < HW / 4; ++k) {
-            const float4 g = g4[k];
-            acc += g.x * wr[4 * k] + g.y * wr[4 * k + 1] + g.z * wr[4 * k + 2] + g.w * wr[4 * k + 3];
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int k = 0; k < HW / 4; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 g = g4[k + u];
+                acc4[u] += g.x * wr[4 * (k + u)] + g.y * wr[4 * (k + u) + 1] + g.z * wr[4 * (k + u) + 2] + g.w * wr[4 * (k + u) + 3];
+            }
         }
-        a.g_w_views[(long long)v * a.ldv + i] += acc + a.s[v] * a.b_feat[i];
+        a.g_w_views[(long long)v * a.ldv + i] += ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + a.s[v] * a.b_feat[i];
         return;
     }
     t -= n1;
