@@ -188,8 +188,7 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
         return set_error("lush_march_bwd: gradient buffers of a pass that received output gradients are required");
     int rc = 0;
     bool packed_b_c = false;
-    const int width = var & (LUSH_VARIANT_DW_WGS(2040) | LUSH_VARIANT_CHAIN_WGS(2040));     // explicit launch widths of the caller
-    const int kvar = var & ~(LUSH_VARIANT_DW_WGS(2040) | LUSH_VARIANT_CHAIN_WGS(2040));
+    const int kvar = var & ~(LUSH_VARIANT_DW_WGS(2040) | LUSH_VARIANT_CHAIN_WGS(2040));     // kernel selection without the launch widths
     if (two && any_main) {
         rc = chain(pfine, L.zf, L.rawf, L.stashf, L.pkf, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc, sf, kvar);
         if (rc) return rc;
@@ -233,7 +232,6 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
             return weights(coarse, g_coarse, L.stashc, S, scr_c, kvar, st);
         }
     }
-    (void)width;
     if (any_c) {
         rc = chain(coarse, L.zc, L.rawc, L.stashc, L.pkc, L.pkbc, pb != pf && !packed_b_c, S, noise_c, two ? g->rgb0 : g->rgb,
                    two ? g->depth0 : g->depth, two ? g->acc0 : g->acc, scr_c, kvar);

@@ -65,7 +65,7 @@ struct WdCtx {
 
 struct WdCarry {             // registers that live from pass to pass
     bf16x8 a0[4];            // first-half fragments of the coming position
-    u32x4 sb[4];             // stash rows read back from the LDS tile, waiting to be stored
+    u32x4 sb[2];             // stash rows read back from the LDS tile, waiting to be stored (two in flight)
 };
 
 }  // namespace lush
