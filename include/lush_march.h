@@ -221,6 +221,9 @@ typedef struct {
 #define LUSH_VARIANT_BWD_512 4       /* fp16 gradient chain: the one-workgroup 32-points-per-wave kernel (round 1) */
 #define LUSH_VARIANT_HEAD_KERNEL 8   /* one-plane backward: K<=3 head gradients by their own kernel instead of riding in the grouped launch */
 #define LUSH_VARIANT_BWD_HALF 16     /* fp16 gradient chain: two 128-point workgroups per CU (round 2) instead of 64 points per wave */
+#define LUSH_VARIANT_PE_ROWS 64      /* one fp16 plane: the forward stashes the encoded rows and the weight gradients read them (round 2),
+                                      * instead of 32 bytes per point that the weight-gradient kernel re-encodes; pass the SAME variant word
+                                      * to the forward and the backward of a pass */
 #define LUSH_VARIANT_NO_OVERLAP 32   /* lush_march_bwd: the two passes one after the other on the caller's stream (no second stream) */
 /* launch widths (0 = one workgroup per CU): the weight-gradient launch / the 64-points-per-wave backward chain on at most n
  * workgroups (n a multiple of 8), so that two kernels can share the chip */

@@ -26,7 +26,7 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // `sp` (stash) planes, then the gamma rows with `pf` (forward) planes -- the forward itself
 // re-reads them.  sp == 0 (inference) leaves only the gamma rows.
 struct StashLayout {
-    size_t mask, mask_dummy, pe, h[NET_MAX_LAYERS], feat, hv, total;
+    size_t mask, mask_dummy, pe, xd, h[NET_MAX_LAYERS], feat, hv, total;
     long long Ppad;
 };
 StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
@@ -40,6 +40,7 @@ StashLayout stash_layout(const NetInfo& n, int pf, int sp, long long P) {
     // (FeatFactorArgs): the feature activations are kept for the three-plane reference mode only
     L.feat = off; off += sp >= 3 ? al256((size_t)sp * L.Ppad * n.HW * 2) : 0;
     L.hv = off;   off += al256((size_t)sp * L.Ppad * n.HV * 2);
+    L.xd = off;   off += sp ? al256((size_t)L.Ppad * 32) : 0;      // points and view directions (in front of the gamma rows: independent of pf)
     L.pe = off;   off += al256((size_t)pf * L.Ppad * PE_ROW * 2);
     L.total = off;
     return L;
@@ -367,6 +368,10 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     a.mask = (unsigned long long*)(b + L.mask);
     a.mask_dummy = b + L.mask_dummy;
     a.pe = (__bf16*)(b + L.pe);
+    a.xd = (float*)(b + L.xd);
+    // the weight gradients of the product's one-fp16-plane kernels re-encode gamma(x), gamma(d) from 32 bytes per point; every
+    // other kernel / variant reads the 256-byte encoded rows (the caller passes the same variant word to forward and backward)
+    a.pe_rows = !(net == 0 && planes == PLANES_F16 && stash_planes == 1 && !(variant & (LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_PE_ROWS)));
     a.h0 = (__bf16*)(b + L.h[0]);
     a.h_stride = n.NL > 1 ? (long long)(L.h[1] - L.h[0]) / 2 : 0;
     a.feat = (__bf16*)(b + L.feat);
@@ -461,14 +466,22 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
             j.X2 = nullptr; j.ldx2 = 0; j.x2col0 = 0; j.k2_in = 0;
             j.z_plane = (long long)L.Ppad * ldz; j.x_plane = (long long)L.Ppad * ldx; j.x2_plane = 0;
             j.dW = dW; j.ldw = ldw; j.wcol0 = wcol0; j.dW2 = dW; j.ldw2 = ldw; j.wcol2 = 0; j.n_out2 = n_out; j.db = dbias;
+            j.pe_mode = 0;
             return j;
         };
+        // (the same rule as lush_mlp_fwd: the forward wrote points and view directions instead of encoded rows)
+        const bool reencode = net == 0 && x_f16 && planes_b == 1 && !(variant & (LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_PE_ROWS));
+        G.xd = reencode ? (const float*)(sb + L.xd) : nullptr;
         auto with_pe = [&](DwJob& j, int col0, int k2, float* dW2, int ldw2, int wcol2) {
             j.X2 = pe; j.ldx2 = PE_ROW; j.x2col0 = col0; j.k2_in = k2; j.x2_plane = plane_pe;
             j.dW2 = dW2; j.ldw2 = ldw2; j.wcol2 = wcol2;
+            j.pe_mode = col0 == 0 ? 1 : 2;
         };
         for (int l = 0; l < n.NL; ++l) {
-            if (l == 0) {
+            if (l == 0 && reencode) {      // no rows to stream: the encoding is the job's second input block, computed in the kernel
+                DwJob& j = job(dzp[0], n.HW, n.HW, nullptr, PE_ROW, 0, 0, g->w[0], XV, 0, g->b[0]);
+                with_pe(j, 0, XV, g->w[0], XV, 0);
+            } else if (l == 0) {
                 job(dzp[0], n.HW, n.HW, pe, PE_ROW, 0, XV, g->w[0], XV, 0, g->b[0]);
             } else if (l == n.SKIP) {
                 DwJob& j = job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], XV + n.HW, XV, g->b[l]);

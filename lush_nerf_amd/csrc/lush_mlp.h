@@ -16,7 +16,8 @@ namespace lush {
 enum { NET_MAX_LAYERS = 8 };
 enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
 // kernel-variant bits of the C ABI (include/lush_march.h LUSH_VARIANT_*): 0 = the product's choice
-enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16, LUSH_VARIANT_NO_OVERLAP = 32 };
+enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16, LUSH_VARIANT_NO_OVERLAP = 32,
+       LUSH_VARIANT_PE_ROWS = 64 };
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -153,6 +154,8 @@ struct MlpFwdArgs {
     unsigned long long* mask;      // ReLU sign bits, see mask_index()
     void* mask_dummy;              // 4 KiB nobody reads: where a kernel that runs the feature layer through its ReLU-layer code sends the words
     __bf16* pe;                    // [NS][Ppad][PE_ROW]
+    float* xd;                     // [Ppad][8]: x (3), 0, viewdir (3), 0 -- what the weight gradients re-encode when pe_rows == 0
+    int pe_rows;                   // write the encoded rows to `pe` (kernels / variants whose weight gradients read them)
     __bf16* h0;                    // h_l = h0 + l*h_stride, each [sp][Ppad][HW]
     __bf16* feat;                  // [sp][Ppad][HW]
     __bf16* hv;                    // [sp][Ppad][HV]
@@ -201,6 +204,7 @@ struct DwJob {
     long long z_plane, x_plane, x2_plane;                   // plane strides in elements (two-plane launches)
     float* dW; int ldw; int wcol0;
     float* dW2; int ldw2; int wcol2; int n_out2;            // where the X2 columns go (usually dW / ldw again), rows < n_out2
+    int pe_mode;                                            // DwGroup::xd given: X2 is computed, not read: 1 = gamma(x), 2 = gamma(viewdir)
     float* db;                                              // may be null
 };
 enum { DW_MAX_JOBS = 12 };
@@ -228,6 +232,7 @@ struct DwGroup {
     int Ppad;                      // multiple of 32
     int pts_per_split;             // multiple of 32
     const float* scale;            // {loss scale, 1/scale} when Z is loss-scaled fp16, else null
+    const float* xd;               // [Ppad][8] points and view directions (MlpFwdArgs::xd), or null: every X2 is read from its rows
 };
 
 }  // namespace lush

@@ -931,7 +931,48 @@ struct GrpStream {
     const char* src2;       // X2 (waves 0..3 when the job has one)
     unsigned stride2, voff2, dst2;
     bool on2;
+    // X2 re-encoded instead of read (DwGroup::xd, DwJob::pe_mode): this lane's 16-byte chunk of gamma(.) of its tile row
+    const char* xd;         // uniform; null: X2 is read.  Else: the slice's first point's quadruple (x or viewdir) in DwGroup::xd
+    long long pe_last;      // last valid point of the array relative to the slice's first (reads are clamped to it)
+    unsigned pe_row16;      // per-lane (waves 0..3): 16 x the lane's tile row = its byte offset inside a tile's 512 bytes of quadruples
+    unsigned pe_dst;        // per-lane LDS byte offset of the chunk inside a stage
+    int pe_gch, pe_nvalid;  // source chunk (8 columns) of gamma(.), its number of valid columns (63 / 27)
 };
+// Quadruples (16 bytes per point) of GRP_PE_CHUNK points at a time through two LDS buffers behind the stages: one LDS-DMA per wave
+// and chunk, issued a whole chunk (16 tiles) ahead, so the ordinary ring waits cover it and no wait of its own stands in the loop.
+constexpr int GRP_PE_CHUNK = 512, GRP_PE_BYTES = GRP_PE_CHUNK * 16;
+
+// 8 columns [8 gch, 8 gch + 8) of gamma(c) = [c, sin(2^k c), cos(2^k c) ...] (utils/run_lushnerf_helpers.py:334-361) as fp16 to
+// `dst` (LDS), bit for bit what wd_pe_tile (lush_mlp_wide.hip) wrote into the forward's LDS image: the same range reduction, the
+// same hardware sin / cos, the same rounding.  Columns >= nvalid are zero.  One pair of columns per trip of a ROLLED loop: unrolled,
+// the compiler evaluated the 40 lane predicates of the 8 columns up front (106 scalar registers spilled).
+__device__ __forceinline__ void dw_pe_write(char* dst, const f32x4 c, int gch, int nvalid) {
+    float hi[3], lo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rev_split(c[i], &hi[i], &lo[i]);
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        float v[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = 8 * gch + 2 * p + t;
+            const int q = j < 3 ? 0 : j - 3;
+            const int k = (q * 43) >> 8;                 // q / 6 for 0 <= q < 64
+            const int r = q - 6 * k;
+            const int i = j < 3 ? j : (r < 3 ? r : r - 3);
+            const float ci = i == 0 ? c[0] : (i == 1 ? c[1] : c[2]);
+            const float h_ = i == 0 ? hi[0] : (i == 1 ? hi[1] : hi[2]);
+            const float l_ = i == 0 ? lo[0] : (i == 1 ? lo[1] : lo[2]);
+            const float s = __builtin_ldexpf(1.0f, k);
+            const float rr = __builtin_amdgcn_fractf(h_ * s) + l_ * s;
+            const float sc = r < 3 ? __builtin_amdgcn_sinf(rr) : __builtin_amdgcn_cosf(rr);
+            v[t] = j < 3 ? ci : (j < nvalid ? sc : 0.f);
+        }
+        unsigned w_[1];
+        split_pair<1, DT_F16>(v[0], v[1], w_);
+        *reinterpret_cast<unsigned*>(dst + 4 * p) = w_[0];
+    }
+}
 
 // The streaming loop of one job, specialised on the number of 32-column X2 blocks (0: none, the side accumulator is the
 // bias alone).  Nothing in it depends on the job except through `st` (registers) and three wave-uniform flags.
@@ -952,6 +993,22 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
     const bool bias_lane = (lane & 31) == 31;
     const char* src = st.src;
     const char* src2 = st.src2;
+    constexpr int KT_ = DMA_KT / NS;
+    const char* coords = tiles + DMA_STAGES * GRP_STAGE;         // [2][GRP_PE_BYTES] (allocated when DwGroup::xd is given)
+    int ti = 0;                                                   // tiles issued
+    auto pe_chunk = [&](int k) {      // this wave's 64 quadruples of chunk k -> LDS buffer k & 1 (one LDS-DMA, gathered: 32-byte stride)
+        long long pt = (long long)k * GRP_PE_CHUNK + w * 64 + lane;
+        if (pt > st.pe_last) pt = st.pe_last;
+        dma16s(st.xd, (unsigned)(pt * 32), __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(DMA_STAGES * GRP_STAGE + (k & 1) * GRP_PE_BYTES + w * 1024)));
+    };
+    constexpr bool PE = XF16 && NS == 1;                          // the only stash format the encoding is recomputed for
+    if constexpr (NV2 > 0 && PE) {
+        if (st.xd != nullptr) {       // chunk 0 before the first tile is issued (once per job: the only drain of the scheme)
+            pe_chunk(0);
+            grp_wait<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
     auto issue = [&](int slot) {
         const unsigned base = lds0 + (unsigned)slot * GRP_STAGE;
 #pragma unroll
@@ -960,8 +1017,18 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
         src += st.stride;
         if constexpr (NV2 > 0) {
             if (x2_wave) {
-                if (st.on2) dma16s(src2, st.voff2, __builtin_amdgcn_readfirstlane(base + st.dst2));
-                src2 += st.stride2;
+                if (!PE || st.xd == nullptr) {
+                    if (st.on2) dma16s(src2, st.voff2, __builtin_amdgcn_readfirstlane(base + st.dst2));
+                    src2 += st.stride2;
+                } else {
+                    // re-encode this tile's X2 rows from the quadruples in LDS (chunk ti / 16, loaded a chunk ahead)
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(coords + ((ti >> 4) & 1) * GRP_PE_BYTES + (ti & 15) * (KT_ * 16) + st.pe_row16);
+                    dw_pe_write(const_cast<char*>(tiles) + slot * GRP_STAGE + st.pe_dst, c, st.pe_gch, st.pe_nvalid);
+                }
+            }
+            if (PE && st.xd != nullptr) {      // every wave: its 64 points of the NEXT chunk when a chunk begins
+                if ((ti & 15) == 0) pe_chunk(ti / 16 + 1);
+                ++ti;
             }
         }
     };
@@ -1017,7 +1084,8 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
             }
         }
     };
-    const bool five = NV2 > 0 && x2_wave;           // DMAs this wave issues per stage: 4, or 5 with an X2 piece
+    const bool five = NV2 > 0 && x2_wave && (!(XF16 && NS == 1) || st.xd == nullptr);      // DMAs this wave issues per stage: 4, or 5 with an X2 piece (a
+                                                                    // re-encoded X2 is none; the chunk DMAs are not counted: an undercount is safe)
     auto wait_younger = [&](int younger) {          // all but the DMAs of the `younger` most recent stages have landed
         if (younger >= DMA_STAGES - 2) { if (five) grp_wait<5 * (DMA_STAGES - 2)>(); else grp_wait<4 * (DMA_STAGES - 2)>(); }
         else if (younger == 2) { if (five) grp_wait<10>(); else grp_wait<8>(); }
@@ -1109,7 +1177,18 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                 st.on[i] = gch * 8 < ncols;
             }
             st.src2 = nullptr; st.stride2 = 0; st.voff2 = 0; st.dst2 = 0; st.on2 = false;
-            if (x2_wave) {
+            st.xd = nullptr; st.pe_last = 0; st.pe_row16 = 0; st.pe_dst = 0; st.pe_gch = 0; st.pe_nvalid = 0;
+            if (has_x2 && G.xd != nullptr && A.pe_mode != 0) {      // (all waves: each moves its share of the quadruples)
+                st.xd = reinterpret_cast<const char*>(G.xd + p_begin * 8 + (A.pe_mode == 2 ? 4 : 0));
+                st.pe_last = (long long)G.Ppad - 1 - p_begin;
+            }
+            if (x2_wave && st.xd != nullptr) {
+                const int row = 8 * w + (lane >> 3);
+                st.pe_gch = (lane & 7) ^ (((row >> 1) & 1) << 2);
+                st.pe_nvalid = A.k2_in;
+                st.pe_row16 = (unsigned)((row % KT) * 16);
+                st.pe_dst = (unsigned)(2 * DMA_OPER + 8 * w * GRP_X2_ROWB + lane * 16);
+            } else if (x2_wave) {
                 const int row = 8 * w + (lane >> 3);
                 const int gch = (lane & 7) ^ (((row >> 1) & 1) << 2);
                 st.src2 = reinterpret_cast<const char*>(A.X2 + ((8 * w) / KT) * A.x2_plane + p_begin * A.ldx2 + A.x2col0);
@@ -1430,7 +1509,7 @@ int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s) {
 
 template <bool XF16, bool ZF16, int NS>
 static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
-    const size_t lds = (size_t)DMA_STAGES * GRP_STAGE;
+    const size_t lds = (size_t)DMA_STAGES * GRP_STAGE + (g.xd ? 2 * GRP_PE_BYTES : 0);
     auto k = dw_group_kernel<XF16, ZF16, NS>;
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, g);
@@ -1441,7 +1520,8 @@ static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
 int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16, hipStream_t s) {
     for (int i = 0; i < g.n; ++i) {
         const DwJob& j = g.j[i];
-        if (j.n_out > DW_T || j.k_in > DW_T || j.n_out < 1 || j.k_in < 8) return set_error("launch_dw_group: layer width out of range");
+        if (j.n_out > DW_T || j.k_in > DW_T || j.n_out < 1 || (j.k_in < 8 && !(j.k_in == 0 && j.X2))) return set_error("launch_dw_group: layer width out of range");
+        if (j.pe_mode && g.xd && (ns != 1 || !x_f16)) return set_error("launch_dw_group: the encoding is recomputed for one fp16 plane only");
         if (j.db == nullptr) return set_error("launch_dw_group: every job carries its bias gradient");
         // the bias rides in column 31 of the last 32-column block of X2, which must therefore be a padding column
         if (j.X2 && (j.k2_in < 8 || j.k2_in > 63 || j.k2_in % 32 == 0)) return set_error("launch_dw_group: second input block must leave its last column free");

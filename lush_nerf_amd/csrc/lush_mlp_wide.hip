@@ -428,10 +428,15 @@ struct WdPass {
 // (utils/run_lushnerf_helpers.py:334-361).  With ONE workgroup per CU nothing hides this prologue, so it is built for
 // speed: hardware sin / cos behind an exact range reduction (sincos_rev, lush_mlp_dev.h: 4.2e-7 absolute, 1/500 of the
 // fp16 grid this kernel rounds the result to), and the row leaves as twelve 16-byte LDS writes.
-__device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid) {
+__device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid, float* xd) {
     const long long gpt = tile_pt0 + tid;
     float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (gpt < P) point_of(rays, z, S, gpt, x, d);
+    if (xd != nullptr) {      // what the weight gradients re-encode (dw_pe_write, lush_mlp.hip): 32 bytes instead of the 256-byte row
+        float4* o = reinterpret_cast<float4*>(xd + gpt * 8);
+        o[0] = make_float4(x[0], x[1], x[2], 0.f);
+        o[1] = make_float4(d[0], d[1], d[2], 0.f);
+    }
     float v[PE_X + PE_D];
 #pragma unroll
     for (int c = 0; c < PE_X + PE_D; ++c) v[c] = 0.f;      // (col 63 and cols 91..95: zero padding the K loops do read)
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
         const long long wpt = pt0 + row0;
         WPROF_T(t_tile);
 #ifndef LUSH_ABL_NOPE
-        wd_pe_tile(peimg, A.rays, A.z, A.S, A.P, pt0, tid);
+        wd_pe_tile(peimg, A.rays, A.z, A.S, A.P, pt0, tid, (SPK > 0 && !A.pe_rows) ? A.xd : nullptr);
 #endif
         // my pieces of the tile's first position have landed.  First tile: the prologue issued S positions, S-1 are younger.
         // Later tiles: that DMA left S positions ago, in the views layer's second quarter; younger are the DMAs of S-1
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
         if (tile == (int)blockIdx.x) wd_wait_vm<2 * (WD_S - 1)>();
         else wd_wait_vm<2 * (WD_S - 1) + (SPK > 0 ? 17 : 1)>();
         lds_barrier();
-        if (SPK > 0) {
+        if (SPK > 0 && A.pe_rows) {      // the encoded rows for weight-gradient kernels that read them (variants)
             for (int i = tid; i < WD_MT * 12; i += WD_NT) {
                 const int c = i % 12, pt = i / 12;
                 const uint4 v = *reinterpret_cast<const uint4*>(peimg + pt * WD_PE_PITCH + c * 16);

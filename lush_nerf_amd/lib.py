@@ -165,7 +165,7 @@ _SIGS = {
 EXPORTS = ["lush_last_error"] + list(_SIGS)
 ABI_VERSION = 6
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
-VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_NO_OVERLAP = 1, 2, 4, 8, 16, 32
+VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_NO_OVERLAP, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 32, 64
 
 
 def variant_widths(dw_wgs: int = 0, chain_wgs: int = 0) -> int:
