@@ -32,8 +32,10 @@ PEAK_HBM_GBS = 8000.0
 # stash bytes per MLP evaluation and bf16 plane ([point][feature] rows)
 # A 1- or 2-plane backward keeps neither the feature activations nor their gradients (the feature layer is linear: its
 # weight gradients follow from dZv^T h_7, FeatFactorArgs in csrc/lush_mlp.h); the 3-plane reference mode stashes both.
-def BYTES_X_STASH(planes):
-    return 2 * (128 + 8 * 256 + (256 if planes >= 3 else 0) + 128)    # gamma row, h_0..h_7, [feature], views hidden
+def BYTES_X_STASH(planes, reencode=False):
+    # gamma row (one fp16 plane, product kernels: 32 bytes of point + view direction that the weight gradients re-encode),
+    # h_0..h_7, [feature], views hidden
+    return (32 if reencode else 2 * 128) + 2 * (8 * 256 + (256 if planes >= 3 else 0) + 128)
 
 
 def BYTES_DZ_STASH(planes):
@@ -386,9 +388,10 @@ def main():
         FLOP/s and algorithmic HBM bytes/s per launch (DESIGN.md section 5 gives the per-evaluation figures)."""
         sp = ops.nplanes(ops.stash_code(pf, pb))
         pbn = ops.nplanes(pb)
-        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH(sp) + 16 + 44 / 64,
+        ree = pf == ops.PLANES_F16 and pbn == 1 and not (a.variant & (lib.VARIANT_FWD_HALF | lib.VARIANT_FWD_512 | lib.VARIANT_PE_ROWS))
+        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH(sp, ree) + 16 + 44 / 64,
                       "mlp_bwd_chain": pbn * BYTES_DZ_STASH(pbn) + 288 + 16 + 32,
-                      "mlp_bwd_weights": pbn * (BYTES_X_STASH(pbn) + BYTES_DZ_STASH(pbn))}
+                      "mlp_bwd_weights": pbn * (BYTES_X_STASH(pbn, ree) + BYTES_DZ_STASH(pbn))}
         per_prod = lambda c: {1: 1, 2: 3, 3: 6}[ops.nplanes(c)]
         mfma_mult = {"mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
         kern = {}

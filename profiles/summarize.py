@@ -98,7 +98,8 @@ if per:
     pf, pb = (_n(planes.split(",")[0]), _n(planes.split(",")[1])) if "?" not in planes else (2, 1)
     # bytes per MLP evaluation and plane (bench.py BYTES_X_STASH / BYTES_DZ_STASH): 1 and 2 planes keep neither
     # the feature activations nor their gradients
-    xs = lambda n: 2 * (128 + 8 * 256 + (256 if n >= 3 else 0) + 128)
+    ree = planes == "h,h" or planes == "h,1"      # one fp16 plane, product kernels: 32 bytes per point instead of the 256-byte gamma row
+    xs = lambda n: (32 if ree else 256) + 2 * (8 * 256 + (256 if n >= 3 else 0) + 128)
     zs = lambda n: 2 * (8 * 256 + (256 if n >= 3 else 0) + 128 + (8 if n == 1 else 0))
     sp = min(pf, pb)
     alg = {"mlp_fwd": evals * (sp * xs(sp) + 16), "mlp_bwd_chain": evals * (pb * zs(pb) + 336),
