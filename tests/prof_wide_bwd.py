@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Developer tool (needs a GPU and a -DLUSH_PROF build named by LUSH_SO): cycle budget of mlp_wide_bwd_kernel, block 0 / wave 0."""
+"""Developer tool (needs a GPU and a -DLUSH_PROF build named by LUSH_SO): cycle budget of mlp_wide_bwd_kernel, block 0 / wave 0.
+Since the kernels grew in round 3 the 16 cycle counters no longer fit their scalar registers: the compiler spills SGPRs, such a build
+faulted on the GPU, and lib.build() refuses it (LUSH_ALLOW_SGPR_SPILLS=1 overrides: at your own risk, under `timeout`).  The figures
+in DESIGN.md section 4 come from earlier builds of the forward in which the counters fitted; ablation builds (-DLUSH_ABL_*) are
+the tool that still works."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
