@@ -73,7 +73,7 @@ class Trainer:
                  lrate: float = 5e-4, lrate_decay: int = 250, perturb: float = 1., raw_noise_std: float = 1.,
                  kernel_start_iter: int = 0, allkernel_start_iter: int = 0, noisenerf_start_iter: int = 1 << 30,
                  chunk: int = 1024 * 32, distributed: bool = False, micro_batch: int = 0, white_bkgd: bool = False,
-                 step_fn=None):
+                 step_fn=None, overlap: str = "auto"):
         self.model = model
         self.H, self.W = H, W
         self.K = [[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]]
@@ -104,6 +104,13 @@ class Trainer:
         self._fwd_bwd = step_fn or self._hip_forward_backward
         self._adam = ops.adam_step
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
+        # lush_march_bwd's two-stream overlap only pays when the runtime gives the two streams different
+        # hardware queues: "auto" times steps 2-3 with it and 4-5 without (one device sync each, once) and keeps the faster;
+        # "on" / "off" fix it; calibrate_overlap() does the same on demand (bench.py, inside its warm-up)
+        self._overlap_mode = overlap
+        self._overlap_probe = [] if overlap == "auto" else None
+        if overlap == "off":
+            self._set_overlap(False)
         self._graph = None                # step_graph: (key, torch.cuda.CUDAGraph, static batch, static loss, draw calls per step, active)
         self._graph_eager_left = 2        # plain steps before the capture (every lazy initialisation behind the entry points has run)
         self.sync_replicas()
@@ -169,6 +176,8 @@ class Trainer:
         """One optimisation step on a batch {rays [N,3,2] (or c2w/view/px/py for device-side ray generation),
         images_idx [N,1], target [N,3], fq_mask [N]}."""
         self.model.train()
+        if self._overlap_probe is not None:
+            self._probe_overlap("begin")
         self.flat.grad.zero_()
         force_naive = i < self.kernel_start_iter
         N = batch["target"].shape[0]
@@ -205,6 +214,8 @@ class Trainer:
                 self._adam(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
                            grad_scale=1.0 / self.world)
         self.global_step += 1
+        if self._overlap_probe is not None:
+            self._probe_overlap("end")
         return loss
 
     # ------------------------------------------------------------------ the step as one HIP graph
@@ -282,6 +293,42 @@ class Trainer:
         hooks.draw_offset += calls
         return loss
 
+    def _set_overlap(self, on: bool):
+        base = self.model.precision
+        bit = 0 if on else ops.lib.VARIANT_NO_OVERLAP
+        self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | bit)
+
+    def _probe_overlap(self, phase: str):
+        """step()'s passive calibration: called at the head ('begin') and the tail ('end') of the first six steps."""
+        import time
+        probe = self._overlap_probe
+        dev = self.flat.param.device
+        if probe is None or dev.type != "cuda" or self.model.precision.bwd != ops.PLANES_F16 or self.model.mlp_fine is None \
+                or (self.model.precision.variant & ops.lib.VARIANT_NO_OVERLAP and not probe):
+            self._overlap_probe = None
+            return
+        k = len(probe) // 2                      # index of the step being probed
+        if phase == "begin":
+            if k == 4:
+                self._set_overlap(False)
+            if k >= 2:
+                torch.cuda.synchronize(dev)
+            probe.append(time.perf_counter())
+        else:
+            if len(probe) // 2 >= 2:
+                torch.cuda.synchronize(dev)
+            probe.append(time.perf_counter())
+            if len(probe) == 12:                 # six steps seen: 2-3 with the overlap, 4-5 without
+                dt = [probe[2 * j + 1] - probe[2 * j] for j in range(6)]
+                t = torch.tensor([dt[2] + dt[3], dt[4] + dt[5]], dtype=torch.float64, device=dev)
+                if self.distributed:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                # (kept unless clearly slower: synchronised single steps scatter by +-1 %, the failure this guards against -- both
+                # kernels in one hardware queue -- costs +12 %)
+                self._set_overlap(bool(t[0] <= 1.03 * t[1]))
+                self.overlap_probe_ms = [float(x) * 500.0 for x in t.tolist()]      # ms per step: with, without
+                self._overlap_probe = None
+
     def calibrate_overlap(self, batches, i0: int = 0, steps: int = 2) -> dict:
         """lush_march_bwd runs the fine pass's weight gradients on a second stream beside the coarse pass's chain (two kernels
         that share the chip only if the runtime gives the two streams different hardware queues -- otherwise they run one after
@@ -292,6 +339,7 @@ class Trainer:
         dev = self.flat.param.device
         if not dev.type == "cuda":
             return {}
+        self._overlap_probe = None            # (explicit calibration replaces the passive one of step())
         base = self.model.precision
         out = {}
         k = i0
@@ -309,7 +357,7 @@ class Trainer:
             if self.distributed:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             out[name] = float(t.item())
-        keep = 0 if out["overlap"] <= out["one_after_the_other"] else ops.lib.VARIANT_NO_OVERLAP
+        keep = 0 if out["overlap"] <= 1.03 * out["one_after_the_other"] else ops.lib.VARIANT_NO_OVERLAP      # (see _probe_overlap)
         self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | keep)
         out["chosen"] = "overlap" if keep == 0 else "one_after_the_other"
         out["steps_taken"] = k - i0
