@@ -265,9 +265,6 @@ def main():
                      allkernel_start_iter=1 << 30, distributed=True, micro_batch=cfg["micro"])
         for i in range(warmup):
             tr.step(batches[i % n_batches], i)
-        # still warm-up: keep the backward's two-stream overlap only if it is faster on this process's streams (it needs
-        # the runtime to give the two streams different hardware queues)
-        cal = tr.calibrate_overlap(batches, warmup) if (pb == ops.PLANES_F16 and cfg["ni"] > 0 and not (a.variant & lib.VARIANT_NO_OVERLAP)) else {}
         sync()
         tr.allreduce_events = []
         t0 = time.perf_counter()
@@ -295,7 +292,6 @@ def main():
         torch.cuda.empty_cache()
         summ = timer.summary()
         summ["_allreduce_ms"] = ar_ms
-        summ["_overlap"] = cal
         return dt, summ
 
     def run_c1(pf, pb, steps, warmup):
@@ -499,11 +495,8 @@ def main():
             # stream, mean over the timed steps): what an N > 1 run adds to the N = 1 step
             "allreduce_ms": round(groups.get("_allreduce_ms", 0.0), 4),
             "kernel_timing": "HIP events around each MLP kernel group on the launch stream, over the same steps run once more "
-                             "group by group, one kernel at a time (the timed region makes one lush_march_fwd / lush_march_bwd call per "
-                             "march, and lush_march_bwd runs the fine pass's weight gradients beside the coarse pass's chain: there a "
-                             "kernel's duration is not its own)",
-            # warm-up calibration of that two-stream overlap (ms per step each way on this process's streams; the faster is kept)
-            "backward_overlap": groups.get("_overlap", {}),
+                             "group by group (the timed region makes one lush_march_fwd / lush_march_bwd call per march and has no "
+                             "events inside; every kernel runs alone on the one stream in both passes)",
         }
         notes = {"2,h": "forward 2 bf16 planes, backward ONE loss-scaled fp16 plane (11-bit operands at the bf16 backward's cost)",
                  "h,h": "forward ONE fp16 plane (outputs within 3e-5 of fp32), backward ONE loss-scaled fp16 plane",

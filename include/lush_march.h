@@ -224,11 +224,8 @@ typedef struct {
 #define LUSH_VARIANT_PE_ROWS 64      /* one fp16 plane: the forward stashes the encoded rows and the weight gradients read them (round 2),
                                       * instead of 32 bytes per point that the weight-gradient kernel re-encodes; pass the SAME variant word
                                       * to the forward and the backward of a pass */
-#define LUSH_VARIANT_NO_OVERLAP 32   /* lush_march_bwd: the two passes one after the other on the caller's stream (no second stream) */
-/* launch widths (0 = one workgroup per CU): the weight-gradient launch / the 64-points-per-wave backward chain on at most n
- * workgroups (n a multiple of 8), so that two kernels can share the chip */
-#define LUSH_VARIANT_DW_WGS(n) ((((n) / 8) & 0xFF) << 8)
-#define LUSH_VARIANT_CHAIN_WGS(n) ((((n) / 8) & 0xFF) << 16)
+/* (bit 32 was round 3's LUSH_VARIANT_NO_OVERLAP -- lush_march_bwd no longer uses a second stream -- and is ignored) */
+#define LUSH_VARIANT_KERNEL_BITS 0xDF /* every bit above that selects a kernel; anything else in the word is ignored */
 
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */

@@ -107,4 +107,5 @@ def load_checkpoint(path: str, model: NeRFAll, trainer=None, map_location="cpu")
         trainer.global_step = int(ck.get("global_step", 0))       # start = ckpt['global_step'] (run_lushnerf.py:385, 419)
         load_adam_state(trainer, ck.get("optimizer_state_dict") or {"state": {}, "param_groups": []})
         trainer.sync_replicas()                                   # a file read on one rank must not fork the replicas
+        trainer.invalidate_graph()                                # a captured step's device counters / rate are stale now
     return int(ck.get("global_step", 0))

@@ -249,8 +249,9 @@ void build_pack_table_half_bwd(const lush_mlp_params* p, PackTable& T, int& bloc
     add(p->w[0], XV, XV, HW, 2, N::KKH);
 }
 
-int dw_splits(long long Ppad, int max_wgs) {
-    int s = max_wgs > 0 && max_wgs < 256 ? max_wgs : 256;      // one 256x256-tile workgroup per CU (fewer: the caller shares the chip)
+int dw_splits(long long Ppad) {
+    int dev = 0, s = 256;      // one 256x256-tile workgroup per CU of the calling thread's device
+    if (current_device_cus(dev, s) != 0) s = 256;
     // every workgroup ends a layer with 256 KB of atomics and starts it with a ring refill: give it at least 128
     // points (the 4096-point noise net ran 128 workgroups of one tile each: 189 us for 7 tiny GEMMs)
     const long long max_s = Ppad / 128 > 0 ? Ppad / 128 : 1;
@@ -408,7 +409,6 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     if (z_f16 && !chain) return set_error("lush_mlp_bwd: the fp16 gradient chain needs the chain kernels");
     float* gscale = z_f16 ? (float*)(db + D.scale) : nullptr;
     a.scale = gscale;
-    a.max_wgs = ((variant >> 16) & 0xFF) * 8;      // LUSH_VARIANT_CHAIN_WGS: share the chip (lush_march_bwd's overlap)
     a.rays = rays; a.z = z; a.S = S; a.P = (int)P; a.n_tiles = (int)(L.Ppad / (chain ? 128 : mlp_bwd_tile(planes_b)));
     a.wpk = (const uint4*)packed_b;
     a.draw = draw;
@@ -447,7 +447,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         d.Ppad = (int)L.Ppad;
         const int tiles = ((n_out + 127) / 128) * ((k_in + 127) / 128);
         (void)tiles;
-        const int splits = dw_splits(L.Ppad, 0);
+        const int splits = dw_splits(L.Ppad);
         long long pps = (L.Ppad + splits - 1) / splits;
         pps = (pps + 31) / 32 * 32;
         d.pts_per_split = (int)pps;
@@ -508,7 +508,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
             j.n_out2 = n.HV;
         }
         if (fold) job(a.dzv + n.HV, ldzv, DZV_EXT, hv, n.HV, 0, n.HV, facH, n.HV, 0, facSH);   // rgb head: Z = the extra columns, X = views hidden
-        const int splits = dw_splits(L.Ppad, ((variant >> 8) & 0xFF) * 8);
+        const int splits = dw_splits(L.Ppad);
         long long pps = (L.Ppad + splits - 1) / splits;
         pps = (pps + 31) / 32 * 32;
         G.Ppad = (int)L.Ppad;

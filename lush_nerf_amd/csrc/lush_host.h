@@ -1,6 +1,7 @@
 // lush-march: host-side helpers shared by the launch translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "lush_mlp.h"
 
 namespace lush {
@@ -13,6 +14,33 @@ int set_hip_error(hipError_t e, const char* what, const char* file, int line);
         hipError_t _e = (expr);                                                     \
         if (_e != hipSuccess) return ::lush::set_hip_error(_e, #expr, __FILE__, __LINE__); \
     } while (0)
+
+// Launch set-up that is safe with several devices and several host threads in one process (the
+// reference calls this path from one DataParallel worker thread per GPU): nothing here is keyed by "the first device
+// that happened to call".  current_device_cus: CU count of the CALLING thread's current device (cached per device id);
+// kernel_lds_once: hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) -- the call is idempotent,
+// so two threads racing on the same device only repeat it.
+struct KernelOnce { std::atomic<unsigned long long> done{0}; };
+inline int current_device_cus(int& dev, int& n_cu) {
+    static std::atomic<int> cus[64];
+    LUSH_HIP(hipGetDevice(&dev));
+    int v = dev >= 0 && dev < 64 ? cus[dev].load(std::memory_order_relaxed) : 0;
+    if (v <= 0) {
+        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        if (v <= 0) v = 256;
+        if (dev >= 0 && dev < 64) cus[dev].store(v, std::memory_order_relaxed);
+    }
+    n_cu = v;
+    return 0;
+}
+inline int kernel_lds_once(KernelOnce& once, int dev, const void* kernel, size_t lds) {
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 0 || dev >= 64 || !(once.done.load(std::memory_order_acquire) & bit)) {
+        LUSH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.done.fetch_or(bit, std::memory_order_release);
+    }
+    return 0;
+}
 
 // lush_mlp.hip
 size_t mlp_fwd_lds_bytes(int hw, int ns, int mt);

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(Comp
     }
     dnorm = wave_sum(dnorm);
     if (lane < 3 && drays != nullptr && norm > 0.f)
-        atomicAdd(&drays[(long long)ray * 11 + 3 + lane], dnorm * c.rays[(long long)ray * 11 + 3 + lane] / norm);   // (atomic: the two passes of a march may run concurrently)
+        drays[(long long)ray * 11 + 3 + lane] += dnorm * c.rays[(long long)ray * 11 + 3 + lane] / norm;   // (the passes of a march run one after the other on one stream)
 }
 
 // ------------------------------------------------------ hierarchical sampling
@@ -1041,9 +1041,8 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void ray_grad_reduce_kernel(co
     for (int i = 0; i < 9; ++i) a[i] = wave_sum(a[i]);
     if (lane == 0) {
         float* o = drays + (long long)ray * 11;
-        // (atomic: lush_march_bwd runs the coarse and the fine pass concurrently, both add into drays)
-        atomicAdd(o + 0, a[0]); atomicAdd(o + 1, a[1]); atomicAdd(o + 2, a[2]); atomicAdd(o + 3, a[3]); atomicAdd(o + 4, a[4]); atomicAdd(o + 5, a[5]);
-        atomicAdd(o + 8, a[6]); atomicAdd(o + 9, a[7]); atomicAdd(o + 10, a[8]);
+        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3]; o[4] += a[4]; o[5] += a[5];
+        o[8] += a[6]; o[9] += a[7]; o[10] += a[8];
     }
 }
 

@@ -22,8 +22,7 @@ struct Layout {
     size_t zc, wc, rawc, pkc, stashc;            // coarse pass
     size_t zf, zs, wf, rawf, pkf, stashf;        // fine pass (N_importance > 0)
     size_t pkbc, pkbf;                           // packed weights of the backward when its plane code differs
-    size_t draw, dstash, dpts;                   // backward scratch of the (last) fine pass, or of the only pass
-    size_t draw_c, dstash_c, dpts_c;             // ... of the coarse pass when there are two (they run concurrently)
+    size_t draw, dstash, dpts;                   // backward scratch, shared by the passes (they run one after the other)
     size_t total;
     size_t stashc_bytes, stashf_bytes;
 };
@@ -53,13 +52,6 @@ bool layout(const lush_march_cfg* c, Layout& L) {
         L.draw = take(Pmax * 16);
         L.dstash = take(lush_mlp_dstash_bytes(0, pb, Pmax));
         L.dpts = take(Pmax * 32);
-        if (Ni > 0) {
-            L.draw_c = take(R * S * 16);
-            L.dstash_c = take(lush_mlp_dstash_bytes(0, pb, R * S));
-            L.dpts_c = take(R * S * 32);
-        } else {
-            L.draw_c = L.draw; L.dstash_c = L.dstash; L.dpts_c = L.dpts;
-        }
     }
     L.total = off;
     return true;
@@ -146,25 +138,18 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     const lush_mlp_params* pfine = cfg->same_net ? coarse : fine;
     const lush_mlp_grads* gfine = cfg->same_net ? g_coarse : g_fine;
     char* w = (char*)workspace;
-    const int pf = cfg->planes_fwd, pb = cfg->planes_bwd, sc = stash_code(pf, pb), var = cfg->variant;
+    const int pf = cfg->planes_fwd, pb = cfg->planes_bwd, sc = stash_code(pf, pb), var = cfg->variant & LUSH_VARIANT_KERNEL_BITS;
     const float* noise_c = draws && cfg->raw_noise_std > 0.f ? draws->noise_c : nullptr;
     const float* noise_f = draws && cfg->raw_noise_std > 0.f ? draws->noise_f : nullptr;
-    // One pass = compositing backward, (re-pack), gradient chain, d(point) -> d(ray), weight gradients.  With two passes the
-    // coarse pass does not depend on the fine one (z_samples are detached, models/lushnerf.py:546), and their kernels
-    // complement each other: the chain is instruction-issue-bound at ~3.7 TB/s of HBM traffic, the weight-gradient launch is
-    // HBM-bound with the matrix pipe at 20 %.  So the fine pass's weight gradients run on a second stream on part of the
-    // chip (alone they saturate HBM from ~160 of 256 CUs: 4.33 / 4.32 / 4.57 / 5.43 ms on 256 / 192 / 160 / 128 workgroups) while
-    // the coarse pass's chain runs on the rest (3.61 / 4.04 / 4.38 / 5.14 ms for the fine-size chain on 256 / 192 / 160 /
-    // 128), and the coarse weight gradients follow on the whole chip.  Side by side both slow down (HBM and power are shared:
-    // 5.9 ms instead of 4.6 for the weight gradients, 4.4 instead of 3.4 for the chain on 96 workgroups), so the step gains
-    // 0.3-0.4 ms, not the chain's 1.8.  LUSH_VARIANT_NO_OVERLAP keeps everything on `st`.
+    // One pass = compositing backward, (re-pack), gradient chain, d(point) -> d(ray), weight gradients; the fine pass first,
+    // then the coarse one (which does not depend on it: z_samples are detached, models/lushnerf.py:546), all on the caller's
+    // stream out of one backward scratch.  (Round 3 ran the fine pass's weight gradients on a second stream beside the coarse
+    // chain, each on part of the chip: both kernels slowed down side by side -- HBM and power are shared -- and the step
+    // gained 0.4 ms on one box and lost 0.3 on two others, the driver's among them; removed in round 4)
     struct Scratch { float* draw; char* dstash; float* dpts; };
-    const Scratch sf{(float*)(w + L.draw), w + L.dstash, (float*)(w + L.dpts)};
-    const Scratch scr_c{(float*)(w + L.draw_c), w + L.dstash_c, (float*)(w + L.dpts_c)};
-    hipStream_t main = (hipStream_t)st;
+    const Scratch x{(float*)(w + L.draw), w + L.dstash, (float*)(w + L.dpts)};
     auto chain = [&](const lush_mlp_params* prm, size_t zoff, size_t rawoff, size_t stashoff, size_t pkoff, size_t pkboff, bool repack,
-                     int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const Scratch& x,
-                     int variant) -> int {
+                     int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc) -> int {
         const float* z = (const float*)(w + zoff);
         int rc = lush_composite_bwd((const float*)(w + rawoff), z, rays, R, Sp, noise, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
                                     g_rgb, g_depth, g_acc, x.draw, drays, st);
@@ -174,13 +159,12 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
             if (rc) return rc;
         }
         rc = lush_mlp_bwd_chain(0, sc, pb, rays, z, R, Sp, w + (pb == pf ? pkoff : pkboff), prm, x.draw, w + stashoff, x.dstash, x.dpts,
-                                variant, st);
+                                var, st);
         if (rc) return rc;
         return lush_ray_grad_reduce(x.dpts, z, R, Sp, drays, st);
     };
-    auto weights = [&](const lush_mlp_params* prm, const lush_mlp_grads* gr, size_t stashoff, int Sp, const Scratch& x, int variant,
-                       lush_stream_t s) -> int {
-        return lush_mlp_bwd_weights(0, sc, pb, R, Sp, prm, x.draw, w + stashoff, x.dstash, gr, variant, s);
+    auto weights = [&](const lush_mlp_params* prm, const lush_mlp_grads* gr, size_t stashoff, int Sp) -> int {
+        return lush_mlp_bwd_weights(0, sc, pb, R, Sp, prm, x.draw, w + stashoff, x.dstash, gr, var, st);
     };
     const bool any_main = g->rgb || g->depth || g->acc;
     const bool any_c = two ? (g->rgb0 || g->depth0 || g->acc0) : any_main;
@@ -188,55 +172,18 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
         return set_error("lush_march_bwd: gradient buffers of a pass that received output gradients are required");
     int rc = 0;
     bool packed_b_c = false;
-    const int kvar = var & ~(LUSH_VARIANT_DW_WGS(2040) | LUSH_VARIANT_CHAIN_WGS(2040));     // kernel selection without the launch widths
     if (two && any_main) {
-        rc = chain(pfine, L.zf, L.rawf, L.stashf, L.pkf, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc, sf, kvar);
+        rc = chain(pfine, L.zf, L.rawf, L.stashf, L.pkf, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc);
         if (rc) return rc;
         packed_b_c = cfg->same_net && pb != pf;     // the shared net's backward fragments are packed now
-        const bool overlap = any_c && !(var & LUSH_VARIANT_NO_OVERLAP) && pb == PLANES_F16 && !(var & (LUSH_VARIANT_BWD_HALF | LUSH_VARIANT_BWD_512));
-        if (!overlap) {
-            rc = weights(pfine, gfine, L.stashf, Sf, sf, kvar, st);
-            if (rc) return rc;
-        } else {
-            static hipStream_t side = nullptr;          // one per process (one process per GPU), created on first use
-            static hipEvent_t fork = nullptr, join = nullptr;
-            if (!side) {
-                // (a stream of another priority: the runtime hands streams of one priority the same hardware queue in turn, and
-                // two kernels in one hardware queue run one after the other -- measured: both kernels on queue 4, 4.8 + 3.4 ms)
-                int lo = 0, hi = 0;
-                LUSH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                LUSH_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
-                LUSH_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-                LUSH_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-            }
-            static int n_cu = 0;
-            if (n_cu == 0) {
-                int dev = 0, v = 0;
-                LUSH_HIP(hipGetDevice(&dev));
-                LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-                n_cu = v > 0 ? v : 256;
-            }
-            int dw_wgs = ((var >> 8) & 0xFF) * 8, ch_wgs = ((var >> 16) & 0xFF) * 8;
-            if (dw_wgs <= 0 || dw_wgs >= n_cu) dw_wgs = n_cu * 11 / 16 / 8 * 8;    // 176 of 256 (measured: 17.27 ms one after the other;
-                                                                                  // 17.77 / 16.84 / 17.11 / 17.44 / 17.95 with 192 / 176 / 160 / 144 / 128)
-            if (ch_wgs <= 0 || ch_wgs > n_cu - dw_wgs) ch_wgs = (n_cu - dw_wgs) / 8 * 8;
-            LUSH_HIP(hipEventRecord(fork, main));
-            LUSH_HIP(hipStreamWaitEvent(side, fork, 0));
-            rc = weights(pfine, gfine, L.stashf, Sf, sf, kvar | LUSH_VARIANT_DW_WGS(dw_wgs), (lush_stream_t)side);
-            if (rc) return rc;
-            LUSH_HIP(hipEventRecord(join, side));
-            rc = chain(coarse, L.zc, L.rawc, L.stashc, L.pkc, L.pkbc, pb != pf && !packed_b_c, S, noise_c, g->rgb0, g->depth0, g->acc0, scr_c,
-                       kvar | LUSH_VARIANT_CHAIN_WGS(ch_wgs));
-            if (rc) return rc;
-            LUSH_HIP(hipStreamWaitEvent(main, join, 0));
-            return weights(coarse, g_coarse, L.stashc, S, scr_c, kvar, st);
-        }
+        rc = weights(pfine, gfine, L.stashf, Sf);
+        if (rc) return rc;
     }
     if (any_c) {
         rc = chain(coarse, L.zc, L.rawc, L.stashc, L.pkc, L.pkbc, pb != pf && !packed_b_c, S, noise_c, two ? g->rgb0 : g->rgb,
-                   two ? g->depth0 : g->depth, two ? g->acc0 : g->acc, scr_c, kvar);
+                   two ? g->depth0 : g->depth, two ? g->acc0 : g->acc);
         if (rc) return rc;
-        rc = weights(coarse, g_coarse, L.stashc, S, scr_c, kvar, st);
+        rc = weights(coarse, g_coarse, L.stashc, S);
     }
     return rc;
 }

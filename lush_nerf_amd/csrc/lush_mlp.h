@@ -16,8 +16,8 @@ namespace lush {
 enum { NET_MAX_LAYERS = 8 };
 enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
 // kernel-variant bits of the C ABI (include/lush_march.h LUSH_VARIANT_*): 0 = the product's choice
-enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16, LUSH_VARIANT_NO_OVERLAP = 32,
-       LUSH_VARIANT_PE_ROWS = 64 };
+enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16,
+       LUSH_VARIANT_PE_ROWS = 64, LUSH_VARIANT_KERNEL_BITS = 0xDF };
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -179,7 +179,6 @@ struct MlpBwdArgs {
     long long plane_h, plane_hv;
     float* dpts;                   // [P][8]: d/dx (3), pad, d/dviewdir (3), pad
     const float* scale;            // fp16 chain only: {loss scale, 1/scale} written by grad_scale_kernel
-    int max_wgs;                   // 0: one workgroup per CU; else at most this many (the caller shares the chip with another kernel)
 };
 
 struct DwArgs {

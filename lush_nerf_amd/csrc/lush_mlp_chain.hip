@@ -1416,14 +1416,10 @@ template <class N, int NS, bool HAS_ALPHA, int DT, int SPK>
 static int launch_chain_sp(const MlpFwdArgs& a, hipStream_t s) {
     auto k = mlp_chain_fwd_kernel<N, NS, HAS_ALPHA, DT, SPK>;
     const size_t lds = chain_lds_bytes<N, NS, HAS_ALPHA>();
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        LUSH_HIP(hipGetDevice(&dev));
-        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = v > 0 ? v : 256;
-    }
-    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static KernelOnce once;
+    int dev = 0, n_cu = 0;
+    if (int rc = current_device_cus(dev, n_cu)) return rc;
+    if (int rc = kernel_lds_once(once, dev, reinterpret_cast<const void*>(k), lds)) return rc;
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;     // one workgroup per CU, tiles strided
     hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
     LUSH_HIP(hipGetLastError());
@@ -1434,19 +1430,10 @@ template <class N, int DT, int SPK>
 static int launch_chain_half_sp(const MlpFwdArgs& a, hipStream_t s) {
     auto k = mlp_chain_fwd_half_kernel<N, DT, SPK>;
     const size_t lds = (size_t)HfSched<N>::S * HfSched<N>::SLOT + (size_t)CH_MT * PE_ROW * 2 + (size_t)CH_NW * 4096;
-    static int n_cu = 0;
-    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        LUSH_HIP(hipGetDevice(&dev));
-        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = v > 0 ? v : 256;
-        if (getenv("LUSH_DEBUG_OCC")) {
-            int nb = 0;
-            LUSH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), CH_NT, lds));
-            fprintf(stderr, "[lush] mlp_chain_fwd_half_kernel: %d workgroups per CU (LDS %zu B each)\n", nb, lds);
-        }
-    }
+    static KernelOnce once;
+    int dev = 0, n_cu = 0;
+    if (int rc = current_device_cus(dev, n_cu)) return rc;
+    if (int rc = kernel_lds_once(once, dev, reinterpret_cast<const void*>(k), lds)) return rc;
     const int grid = a.n_tiles < 2 * n_cu ? a.n_tiles : 2 * n_cu;     // two workgroups per CU, tiles strided
     hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
     LUSH_HIP(hipGetLastError());
@@ -1504,14 +1491,10 @@ static int launch_chain_bwd_k(const MlpBwdArgs& a, hipStream_t s) {
     auto k = mlp_chain_bwd_kernel<N, NS, HAS_ALPHA, DT>;
     const size_t lds = (size_t)CH_S * BwSched<N, NS>::SLOT + (size_t)CH_NW * 4096 + (size_t)CH_MT * BW_DPE_LD * 4 +
                        (size_t)(CH_NT / CH_MT) * CH_MT * 6 * 4 + (size_t)(3 * N::HV + N::HW) * 4;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        LUSH_HIP(hipGetDevice(&dev));
-        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = v > 0 ? v : 256;
-    }
-    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static KernelOnce once;
+    int dev = 0, n_cu = 0;
+    if (int rc = current_device_cus(dev, n_cu)) return rc;
+    if (int rc = kernel_lds_once(once, dev, reinterpret_cast<const void*>(k), lds)) return rc;
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
     hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
     LUSH_HIP(hipGetLastError());
@@ -1526,14 +1509,10 @@ static int launch_chain_bwd_half(const MlpBwdArgs& a, hipStream_t s) {
     auto k = mlp_chain_bwd_half_kernel<N, HAS_ALPHA, DT>;
     const size_t lds = (size_t)HbSched<N>::S * HbSched<N>::SLOT + (size_t)CH_NW * 4096 + (size_t)CH_MT * BH_DPE_LD * 2 +
                        (size_t)(3 * N::HV + N::HW) * 4;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        LUSH_HIP(hipGetDevice(&dev));
-        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = v > 0 ? v : 256;
-    }
-    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static KernelOnce once;
+    int dev = 0, n_cu = 0;
+    if (int rc = current_device_cus(dev, n_cu)) return rc;
+    if (int rc = kernel_lds_once(once, dev, reinterpret_cast<const void*>(k), lds)) return rc;
     const int grid = a.n_tiles < 2 * n_cu ? a.n_tiles : 2 * n_cu;     // two workgroups per CU
     hipLaunchKernelGGL(k, dim3(grid), dim3(CH_NT), lds, s, a);
     LUSH_HIP(hipGetLastError());

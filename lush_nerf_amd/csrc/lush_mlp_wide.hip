@@ -709,14 +709,10 @@ template <int SPK>
 static int launch_wide_sp(const MlpFwdArgs& a, hipStream_t s) {
     auto k = mlp_wide_fwd_kernel<NetNerf, SPK>;
     const size_t lds = mlp_wide_fwd_lds_bytes();
-    static int n_cu = 0;                 // (per instantiation, once per process: these runtime calls cost more than the launch in the small configs)
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        LUSH_HIP(hipGetDevice(&dev));
-        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        n_cu = v > 0 ? v : 256;
-    }
+    static KernelOnce once;              // (per instantiation and device: the attribute call costs more than the launch in the small configs)
+    int dev = 0, n_cu = 0;
+    if (int rc = current_device_cus(dev, n_cu)) return rc;
+    if (int rc = kernel_lds_once(once, dev, reinterpret_cast<const void*>(k), lds)) return rc;
     const int tiles = (a.n_tiles * 128 + WD_MT - 1) / WD_MT;      // a.n_tiles counts 128-point tiles (point arrays are padded to 256)
     MlpFwdArgs b = a;
     b.n_tiles = tiles;

@@ -764,19 +764,14 @@ int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s) {
     auto k = mlp_wide_bwd_kernel<N>;
     const size_t lds = (size_t)(3 * N::HV + N::HW) * 4 + (size_t)WD_S * WD_SLOT + 8 * 4096 + 4 * 4096 + (size_t)WD_MT * WB_DPE_LD * 2 + 4096;
     if (a.scale == nullptr) return set_error("launch_mlp_wide_bwd: the fp16 chain needs its loss scale");
-    static int n_cu = 0;                 // (once per process: these three runtime calls cost more than the launch in the small configs)
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        LUSH_HIP(hipGetDevice(&dev));
-        LUSH_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        n_cu = v > 0 ? v : 256;
-    }
+    static KernelOnce once;              // (per device: the attribute call costs more than the launch in the small configs)
+    int dev = 0, n_cu = 0;
+    if (int rc = current_device_cus(dev, n_cu)) return rc;
+    if (int rc = kernel_lds_once(once, dev, reinterpret_cast<const void*>(k), lds)) return rc;
     const int tiles = (a.n_tiles * 128 + WD_MT - 1) / WD_MT;      // a.n_tiles counts 128-point tiles (point arrays are padded to 256)
     MlpBwdArgs b = a;
     b.n_tiles = tiles;
-    const int cus = a.max_wgs > 0 && a.max_wgs < n_cu ? a.max_wgs : n_cu;
-    const int grid = tiles < cus ? tiles : cus;                   // one workgroup per CU, tiles strided
+    const int grid = tiles < n_cu ? tiles : n_cu;                 // one workgroup per CU, tiles strided
     hipLaunchKernelGGL(k, dim3(grid), dim3(WD_NT), lds, s, b);
     LUSH_HIP(hipGetLastError());
     return 0;

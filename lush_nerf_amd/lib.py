@@ -165,17 +165,7 @@ _SIGS = {
 EXPORTS = ["lush_last_error"] + list(_SIGS)
 ABI_VERSION = 6
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
-VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_NO_OVERLAP, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 32, 64
-
-
-def variant_widths(dw_wgs: int = 0, chain_wgs: int = 0) -> int:
-    """LUSH_VARIANT_DW_WGS / LUSH_VARIANT_CHAIN_WGS: launch widths in workgroups (multiples of 8; 0 = the library's choice)."""
-    return (((dw_wgs // 8) & 0xFF) << 8) | (((chain_wgs // 8) & 0xFF) << 16)
-# include/lush_march.h: LUSH_FAULT_*
-FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
-               128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}
-FAULT_BITS = {n: b for b, n in FAULT_NAMES.items()}
-FAULT_COARSE_SHIFT = 5
+VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 64
 
 
 def fault_names(word: int):

@@ -73,7 +73,7 @@ class Trainer:
                  lrate: float = 5e-4, lrate_decay: int = 250, perturb: float = 1., raw_noise_std: float = 1.,
                  kernel_start_iter: int = 0, allkernel_start_iter: int = 0, noisenerf_start_iter: int = 1 << 30,
                  chunk: int = 1024 * 32, distributed: bool = False, micro_batch: int = 0, white_bkgd: bool = False,
-                 step_fn=None, overlap: str = "auto"):
+                 step_fn=None):
         self.model = model
         self.H, self.W = H, W
         self.K = [[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]]
@@ -104,14 +104,7 @@ class Trainer:
         self._fwd_bwd = step_fn or self._hip_forward_backward
         self._adam = ops.adam_step
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
-        # lush_march_bwd's two-stream overlap only pays when the runtime gives the two streams different
-        # hardware queues: "auto" times steps 2-3 with it and 4-5 without (one device sync each, once) and keeps the faster;
-        # "on" / "off" fix it; calibrate_overlap() does the same on demand (bench.py, inside its warm-up)
-        self._overlap_mode = overlap
-        self._overlap_probe = [] if overlap == "auto" else None
-        if overlap == "off":
-            self._set_overlap(False)
-        self._graph = None                # step_graph: (key, torch.cuda.CUDAGraph, static batch, static loss, draw calls per step, active)
+        self._graph = None                # step_graph: the captured step (graphs, static batch / loss, device step state + host mirror)
         self._graph_eager_left = 2        # plain steps before the capture (every lazy initialisation behind the entry points has run)
         self.sync_replicas()
 
@@ -127,6 +120,7 @@ class Trainer:
         dist.broadcast(meta, 0)
         meta = [int(x) for x in meta.tolist()]
         self.steps, self.global_step = meta[:3], meta[3]
+        self.invalidate_graph()
 
     def replica_checksum(self) -> float:
         """max over ranks of |sum(param) - rank 0's sum(param)| (debug aid; 0.0 when replicas agree)."""
@@ -176,8 +170,6 @@ class Trainer:
         """One optimisation step on a batch {rays [N,3,2] (or c2w/view/px/py for device-side ray generation),
         images_idx [N,1], target [N,3], fq_mask [N]}."""
         self.model.train()
-        if self._overlap_probe is not None:
-            self._probe_overlap("begin")
         self.flat.grad.zero_()
         force_naive = i < self.kernel_start_iter
         N = batch["target"].shape[0]
@@ -197,14 +189,7 @@ class Trainer:
         finally:
             hooks.sink = sink_before
         if self.distributed:
-            ev = None
-            if self.allreduce_events is not None and self.flat.grad.is_cuda:      # bench.py: HIP events around the one collective
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            dist.all_reduce(self.flat.grad)          # RCCL sum over xGMI; the 1/world mean is folded into Adam
-            if ev is not None:
-                ev[1].record()
-                self.allreduce_events.append(ev)
+            self._all_reduce()          # RCCL sum over xGMI; the 1/world mean is folded into Adam
         lr = self.lr() if self._lr_next is None else self._lr_next
         self._lr_next = None
         active = [True, not force_naive, False]
@@ -214,13 +199,23 @@ class Trainer:
                 self._adam(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
                            grad_scale=1.0 / self.world)
         self.global_step += 1
-        if self._overlap_probe is not None:
-            self._probe_overlap("end")
         return loss
 
     # ------------------------------------------------------------------ the step as one HIP graph
-    def _step_body(self, batch, i, force_naive, state):
-        """What step() enqueues, with rate / Adam step counts / draw counter taken from the device step state."""
+    def _all_reduce(self):
+        """The step's ONE collective: sum of the flat gradient over the ranks (RCCL over xGMI; 1/world is folded into Adam)."""
+        ev = None
+        if self.allreduce_events is not None and self.flat.grad.is_cuda:      # bench.py: HIP events around the one collective
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        dist.all_reduce(self.flat.grad)
+        if ev is not None:
+            ev[1].record()
+            self.allreduce_events.append(ev)
+
+    def _body_grads(self, batch, i, force_naive, state):
+        """First half of what step() enqueues -- zero the flat gradient, forward + backward of every micro-batch -- with the
+        Philox draw counter taken from the device step state."""
         self.flat.grad.zero_()
         N = batch["target"].shape[0]
         mb = self.micro_batch if 0 < self.micro_batch < N else N
@@ -235,7 +230,10 @@ class Trainer:
                 loss = part if loss is None else loss + part
         finally:
             hooks.sink, hooks.state = sink_before, None
-        calls = hooks.draw_delta
+        return loss, hooks.draw_delta
+
+    def _body_update(self, force_naive, state, calls):
+        """Second half: Adam on the active segments with rate / step counts from the device step state, then advance it."""
         active = [True, not force_naive, False]
         for s, (a, b) in enumerate(self.flat.segments):
             if active[s] and b > a:
@@ -244,124 +242,89 @@ class Trainer:
         mask = sum(1 << s for s, (a, b) in enumerate(self.flat.segments) if active[s] and b > a)
         ops.lib.call("lush_step_state_advance", ops.lib.ptr(state), int(calls), int(mask), float(self.lrate),
                      float(self.lrate_decay * 1000), 0.9, 0.999, ops._stream())
-        return loss, calls, mask
+        return mask
 
-    def step_graph(self, batch: Dict[str, torch.Tensor], i: int):
+    def _state_init(self, state):
+        """(Re-)write the device step state from the host's counters: what the graph's kernels read instead of arguments."""
+        hooks = self.model.hooks
+        steps = (ops.C.c_int * 3)(*self.steps)
+        ops.lib.call("lush_step_state_init", ops.lib.ptr(state), ops.C.c_ulonglong(hooks.draw_offset), int(self.global_step), steps,
+                     float(self.lrate), float(self.lrate_decay * 1000), 0.9, 0.999, ops._stream())
+        return (int(hooks.draw_offset), int(self.global_step), tuple(self.steps))
+
+    def invalidate_graph(self):
+        """Forget the captured step (checkpoint load, replica sync: parameters, moments and counters were rewritten)."""
+        self._graph = None
+        self._graph_eager_left = max(self._graph_eager_left, 1)
+
+    def step_graph(self, batch: Dict[str, torch.Tensor], i: int, split: Optional[bool] = None):
         """step() with the whole step -- ray generation, both marches, loss, backward, Adam -- captured once in a HIP graph
         and replayed: one graph launch instead of ~50 kernel launches from Python (the launch-bound configurations: BASELINE
         config 1 spends its step in the host's launch path).  What the host passes per step as kernel arguments -- the
         learning rate, Adam's step counts, the Philox draw counter -- lives in the device step state (lush_step_state_*), which
-        the graph's last node advances, so replays continue exactly where eager steps would: same draws, same rates.
-        The first calls run step() itself (they are real steps); the batch is copied into the graph's static tensors before
-        every replay; the returned loss
-        is the graph's static tensor, overwritten by the next replay.  Single process only: a captured RCCL all-reduce has not
-        been validated (world size 1 skips the all-reduce, which is the identity there); explicit draws, the consistency
-        branch and a rate restored from a checkpoint fall back to step()."""
+        the graph's last node advances, so replays continue exactly where eager steps would: same draws, same rates.  The host
+        keeps a mirror of those counters next to the graph; whenever they no longer match the trainer's own (an eager step()
+        in between -- consistency steps, a restored rate --, a checkpoint load, sync_replicas) the state is re-written from
+        the host before the replay: no re-capture needed.
+        With more than one rank (or split=True) the step is TWO graphs around the one collective: [zero grad, forward,
+        backward] -> dist.all_reduce on the same stream, not captured -> [Adam, state advance]; the reference's
+        DataParallel semantics (run_lushnerf.py:348, 652-661) as in step().
+        The first calls, and one call after every change of the capture key, run step() itself (they are real steps: lazy
+        initialisation behind the entry points runs outside a capture); the batch is copied into the graph's static tensors
+        before every replay; the returned loss is the graph's static tensor, overwritten by the next replay.  Explicit draws,
+        the consistency branch and a rate restored from a checkpoint fall back to step()."""
         force_naive = i < self.kernel_start_iter
         allk = i < self.allkernel_start_iter
-        if self.world > 1:
-            raise NotImplementedError("Trainer.step_graph: a captured RCCL all-reduce has not been validated; use step()")
+        split = (self.world > 1) if split is None else bool(split)
+        prec = self.model.precision
+        key = (force_naive, allk, split, prec.fwd, prec.bwd, prec.variant,
+               tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in batch.items())))
+        if self._graph is not None and self._graph["key"] != key:
+            self.invalidate_graph()         # (e.g. force_naive flips at kernel_start_iter: the RBK / noise kernels' first call must be eager)
         if self._lr_next is not None or i >= self.noisenerf_start_iter or self._graph_eager_left > 0 or not self.flat.param.is_cuda:
             self._graph_eager_left = max(self._graph_eager_left - 1, 0)
             return self.step(batch, i)
-        key = (force_naive, allk, tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in batch.items())))
         hooks = self.model.hooks
-        if self._graph is None or self._graph[0] != key:
+        if self._graph is None:
             self.model.train()
             dev = self.flat.param.device
             state = torch.zeros(ops.lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
-            steps = (ops.C.c_int * 3)(*self.steps)
-            ops.lib.call("lush_step_state_init", ops.lib.ptr(state), ops.C.c_ulonglong(hooks.draw_offset), int(self.global_step), steps,
-                         float(self.lrate), float(self.lrate_decay * 1000), 0.9, 0.999, ops._stream())
+            mirror = self._state_init(state)
             static = {k: v.clone() for k, v in batch.items()}
-            graph = torch.cuda.CUDAGraph()
-            distributed, self.distributed = self.distributed, False
+            g1 = torch.cuda.CUDAGraph()
+            g2 = None
+            distributed, self.distributed = self.distributed, False      # (the captured body never calls the collective itself)
             try:
-                with torch.cuda.graph(graph):
-                    loss, calls, mask = self._step_body(static, i, force_naive, state)
+                if not split:
+                    with torch.cuda.graph(g1):
+                        loss, calls = self._body_grads(static, i, force_naive, state)
+                        mask = self._body_update(force_naive, state, calls)
+                else:
+                    with torch.cuda.graph(g1):
+                        loss, calls = self._body_grads(static, i, force_naive, state)
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, pool=g1.pool()):
+                        mask = self._body_update(force_naive, state, calls)
             finally:
                 self.distributed = distributed
-            self._graph = (key, graph, static, loss, calls, mask, state)
-        key, graph, static, loss, calls, mask, state = self._graph
+            self._graph = dict(key=key, g1=g1, g2=g2, static=static, loss=loss, calls=calls, mask=mask, state=state, mirror=mirror)
+        G = self._graph
+        if G["mirror"] != (int(hooks.draw_offset), int(self.global_step), tuple(self.steps)):
+            G["mirror"] = self._state_init(G["state"])
         for k, v in batch.items():
-            static[k].copy_(v, non_blocking=True)
-        graph.replay()
+            G["static"][k].copy_(v, non_blocking=True)
+        G["g1"].replay()
+        if G["g2"] is not None:
+            if self.distributed:
+                self._all_reduce()
+            G["g2"].replay()
         for s in range(3):
-            if (mask >> s) & 1:
+            if (G["mask"] >> s) & 1:
                 self.steps[s] += 1
         self.global_step += 1
-        hooks.draw_offset += calls
-        return loss
-
-    def _set_overlap(self, on: bool):
-        base = self.model.precision
-        bit = 0 if on else ops.lib.VARIANT_NO_OVERLAP
-        self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | bit)
-
-    def _probe_overlap(self, phase: str):
-        """step()'s passive calibration: called at the head ('begin') and the tail ('end') of the first six steps."""
-        import time
-        probe = self._overlap_probe
-        dev = self.flat.param.device
-        if probe is None or dev.type != "cuda" or self.model.precision.bwd != ops.PLANES_F16 or self.model.mlp_fine is None \
-                or (self.model.precision.variant & ops.lib.VARIANT_NO_OVERLAP and not probe):
-            self._overlap_probe = None
-            return
-        k = len(probe) // 2                      # index of the step being probed
-        if phase == "begin":
-            if k == 4:
-                self._set_overlap(False)
-            if k >= 2:
-                torch.cuda.synchronize(dev)
-            probe.append(time.perf_counter())
-        else:
-            if len(probe) // 2 >= 2:
-                torch.cuda.synchronize(dev)
-            probe.append(time.perf_counter())
-            if len(probe) == 12:                 # six steps seen: 2-3 with the overlap, 4-5 without
-                dt = [probe[2 * j + 1] - probe[2 * j] for j in range(6)]
-                t = torch.tensor([dt[2] + dt[3], dt[4] + dt[5]], dtype=torch.float64, device=dev)
-                if self.distributed:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                # (kept unless clearly slower: synchronised single steps scatter by +-1 %, the failure this guards against -- both
-                # kernels in one hardware queue -- costs +12 %)
-                self._set_overlap(bool(t[0] <= 1.03 * t[1]))
-                self.overlap_probe_ms = [float(x) * 500.0 for x in t.tolist()]      # ms per step: with, without
-                self._overlap_probe = None
-
-    def calibrate_overlap(self, batches, i0: int = 0, steps: int = 2) -> dict:
-        """lush_march_bwd runs the fine pass's weight gradients on a second stream beside the coarse pass's chain (two kernels
-        that share the chip only if the runtime gives the two streams different hardware queues -- otherwise they run one after
-        the other on part of the chip each, which is slower than not overlapping at all).  This times `steps` real steps each
-        way on THIS process's streams, keeps the faster setting in the model's precision (all ranks take the slowest rank's
-        view) and returns the two timings in ms per step.  The steps are ordinary optimisation steps."""
-        import time
-        dev = self.flat.param.device
-        if not dev.type == "cuda":
-            return {}
-        self._overlap_probe = None            # (explicit calibration replaces the passive one of step())
-        base = self.model.precision
-        out = {}
-        k = i0
-        for name, bit in (("overlap", 0), ("one_after_the_other", ops.lib.VARIANT_NO_OVERLAP)):
-            self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | bit)
-            self.step(batches[k % len(batches)], k)       # (one untimed step: lazy initialisation of the second stream)
-            k += 1
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                self.step(batches[k % len(batches)], k)
-                k += 1
-            torch.cuda.synchronize(dev)
-            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
-            if self.distributed:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            out[name] = float(t.item())
-        keep = 0 if out["overlap"] <= 1.03 * out["one_after_the_other"] else ops.lib.VARIANT_NO_OVERLAP      # (see _probe_overlap)
-        self.model.precision = ops.Precision(base.fwd, base.bwd, (base.variant & ~ops.lib.VARIANT_NO_OVERLAP) | keep)
-        out["chosen"] = "overlap" if keep == 0 else "one_after_the_other"
-        out["steps_taken"] = k - i0
-        return out
+        hooks.draw_offset += G["calls"]
+        G["mirror"] = (int(hooks.draw_offset), int(self.global_step), tuple(self.steps))
+        return G["loss"]
 
     def faults(self) -> int:
         """Numerical-fault word of the model's render calls since the last read (one device sync; the reference

@@ -110,7 +110,9 @@ def t_gen_rays():
 
 
 def t_composite():
-    for S, train in ((64, True), (128, True), (32, False)):
+    # S = 256 is BASELINE config 5's fine pass (128 + 128): composite_fwd_kernel<4> / composite_bwd_kernel<4>, four
+    # 64-sample blocks per wavefront with the carry of the exclusive product / the reverse affine scan between them
+    for S, train in ((64, True), (128, True), (32, False), (256, True), (256, False), (200, True)):
         R = 70
         raw = torch.from_numpy(synth.normal((R, S, 4), 11, S)) * torch.tensor([1., 1., 1., 30.])
         z = torch.sort(torch.from_numpy(synth.uniform((R, S), 0, 1, 12, S)), -1)[0]
@@ -831,15 +833,17 @@ def t_train_e2e():
             rep(f"train {name} grad_rays vs fixture", rays.grad, g["grad_rays"], sec)
 
 
-def t_train_bench_regime(n=512, seed=21):
+def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
     """The regime bench.py runs the chain kernels in: MANY 128-point tiles per persistent workgroup, so the weight stream
     wraps into the next tile (mlp_chain_*_half_kernel: min(n_tiles, 2 n_cu) workgroups; the 512-register kernels: n_cu)
     and dw_group_kernel walks many slices.  N_rand 512 with the blur kernel on = 2 560 marched rays = 327 680 fine points
     = 2 560 tiles (5 per workgroup for the half-row kernels, 10 for the one-workgroup ones).  No reference fixture exists
     at this size; the oracle (pinned to the fixtures by tests/test_oracle_golden.py) is evaluated here: outputs against
     its plain fp32 run at the north-star bound, gradients through the masked float64 / fp32 pair of masked_grad_check
-    (models/lushnerf.py:481-583, 630-654; run_lushnerf.py:652-661)."""
-    Ns = Ni = 64
+    (models/lushnerf.py:481-583, 630-654; run_lushnerf.py:652-661).
+    (n, Ns, Ni) = (256, 128, 128) is BASELINE config 5's sampling at the same point count (1 280 marched rays x 256 =
+    327 680 fine points): composite_*_kernel<4>, sample_merge at 128 + 128, ray_grad_reduce over 256 samples and the
+    chain / weight-gradient kernels with 256 consecutive points per ray."""
     prec = ops.Precision(*E2E_PLANES)
     rbk_scale = 2.0e4
     net = _nerf_all(Ni, seed, sharp=True, precision=prec, rbk_scale=rbk_scale)
@@ -868,6 +872,7 @@ def t_train_bench_regime(n=512, seed=21):
         ref = O.forward_train(p, H, W, F, b["rays"], b["images_idx"], Ns, Ni, force_naive=False, allkernel=True,
                               kernel_pixel=b["fq_mask"], draws=cpu_draws)
         ref_loss = O.train_loss(ref[0], ref[1], b["target"])
+    tagname = "bench regime" if (Ns, Ni) == (64, 64) else f"bench regime {Ns}+{Ni}"
     rep("bench regime rgb_blur", out[0], ref[0], 1e-4)
     rep("bench regime rgb0_blur", out[1], ref[1], 1e-4)
     rep("bench regime noise", out[3], ref[3], 1e-4)
@@ -881,7 +886,7 @@ def t_train_bench_regime(n=512, seed=21):
                             kernel_pixel=b["fq_mask"], draws={k: v.to(dt) for k, v in cpu_draws.items()})
         O.train_loss(r[0], r[1], b["target"].to(dt)).backward()
         return pp, {"grad_rays": rays_c}
-    masked_grad_check("bench regime", run_oracle, _canon_grads(net), {"grad_rays": rays.grad}, keep, prec)
+    masked_grad_check(tagname, run_oracle, _canon_grads(net), {"grad_rays": rays.grad}, keep, prec)
 
 
 if __name__ == "__main__":
