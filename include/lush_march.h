@@ -28,8 +28,10 @@ extern "C" {
 typedef void* lush_stream_t;
 
 const char* lush_last_error(void);
-int lush_abi_version(void);   /* 6 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
-                             * backward entry points write their outputs instead of accumulating) */
+int lush_abi_version(void);   /* 7 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
+                             * backward entry points write their outputs instead of accumulating; 7, round 4: the fused ray-level
+                             * entry points lush_rbk_warp_ndc_* and lush_blur_mix_*, an explicit d_rvw row stride, and no second
+                             * stream inside lush_march_bwd) */
 
 /* ------------------------------------------------------------------ sampling
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
@@ -145,14 +147,17 @@ typedef struct {
 } lush_rbk_grads;
 #define LUSH_RBK_ACT_STRIDE 512      /* floats per image in `acts` */
 #define LUSH_RBK_RVW_STRIDE 32       /* r(12) v(12) w(5) pad(3) */
-/* acts [num_img][512] (hidden activations + r, v, w). */
+#define LUSH_RBK_RVW_OFFSET 480      /* acts[i][480..511]: lush_rbk_mlp_fwd leaves them ZERO, so the gradients w.r.t. r, v, w of image
+                                      * i may be accumulated right there (d_rvw = acts + 480, rvw_stride = 512): no buffer of their
+                                      * own, no zero-fill launch */
+/* acts [num_img][512] (hidden activations + r, v, w; every element written, [464..511] as zeros). */
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts,
                      lush_stream_t stream);
-/* d_rvw [num_img][32] = gradients w.r.t. r(12), v(12), normalised w(5).
+/* d_rvw [num_img][rvw_stride >= 32] = gradients w.r.t. r(12), v(12), normalised w(5) in the first 29 floats of a row.
  * `g` is overwritten, or added to when accumulate != 0 (gradient buffers that already hold a slice's
  * contribution); scratch >= num_img*512 floats. */
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
-                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, int accumulate,
+                     const float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate,
                      lush_stream_t stream);
 /* rbk_warp (models/lushnerf.py:75-98) + SE3Field.warp (utils/rigid_warping.py:20-140):
  * rays [N][3][2], idx [N] int64 -> new_rays [N*(M+1)][3][2] (slot 0 = input ray),
@@ -161,11 +166,24 @@ int lush_rbk_warp_fwd(const float* rays, const int64_t* idx, int N, int M, const
                       float* new_rays, float* ccw, lush_stream_t stream);
 /* mask [N] (uint8) or NULL: rays whose mask is 0 pass no gradient through
  * new_rays (the allkernel torch.where(..., x, x.detach()), models/lushnerf.py:641-643).
- * d_rvw [num_img][32] accumulate (must be zeroed by the caller); drays [N][3][2]
+ * d_rvw [num_img][rvw_stride] accumulate (zero before the first call of a step); drays [N][3][2]
  * overwritten, may be NULL. */
 int lush_rbk_warp_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts,
                       const float* dnew_rays, const float* dccw, const uint8_t* mask,
-                      float* d_rvw, float* drays, lush_stream_t stream);
+                      float* d_rvw, int rvw_stride, float* drays, lush_stream_t stream);
+/* The two above and lush_pack_rays_fwd / _bwd in ONE kernel per direction (SURVEY.md section 7.2 `rbk_warp_ndc`):
+ * Rigid_Blurring_Kernel.forward's warp (models/lushnerf.py:75-98, utils/rigid_warping.py:20-140) followed by the head of
+ * render_train_scene (:772-795; ndc_rays, utils/run_lushnerf_helpers.py:542-562) for the M + 1 rays of every input ray --
+ * the warped rays never exist in memory -- and the same head for the input ray alone, which is what render_train_noise
+ * (:827-850) marches: rays [N][3][2], idx [N] -> batch [N*(M+1)][11] (row n*(M+1) = the input ray), ccw [N][M+1],
+ * batch0 [N][11] (may be NULL).  cx, cy, near, far as lush_pack_rays_fwd. */
+int lush_rbk_warp_ndc_fwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, int ndc, float cx, float cy,
+                          float near, float far, float* batch, float* ccw, float* batch0, lush_stream_t stream);
+/* dbatch [N*(M+1)][11] (NULL: no gradient through the rays) and dccw [N][M+1] (NULL: none through the weights) -> d_rvw
+ * (accumulate, as lush_rbk_warp_bwd), drays [N][3][2] (overwritten; may be NULL). */
+int lush_rbk_warp_ndc_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, int ndc, float cx, float cy,
+                          const float* dbatch, const float* dccw, const uint8_t* mask, float* d_rvw, int rvw_stride,
+                          float* drays, lush_stream_t stream);
 
 /* ------------------------------------------------------- blur mix and tone map
  * rbk_weighted_sum (models/lushnerf.py:100-116): x [N*M][C], ccw [N][M] -> y [N][C]. */
@@ -181,6 +199,17 @@ int lush_tonemap_bwd(const float* x, const float* nraw, int n, int gamma, const 
 /* y = 0.1*sigmoid(x), models/lushnerf.py:649, 660. */
 int lush_noise_act_fwd(const float* x, int n, float* y, lush_stream_t stream);
 int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_stream_t stream); /* every element written */
+/* The tail of NeRFAll.forward's training branch in ONE kernel per direction (SURVEY.md section 7.2 `blur_mix_tonemap`;
+ * models/lushnerf.py:644-654, 100-116; utils/run_lushnerf_helpers.py:164-174): with s = sum_m ccw[n][m] rgb[n*M1+m],
+ * s0 the same on rgb0 and nz = 0.1 sigmoid(nraw):  blur = tm(s + nz), blur0 = tm(s0 + nz), noise = nz, sharp = tm(s),
+ * sharp0 = tm(s0); tm = x ** (1/2.2) when gamma, else identity.  rgb, rgb0 [N*M1][3]; ccw [N][M1]; nraw [N][3]; outputs [N][3]. */
+int lush_blur_mix_fwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+                      float* blur, float* blur0, float* noise, float* sharp, float* sharp0, lush_stream_t stream);
+/* g_* [N][3]: gradients of the five outputs, any of them NULL (= 0).  d_rgb, d_rgb0 [N*M1][3], d_ccw [N][M1], d_nraw [N][3]:
+ * every element written. */
+int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+                      const float* g_blur, const float* g_blur0, const float* g_noise, const float* g_sharp,
+                      const float* g_sharp0, float* d_rgb, float* d_rgb0, float* d_ccw, float* d_nraw, lush_stream_t stream);
 /* Training loss of run_lushnerf.py:652-661: sum over the two colours of
  * 0.5*MSE + 0.5*L1 against target [n][3], times `scale` (the share of a micro-batch in the step's
  * mean; 1 for the plain loss).  loss[0] accumulate (zero it first); ga / gb = d loss / d a, d loss / d b

@@ -317,14 +317,10 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const
 }
 
 // -------------------------------------------------------------- ray prologue
-__global__ void pack_rays_fwd_kernel(const float* __restrict__ rays, int N, int ndc, float cx, float cy, float near,
-                                     float far, float* __restrict__ batch) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float* r = rays + (long long)n * 6;          // [3][2]: r[2*i] = o_i, r[2*i+1] = d_i
-    float o[3] = {r[0], r[2], r[4]}, d[3] = {r[1], r[3], r[5]};
+// one ray (o, d) -> its 11 batch columns [o' d' near far viewdir]
+__device__ __forceinline__ void pack_one(const float (&o)[3], const float (&d)[3], int ndc, float cx, float cy, float near, float far,
+                                         float* __restrict__ b) {
     const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    float* b = batch + (long long)n * 11;
     b[8] = d[0] / nrm; b[9] = d[1] / nrm; b[10] = d[2] / nrm;
     if (ndc) {   // utils/run_lushnerf_helpers.py:542-562 with near = 1
         const float t = -(1.f + o[2]) / d[2];
@@ -341,15 +337,11 @@ __global__ void pack_rays_fwd_kernel(const float* __restrict__ rays, int N, int 
     }
     b[6] = near; b[7] = far;
 }
-
-__global__ void pack_rays_bwd_kernel(const float* __restrict__ rays, int N, int ndc, float cx, float cy,
-                                     const float* __restrict__ dbatch, float* __restrict__ drays) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float* r = rays + (long long)n * 6;
-    const float o[3] = {r[0], r[2], r[4]}, d[3] = {r[1], r[3], r[5]};
-    const float* g = dbatch + (long long)n * 11;
-    float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+// reverse mode of pack_one: g = d loss / d (batch row) -> go, gd (overwritten)
+__device__ __forceinline__ void pack_one_bwd(const float (&o)[3], const float (&d)[3], int ndc, float cx, float cy,
+                                             const float* __restrict__ g, float (&go)[3], float (&gd)[3]) {
+    go[0] = go[1] = go[2] = 0.f;
+    gd[0] = gd[1] = gd[2] = 0.f;
     // viewdir = d/|d|
     const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     const float v[3] = {d[0] / nrm, d[1] / nrm, d[2] / nrm};
@@ -376,6 +368,25 @@ __global__ void pack_rays_bwd_kernel(const float* __restrict__ rays, int N, int 
 #pragma unroll
         for (int i = 0; i < 3; ++i) { go[i] += g[i]; gd[i] += g[3 + i]; }
     }
+}
+
+__global__ void pack_rays_fwd_kernel(const float* __restrict__ rays, int N, int ndc, float cx, float cy, float near,
+                                     float far, float* __restrict__ batch) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = rays + (long long)n * 6;          // [3][2]: r[2*i] = o_i, r[2*i+1] = d_i
+    const float o[3] = {r[0], r[2], r[4]}, d[3] = {r[1], r[3], r[5]};
+    pack_one(o, d, ndc, cx, cy, near, far, batch + (long long)n * 11);
+}
+
+__global__ void pack_rays_bwd_kernel(const float* __restrict__ rays, int N, int ndc, float cx, float cy,
+                                     const float* __restrict__ dbatch, float* __restrict__ drays) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = rays + (long long)n * 6;
+    const float o[3] = {r[0], r[2], r[4]}, d[3] = {r[1], r[3], r[5]};
+    float go[3], gd[3];
+    pack_one_bwd(o, d, ndc, cx, cy, dbatch + (long long)n * 11, go, gd);
     float* out = drays + (long long)n * 6;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { out[2 * i] = go[i]; out[2 * i + 1] = gd[i]; }
@@ -583,11 +594,11 @@ __global__ void rbk_warp_fwd_kernel(const float* __restrict__ rays, const int64_
 __global__ void rbk_warp_bwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
                                     const float* __restrict__ acts, const float* __restrict__ dnew,
                                     const float* __restrict__ dccw, const uint8_t* __restrict__ mask,
-                                    float* __restrict__ d_rvw, float* __restrict__ drays) {
+                                    float* __restrict__ d_rvw, int rvw_stride, float* __restrict__ drays) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const long long img = idx[n];
-    float* G = d_rvw + img * LUSH_RBK_RVW_STRIDE;
+    float* G = d_rvw + img * rvw_stride;
     if (dccw)
         for (int m = 0; m <= M; ++m) atomicAdd(G + 24 + m, dccw[(long long)n * (M + 1) + m]);
     const bool live = dnew != nullptr && (mask == nullptr || mask[n] != 0);
@@ -608,6 +619,94 @@ __global__ void rbk_warp_bwd_kernel(const float* __restrict__ rays, const int64_
             const V3 gwo = {w6[0], w6[2], w6[4]}, gwd = {w6[1], w6[3], w6[5]};
             // wd = we - wo
             const V3 gye = gwd, gyo = gwo - gwd;
+            V3 gp_o = {0, 0, 0}, gp_e = {0, 0, 0}, gw = {0, 0, 0}, gnu = {0, 0, 0};
+            float gth = 0.f, gs = 0.f, gc = 0.f;
+            se3_apply_bwd(q, o, gyo, gp_o, gw, gnu, gth, gs, gc);
+            se3_apply_bwd(q, end, gye, gp_e, gw, gnu, gth, gs, gc);
+            V3 gr, gv;
+            se3_finish_bwd(q, r, gw, gnu, gth, gs, gc, gr, gv);
+            go = go + gp_o + gp_e;
+            gd = gd + gp_e;
+            atomicAdd(G + m, gr.x); atomicAdd(G + M + m, gr.y); atomicAdd(G + 2 * M + m, gr.z);
+            atomicAdd(G + 12 + m, gv.x); atomicAdd(G + 12 + M + m, gv.y); atomicAdd(G + 12 + 2 * M + m, gv.z);
+        }
+    }
+    if (drays) {
+        float* out = drays + (long long)n * 6;
+        out[0] = go.x; out[1] = gd.x; out[2] = go.y; out[3] = gd.y; out[4] = go.z; out[5] = gd.z;
+    }
+}
+
+// ------------------------------------------------- warp + NDC + pack in one (SURVEY 7.2 `rbk_warp_ndc`)
+// Rigid_Blurring_Kernel.rbk_warp (models/lushnerf.py:75-98) followed by the head of render_train_scene (:772-795: view
+// directions, ndc_rays helpers:542-562, near / far columns) for the M + 1 rays of every input ray, and the same head for the
+// input ray alone (render_train_noise, :827-850): rays [N][3][2] -> batch [N*(M+1)][11], ccw [N][M+1], batch0 [N][11].
+// One thread per (input ray, motion slot): the warped rays never exist in memory.
+__global__ void rbk_warp_ndc_fwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
+                                        const float* __restrict__ acts, int ndc, float cx, float cy, float near, float far,
+                                        float* __restrict__ batch, float* __restrict__ ccw, float* __restrict__ batch0) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M1 = M + 1;
+    if (t >= (long long)N * M1) return;
+    const long long n = t / M1;
+    const int m = (int)(t % M1);
+    const float* r6 = rays + n * 6;
+    const V3 o = {r6[0], r6[2], r6[4]}, d = {r6[1], r6[3], r6[5]};
+    const float* A = acts + idx[n] * LUSH_RBK_ACT_STRIDE;
+    V3 wo = o, wd = d;
+    if (m > 0) {    // r.reshape(N,3,M): component c of motion m-1 is column c*M + m-1 (models/lushnerf.py:76)
+        const int k = m - 1;
+        const V3 r = {A[RA_R + k], A[RA_R + M + k], A[RA_R + 2 * M + k]};
+        const V3 v = {A[RA_V + k], A[RA_V + M + k], A[RA_V + 2 * M + k]};
+        const Se3 q = se3_setup(r, v);
+        wo = se3_apply(q, o);
+        wd = se3_apply(q, o + d) - wo;
+    }
+    const float oo[3] = {wo.x, wo.y, wo.z}, dd[3] = {wd.x, wd.y, wd.z};
+    pack_one(oo, dd, ndc, cx, cy, near, far, batch + t * 11);
+    ccw[t] = A[RA_WN + m];
+    if (m == 0 && batch0 != nullptr) pack_one(oo, dd, ndc, cx, cy, near, far, batch0 + n * 11);
+}
+
+// Reverse: dbatch [N*(M+1)][11] (may be NULL: only the weights' gradient), dccw [N][M+1] (may be NULL) -> d_rvw [num_img][32]
+// (atomics; zeroed by lush_rbk_mlp_fwd), drays [N][3][2] (overwritten; may be NULL).  mask as in rbk_warp_bwd_kernel.
+__global__ void rbk_warp_ndc_bwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
+                                        const float* __restrict__ acts, int ndc, float cx, float cy,
+                                        const float* __restrict__ dbatch, const float* __restrict__ dccw,
+                                        const uint8_t* __restrict__ mask, float* __restrict__ d_rvw, int rvw_stride,
+                                        float* __restrict__ drays) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int M1 = M + 1;
+    const long long img = idx[n];
+    float* G = d_rvw + img * rvw_stride;
+    if (dccw)
+        for (int m = 0; m <= M; ++m) atomicAdd(G + 24 + m, dccw[(long long)n * M1 + m]);
+    const bool live = dbatch != nullptr && (mask == nullptr || mask[n] != 0);
+    V3 go = {0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f};
+    if (live) {
+        const float* r6 = rays + (long long)n * 6;
+        const V3 o = {r6[0], r6[2], r6[4]}, d = {r6[1], r6[3], r6[5]};
+        const V3 end = o + d;
+        const float* A = acts + img * LUSH_RBK_ACT_STRIDE;
+        const float* g11 = dbatch + (long long)n * M1 * 11;
+        {   // slot 0: the input ray itself
+            const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+            float a[3], b[3];
+            pack_one_bwd(oo, dd, ndc, cx, cy, g11, a, b);
+            go = {a[0], a[1], a[2]};
+            gd = {b[0], b[1], b[2]};
+        }
+        for (int m = 0; m < M; ++m) {
+            const V3 r = {A[RA_R + m], A[RA_R + M + m], A[RA_R + 2 * M + m]};
+            const V3 v = {A[RA_V + m], A[RA_V + M + m], A[RA_V + 2 * M + m]};
+            const Se3 q = se3_setup(r, v);
+            const V3 wo = se3_apply(q, o), wd = se3_apply(q, end) - wo;     // (recomputed: the warped rays were never stored)
+            const float oo[3] = {wo.x, wo.y, wo.z}, dd[3] = {wd.x, wd.y, wd.z};
+            float a[3], b[3];
+            pack_one_bwd(oo, dd, ndc, cx, cy, g11 + (m + 1) * 11, a, b);
+            const V3 gwo = {a[0], a[1], a[2]}, gwd = {b[0], b[1], b[2]};
+            const V3 gye = gwd, gyo = gwo - gwd;       // wd = we - wo
             V3 gp_o = {0, 0, 0}, gp_e = {0, 0, 0}, gw = {0, 0, 0}, gnu = {0, 0, 0};
             float gth = 0.f, gs = 0.f, gc = 0.f;
             se3_apply_bwd(q, o, gyo, gp_o, gw, gnu, gth, gs, gc);
@@ -718,12 +817,13 @@ __device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, floa
 __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
-                                                          float* __restrict__ /*scratch: unused since the LDS version*/, int accumulate) {
+                                                          float* __restrict__ /*scratch: unused since the LDS version*/, int accumulate,
+                                                          int RS /* floats between two images' rows of d_rvw */) {
     // LDS: activations [n][RBK_LS] then adjoints of the pre-activations in the same per-image layout
     extern __shared__ float rbk_lds[];
     float* A = rbk_lds;
     float* sc = rbk_lds + n * RBK_LS;
-    const int ST = LUSH_RBK_ACT_STRIDE, RS = LUSH_RBK_RVW_STRIDE;
+    const int ST = LUSH_RBK_ACT_STRIDE;
     for (int t = threadIdx.x; t < n * ST; t += blockDim.x) {
         A[(t / ST) * RBK_LS + (t % ST)] = acts[t];
         sc[(t / ST) * RBK_LS + (t % ST)] = 0.f;
@@ -811,6 +911,8 @@ __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel_g(lush_rbk_params p, 
         }
         for (int m = 0; m <= M; ++m) acts[i * ST + RA_WN + m] = acts[i * ST + RA_WS + m] / (sum + 1e-10f);
     }
+    for (int t = threadIdx.x; t < n * (ST - RA_WN - 8); t += blockDim.x)       // the row tail is zero (as the LDS version leaves it):
+        acts[(t / (ST - RA_WN - 8)) * ST + RA_WN + 8 + t % (ST - RA_WN - 8)] = 0.f;   // LUSH_RBK_RVW_OFFSET.. may hold d_rvw
 }
 
 // dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
@@ -851,9 +953,9 @@ __device__ void rbk_dense_bwd_w_g(const float* dz, int zs, const float* x, int x
 __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel_g(lush_rbk_params p, int n, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
-                                                          float* __restrict__ sc, int accumulate) {
+                                                          float* __restrict__ sc, int accumulate, int RS) {
     // scratch uses the same per-image layout as acts, holding adjoints of the pre-activations
-    const int ST = LUSH_RBK_ACT_STRIDE, RS = LUSH_RBK_RVW_STRIDE;
+    const int ST = LUSH_RBK_ACT_STRIDE;
     for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
         const int i = t / (3 * M), o = t % (3 * M);
         sc[i * ST + RA_R + o] = d_rvw[i * RS + o] * window;
@@ -948,6 +1050,70 @@ __global__ void noise_act_bwd_kernel(const float* __restrict__ x, int n, const f
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) { const float s = 1.f / (1.f + expf(-x[t])); dx[t] = dy[t] * 0.1f * s * (1.f - s); }
 }
+// ------------------------------------------------- blur mix + noise + tone map in one (SURVEY 7.2 `blur_mix_tonemap`)
+// The tail of NeRFAll.forward's training branch (models/lushnerf.py:644-654): rbk_weighted_sum of the fine and the coarse
+// colour (:100-116), rgb_noise = 0.1 sigmoid(noise_raw) (:649), and the five tone-mapped / plain outputs of the 7-tuple
+//   blur = tm(sum_m ccw x + rgb_noise), blur0 likewise, noise = rgb_noise, sharp = tm(sum_m ccw x), sharp0 likewise.
+// One thread per (input ray, channel); the weighted sums in the order of wsum_fwd_kernel (m ascending).
+__device__ __forceinline__ float tm_apply(float v, int gamma) { return gamma ? powf(v, INV_GAMMA) : v; }
+__device__ __forceinline__ float tm_slope(float v, int gamma) { return gamma ? INV_GAMMA * powf(v, INV_GAMMA - 1.f) : 1.f; }
+__global__ void blur_mix_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0, const float* __restrict__ ccw,
+                                    const float* __restrict__ nraw, int N, int M1, int gamma, float* __restrict__ blur,
+                                    float* __restrict__ blur0, float* __restrict__ noise, float* __restrict__ sharp,
+                                    float* __restrict__ sharp0) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * 3) return;
+    const long long n = t / 3;
+    const int c = (int)(t % 3);
+    float s = 0.f, s0 = 0.f;
+    for (int m = 0; m < M1; ++m) {
+        const float w = ccw[n * M1 + m];
+        s += rgb[(n * M1 + m) * 3 + c] * w;
+        s0 += rgb0[(n * M1 + m) * 3 + c] * w;
+    }
+    const float nz = 0.1f * (1.f / (1.f + expf(-nraw[t])));
+    blur[t] = tm_apply(s + nz, gamma);
+    blur0[t] = tm_apply(s0 + nz, gamma);
+    noise[t] = nz;
+    sharp[t] = tm_apply(s, gamma);
+    sharp0[t] = tm_apply(s0, gamma);
+}
+// Reverse: one thread per (input ray, motion slot).  Any of the five output gradients may be NULL (= 0).  d_rgb / d_rgb0
+// [N*M1][3], d_ccw [N][M1], d_nraw [N][3] overwritten (d_nraw by the slot-0 thread).
+__global__ void blur_mix_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0, const float* __restrict__ ccw,
+                                    const float* __restrict__ nraw, int N, int M1, int gamma, const float* __restrict__ g_blur,
+                                    const float* __restrict__ g_blur0, const float* __restrict__ g_noise,
+                                    const float* __restrict__ g_sharp, const float* __restrict__ g_sharp0,
+                                    float* __restrict__ d_rgb, float* __restrict__ d_rgb0, float* __restrict__ d_ccw,
+                                    float* __restrict__ d_nraw) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * M1) return;
+    const long long n = t / M1;
+    const int slot = (int)(t % M1);
+    const float w = ccw[t];
+    float dw = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f, s0 = 0.f;            // (recomputed per thread: M1 * 6 loads that the wave's neighbours share through L1)
+        for (int m = 0; m < M1; ++m) {
+            const float wm = ccw[n * M1 + m];
+            s += rgb[(n * M1 + m) * 3 + c] * wm;
+            s0 += rgb0[(n * M1 + m) * 3 + c] * wm;
+        }
+        const float sg = 1.f / (1.f + expf(-nraw[n * 3 + c]));
+        const float nz = 0.1f * sg;
+        const float gb = g_blur ? g_blur[n * 3 + c] * tm_slope(s + nz, gamma) : 0.f;
+        const float gb0 = g_blur0 ? g_blur0[n * 3 + c] * tm_slope(s0 + nz, gamma) : 0.f;
+        const float gs = gb + (g_sharp ? g_sharp[n * 3 + c] * tm_slope(s, gamma) : 0.f);       // d / d (weighted sum), fine
+        const float gs0 = gb0 + (g_sharp0 ? g_sharp0[n * 3 + c] * tm_slope(s0, gamma) : 0.f);  // ... coarse
+        d_rgb[t * 3 + c] = gs * w;
+        d_rgb0[t * 3 + c] = gs0 * w;
+        dw += gs * rgb[t * 3 + c] + gs0 * rgb0[t * 3 + c];
+        if (slot == 0) d_nraw[n * 3 + c] = (gb + gb0 + (g_noise ? g_noise[n * 3 + c] : 0.f)) * 0.1f * sg * (1.f - sg);
+    }
+    d_ccw[t] = dw;
+}
+
 __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ tg,
                             int n3, float scale, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1122,7 +1288,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 6; }
+int lush_abi_version(void) { return 7; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
@@ -1234,15 +1400,16 @@ int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window,
     return 0;
 }
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
-                     const float* d_rvw, const lush_rbk_grads* g, float* scratch, int accumulate, lush_stream_t st) {
+                     const float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
+    if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_mlp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
     const size_t lds = (size_t)2 * num_img * RBK_LS * sizeof(float);
     if (lds > 160 * 1024) {
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate);
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate, rvw_stride);
     } else {
         LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate);
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate, rvw_stride);
     }
     CHECK_LAUNCH();
     return 0;
@@ -1254,8 +1421,49 @@ int lush_rbk_warp_fwd(const float* rays, const int64_t* idx, int N, int M, const
     return 0;
 }
 int lush_rbk_warp_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, const float* dnew_rays,
-                      const float* dccw, const uint8_t* mask, float* d_rvw, float* drays, lush_stream_t st) {
-    hipLaunchKernelGGL(rbk_warp_bwd_kernel, dim3(cdiv(N, 128)), dim3(128), 0, S_(st), rays, idx, N, M, acts, dnew_rays, dccw, mask, d_rvw, drays);
+                      const float* dccw, const uint8_t* mask, float* d_rvw, int rvw_stride, float* drays, lush_stream_t st) {
+    if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_warp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
+    hipLaunchKernelGGL(rbk_warp_bwd_kernel, dim3(cdiv(N, 128)), dim3(128), 0, S_(st), rays, idx, N, M, acts, dnew_rays, dccw, mask, d_rvw, rvw_stride, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_rbk_warp_ndc_fwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, int ndc, float cx, float cy,
+                          float near, float far, float* batch, float* ccw, float* batch0, lush_stream_t st) {
+    if (N < 1 || M < 1 || M > 4) return set_error("lush_rbk_warp_ndc_fwd: need N >= 1 and 1 <= num_motion <= 4");
+    if (!rays || !idx || !acts || !batch || !ccw) return set_error("lush_rbk_warp_ndc_fwd: rays, idx, acts, batch and ccw are required");
+    hipLaunchKernelGGL(rbk_warp_ndc_fwd_kernel, dim3(cdiv((long long)N * (M + 1), 256)), dim3(256), 0, S_(st), rays, idx, N, M, acts, ndc,
+                       cx, cy, near, far, batch, ccw, batch0);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_rbk_warp_ndc_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, int ndc, float cx, float cy,
+                          const float* dbatch, const float* dccw, const uint8_t* mask, float* d_rvw, int rvw_stride, float* drays,
+                          lush_stream_t st) {
+    if (N < 1 || M < 1 || M > 4) return set_error("lush_rbk_warp_ndc_bwd: need N >= 1 and 1 <= num_motion <= 4");
+    if (!rays || !idx || !acts || !d_rvw) return set_error("lush_rbk_warp_ndc_bwd: rays, idx, acts and d_rvw are required");
+    if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_warp_ndc_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
+    hipLaunchKernelGGL(rbk_warp_ndc_bwd_kernel, dim3(cdiv(N, 128)), dim3(128), 0, S_(st), rays, idx, N, M, acts, ndc, cx, cy, dbatch,
+                       dccw, mask, d_rvw, rvw_stride, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_blur_mix_fwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+                      float* blur, float* blur0, float* noise, float* sharp, float* sharp0, lush_stream_t st) {
+    if (N < 1 || M1 < 1) return set_error("lush_blur_mix_fwd: empty");
+    if (!rgb || !rgb0 || !ccw || !nraw || !blur || !blur0 || !noise || !sharp || !sharp0) return set_error("lush_blur_mix_fwd: every pointer is required");
+    hipLaunchKernelGGL(blur_mix_fwd_kernel, dim3(cdiv(3LL * N, 256)), dim3(256), 0, S_(st), rgb, rgb0, ccw, nraw, N, M1, gamma, blur, blur0,
+                       noise, sharp, sharp0);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+                      const float* g_blur, const float* g_blur0, const float* g_noise, const float* g_sharp, const float* g_sharp0,
+                      float* d_rgb, float* d_rgb0, float* d_ccw, float* d_nraw, lush_stream_t st) {
+    if (N < 1 || M1 < 1) return set_error("lush_blur_mix_bwd: empty");
+    if (!rgb || !rgb0 || !ccw || !nraw || !d_rgb || !d_rgb0 || !d_ccw || !d_nraw) return set_error("lush_blur_mix_bwd: inputs and the four gradient outputs are required");
+    hipLaunchKernelGGL(blur_mix_bwd_kernel, dim3(cdiv((long long)N * M1, 256)), dim3(256), 0, S_(st), rgb, rgb0, ccw, nraw, N, M1, gamma,
+                       g_blur, g_blur0, g_noise, g_sharp, g_sharp0, d_rgb, d_rgb0, d_ccw, d_nraw);
     CHECK_LAUNCH();
     return 0;
 }

@@ -79,7 +79,7 @@ __device__ __forceinline__ void lush_sincos(float x, float* sn, float* cs) {
 
 // Hardware sin / cos (v_sin_f32 / v_cos_f32 take revolutions) behind an exact range reduction: the coordinate over 2 pi
 // as a double-float hi + lo (rev_split: one FMA), times the power of two (exact), v_fract (exact), + the scaled lo.
-// 4.2e-7 absolute against float64 over 2^k [-2, 2], k = 0..9 (tests/micro/sincos_hw.hip): 1/500 of the fp16 grid -- used by
+// 4.2e-7 absolute against float64 over 2^k [-2, 2], k = 0..9 (tools/micro/sincos_hw.hip): 1/500 of the fp16 grid -- used by
 // the one-fp16-plane kernels only (the two-plane bf16 kernels carry 2^-17 and keep lush_sincos above); ~6 instructions
 // instead of ~30.
 __device__ __forceinline__ void rev_split(float x, float* hi, float* lo) {

@@ -106,7 +106,7 @@ struct WdConv {
             // zero flags of the pair (1 where the clamped halfword is zero) at bits 0 and 16, shifted to 8 tt + 2 i / + 16 and
             // merged; the last unit folds the high halves in and inverts: bit q = accumulator q positive.
             // (v_dot2_u32_u16 would place both flags in one instruction, but costs ~12 cycles and stalls the matrix pipe:
-            // tests/micro/mfma_fillers.hip; v_lshl_or_b32 hides behind the MFMAs like any plain VALU instruction.)
+            // tools/micro/mfma_fillers.hip; v_lshl_or_b32 hides behind the MFMAs like any plain VALU instruction.)
             constexpr int sh = 8 * tt + 2 * i;
             unsigned z;
             if constexpr (tt == 0 && i == 0) {
@@ -300,6 +300,14 @@ struct WdPass {
             if constexpr (G == 0) {
                 alpha[0] = pend[0][0][0];
                 alpha[1] = pend[1][0][0];
+            }
+            if constexpr (G == 1) {
+                // Only row 0 of the alpha head's two accumulator blocks is ever read, so for the register allocator the other 15
+                // registers of each block die with the block's LAST MFMA -- and it handed them to the outputs of the conversion
+                // units' asm statements in the very next gaps, 2 .. 9 wait states behind an MFMA that writes all 16 for 11
+                // (isa_check.py rule R4; hipcc pads its own instructions there, not an asm statement's).  Whole blocks stay
+                // live until here, two MFMAs (16 wait states) later.
+                asm volatile("" ::"v"(pend[0][0]), "v"(pend[1][0]));
             }
             if constexpr (G >= 1 && G <= 8) {       // re-load both blocks of each column set with the next pass's biases
                 constexpr int q = G - 1, c = q % 2, rbl = (q / 2) % 2, jj = q / 4;    // two loads per gap

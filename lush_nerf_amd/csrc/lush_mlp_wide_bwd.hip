@@ -498,7 +498,12 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(drn[c]) : "v"((unsigned)(gpt * 16)), "s"(A.draw) : "memory");
         }
     };
+    // (first tile: waited for right here -- nothing runs beside it anyway -- so that the tile loop's head has ONE wait for every
+    // tile.  With a vmcnt(0) for the first tile and a vmcnt(32) for the others selected by `tile == blockIdx.x` at the loop
+    // head, no path-insensitive reading of the code can tell that the prefetch is always waited for; lush_nerf_amd/isa_check.py
+    // rule R5 follows every path and now finds the wait on each of them.)
     if ((int)blockIdx.x < A.n_tiles) prefetch(blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
 #ifdef LUSH_PROF
     for (int i = 0; i < 16; ++i) cx.prof[i] = 0;
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
@@ -517,10 +522,9 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         const char* mbase[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) mbase[c] = wd_uniform(reinterpret_cast<const char*>(A.mask) + (wpt / 32 + c) * CB_BYTES - w * 1024);
-        // the prefetch has landed.  First tile: nothing was issued behind it; later tiles: the 32 row stores of dZ_0 were (and the two
-        // d(point) stores, unless the whole wave lies beyond P: not counted -- an undercount is safe)
-        if (tile == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
-        else asm volatile("s_waitcnt vmcnt(32)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
+        // the prefetch has landed.  First tile: waited for in front of the loop; later tiles: the 32 row stores of dZ_0 were issued
+        // behind it (and the two d(point) stores, unless the whole wave lies beyond P: not counted -- an undercount is safe)
+        asm volatile("s_waitcnt vmcnt(32)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
         float4 dr[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {

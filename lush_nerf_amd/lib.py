@@ -13,7 +13,7 @@ from typing import Sequence
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO_PATH = os.environ.get("LUSH_SO") or os.path.join(HERE, "liblush_march.so")   # LUSH_SO: developer ablation builds
+SO_PATH = os.path.join(HERE, "liblush_march.so")      # (developer tools load another build with use_library(path) BEFORE load())
 SOURCES = ["lush_march.hip", "lush_mlp.hip", "lush_mlp_chain.hip", "lush_mlp_wide.hip", "lush_mlp_wide_bwd.hip", "lush_abi.hip", "lush_march_abi.hip"]
 HEADERS = ["lush_common.h", "lush_mlp.h", "lush_mlp_dev.h", "lush_mlp_wide.h", "lush_host.h", os.path.join("..", "..", "include", "lush_march.h")]
 
@@ -34,19 +34,36 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into lush_nerf_amd/liblush_march.so."""
-    if not force and not needs_build():
+def use_library(path: str):
+    """Developer tools only (tools/*.py: ablation / profiling builds): load() will open `path` instead of the in-tree product."""
+    global SO_PATH, _lib
+    if _lib is not None:
+        raise RuntimeError("lib.use_library: a library is already loaded")
+    SO_PATH = os.path.abspath(path)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: Sequence[str] = (), out: str = None, audit: bool = True) -> str:
+    """Compile the HIP sources for gfx950 into lush_nerf_amd/liblush_march.so and audit the result (isa_check).
+
+    The product build takes nothing from the environment.  `extra_flags` / `out` are for developer builds (tools/build_variant.py:
+    -DLUSH_PROF, the -DLUSH_ABL_* timing ablations) and refuse to write the product's path."""
+    product = out is None
+    if extra_flags and product:
+        raise ValueError("lib.build: extra compiler flags need an explicit `out` path (the in-tree product is built without any)")
+    target = SO_PATH if product else os.path.abspath(out)
+    if product and not force and not needs_build():
         return SO_PATH
     # -ffp-contract=off: fp32 VALU expressions round op by op like the reference's torch ops
     # (o + d*z must not become one FMA: a 1-ulp point error is amplified x512 by the encoding).
     # one hipcc -c per source, in parallel (the chain kernels alone take ~1 min), then one link
+    import re
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *os.environ.get("LUSH_HIPCC_FLAGS", "").split()]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *extra_flags]
     # per file: the 64-points-per-wave kernels keep their accumulators in VGPRs (the VALU converts them; AGPR-resident
     # accumulators cost one v_accvgpr_read per value) and let the B-operand buffers, which only MFMAs read, go to AGPRs
     per_file = {"lush_mlp_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lush_mlp_wide_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    usage = {}
     with tempfile.TemporaryDirectory(prefix="lush_build_") as tmp:
         def compile_one(f):
             obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
@@ -56,27 +73,41 @@ def build(force: bool = False, verbose: bool = False) -> str:
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-            # Measured twice in round 3 (a forward with scalar-base stash stores: 113 SGPR spills; a profiling build of the backward:
-            # 134): with that many scalar registers spilled, the 512-register kernels -- every register of the file in use, scalar
-            # operands in inline asm -- ran with a wrong scalar base and faulted on the GPU.  Such a build must not reach the GPU:
-            # none at all in those two files (other kernels of this library have run correctly with 16 .. 63 spilled scalar registers
-            # since round 1: the failure is specific to the 512-register kernels, so only they are guarded).
-            import re
-            spills = [int(m) for m in re.findall(r"SGPRs Spill: (\d+)", r.stderr)]
-            if f in per_file and spills and max(spills) > 0 and not os.environ.get("LUSH_ALLOW_SGPR_SPILLS"):
-                raise RuntimeError(f"{f}: the compiler spilled scalar registers ({max(spills)} in one kernel); "
-                                   "builds of this file like that are known to fault on the GPU")
+            # resource usage per kernel (informational; build_report() prints it).  Scalar spills are legal compiler behaviour;
+            # what made round 3's spilled builds fault is checked on the emitted code below (isa_check rule R1).
+            names = re.findall(r"Function Name: (\S+)", r.stderr)
+            sg = [int(m) for m in re.findall(r"SGPRs Spill: (\d+)", r.stderr)]
+            vg = [int(m) for m in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
+            sc = [int(m) for m in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+            if f in per_file and not (names and len(names) == len(sg) == len(vg) == len(sc)):
+                raise RuntimeError(f"{f}: no kernel-resource-usage remarks parsed (hipcc output format changed?)")
+            for n, a_, b_, c_ in zip(names, sg, vg, sc):
+                usage[n] = {"file": f, "sgpr_spills": a_, "vgpr_spills": b_, "scratch_bytes_per_lane": c_}
             return obj
         with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
             objs = list(ex.map(compile_one, SOURCES))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", SO_PATH + ".tmp"]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", target + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
-    os.replace(SO_PATH + ".tmp", SO_PATH)
-    return SO_PATH
+    if audit:
+        # The hazards hipcc does not pad for `asm volatile` statements, checked on what was actually emitted (DESIGN.md
+        # section 4, "Hazards"): a build in which register allocation or scheduling happened to create one never reaches a GPU.
+        from . import isa_check
+        n, found = isa_check.check_shared_object(target + ".tmp")
+        if found:
+            os.replace(target + ".tmp", target + ".rejected")
+            raise RuntimeError(f"isa_check: {len(found)} hazard(s) in the built code objects ({n} kernels; the library was left at "
+                               f"{target}.rejected, NOT installed):\n  " + "\n  ".join(found[:20]))
+    os.replace(target + ".tmp", target)
+    global LAST_BUILD_USAGE
+    LAST_BUILD_USAGE = usage
+    return target
+
+
+LAST_BUILD_USAGE = {}
 
 
 class MlpParams(C.Structure):
@@ -126,9 +157,13 @@ _SIGS = {
     "lush_align_rays": ([_p, _p, _p, _i, _p, _i, _i, _ll, _i, _i, _f, _f, _f, _f, _p, _p, _p], _i),
     "lush_consist_loss_fwd_bwd": ([_p, _p, _i, _i, _f, _p, _p, _p], _i),
     "lush_rbk_mlp_fwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p], _i),
-    "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, C.POINTER(RbkParams), _p, _i, _p], _i),
+    "lush_rbk_mlp_bwd": ([C.POINTER(RbkParams), _i, _i, _f, _p, _p, _i, C.POINTER(RbkParams), _p, _i, _p], _i),
     "lush_rbk_warp_fwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
-    "lush_rbk_warp_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p], _i),
+    "lush_rbk_warp_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p], _i),
+    "lush_rbk_warp_ndc_fwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _f, _f, _p, _p, _p, _p], _i),
+    "lush_rbk_warp_ndc_bwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _p, _p, _p, _p, _i, _p, _p], _i),
+    "lush_blur_mix_fwd": ([_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_blur_mix_bwd": ([_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p], _i),
     "lush_wsum_fwd": ([_p, _p, _i, _i, _i, _p, _p], _i),
     "lush_wsum_bwd": ([_p, _p, _i, _i, _i, _p, _p, _p, _p], _i),
     "lush_tonemap_fwd": ([_p, _p, _i, _i, _p, _p], _i),
@@ -163,9 +198,14 @@ _SIGS = {
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 6
+ABI_VERSION = 7
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
 VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 64
+# include/lush_march.h: LUSH_FAULT_*
+FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
+               128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}
+FAULT_BITS = {n: b for b, n in FAULT_NAMES.items()}
+FAULT_COARSE_SHIFT = 5
 
 
 def fault_names(word: int):

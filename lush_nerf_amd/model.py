@@ -97,6 +97,12 @@ class Rigid_Blurring_Kernel(nn.Module):
         return ops.RbkWarp.apply(rays, rays_info['images_idx'], self.num_motion, self.rv_window, grad_mask, hooks,
                                  *self.tensors())
 
+    def warp_ndc(self, rays, rays_info, H, W, focal, ndc, near, far, grad_mask=None, hooks=None):
+        """forward() followed by the ray prologue of render_train_scene / render_train_noise in one kernel (ops.RbkWarpNdc):
+        -> (ray batch [N*(M+1),11] of the warped rays, ccw [N,M+1], ray batch [N,11] of the input rays)."""
+        return ops.RbkWarpNdc.apply(rays, rays_info['images_idx'], self.num_motion, self.rv_window, grad_mask, hooks,
+                                    H, W, focal, ndc, near, far, *self.tensors())
+
     def rbk_weighted_sum(self, rgb, depth, acc, extras, ccw):
         rgb, depth, acc = ops.WSum.apply(rgb, ccw), ops.WSum.apply(depth, ccw), ops.WSum.apply(acc, ccw)
         for k, v in extras.items():
@@ -278,6 +284,20 @@ class NeRFAll(nn.Module):
         k_extract = ['rgb_map', 'depth_map', 'acc_map']
         return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
 
+    def _render_train_scene_packed(self, batch, chunk, draws=None, **kwargs):
+        """render_train_scene on an already packed ray batch [R,11] (the fused warp + NDC kernel made it)."""
+        for k in ("c2w", "ndc", "near", "far", "use_viewdirs", "c2w_staticcam", "use_awp", "allkernel", "kernelpixel", "render_noise"):
+            kwargs.pop(k, None)
+        res = self._chunks(lambda b, d: self.render_rays_nonoise(b, draws=d, **kwargs), batch, chunk, draws)
+        all_ret = self._merge(res, batch.shape[:-1])
+        k_extract = ['rgb_map', 'depth_map', 'acc_map']
+        return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
+
+    def _render_train_noise_packed(self, batch0, chunk, **kwargs):
+        """render_train_noise on an already packed ray batch [N,11]."""
+        res = self._chunks(lambda b, d: self._noise(b, kwargs['N_samples'], kwargs.get('lindisp', False)), batch0, chunk, None)
+        return torch.cat(res, 0) if len(res) > 1 else res[0]
+
     def render_train_noise(self, H, W, K, chunk, rays=None, c2w=None, ndc=True, near=0., far=1.,
                            use_viewdirs=False, c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None,
                            render_noise=True, draws=None, **kwargs):
@@ -297,14 +317,18 @@ class NeRFAll(nn.Module):
             if self.blur_kernel_net is not None and not force_baseline and self.blur_model_type == 'dpnerf':
                 kwargs['img_idx'] = rays_info['images_idx'].squeeze(-1)
                 mask = kernel_pixel if allkernel else None      # torch.where(mask, x, x.detach()) (:641-643)
-                rays_transform, ccw = self.mlp_rbk(rays, rays_info, grad_mask=mask, hooks=self.hooks)
-                rgb, depth, acc, extras = self.render_train_scene(H, W, K, chunk, rays_transform, **kwargs)
-                noise_raw = self.render_train_noise(H, W, K, chunk, rays, **kwargs)
-                rgb_noise = ops.NoiseAct.apply(noise_raw)
-                rgb_pure = ops.WSum.apply(rgb, ccw)
-                rgb0_pure = ops.WSum.apply(extras['rgb0'], ccw)
-                return (self.tonemapping(rgb_pure, noise_raw), self.tonemapping(rgb0_pure, noise_raw), {},
-                        rgb_noise, rgb_noise, self.tonemapping(rgb_pure), self.tonemapping(rgb0_pure))
+                if not kwargs.get('use_viewdirs', False):
+                    raise NotImplementedError("use_viewdirs=False is not built (every config sets it)")
+                # (:638-654) warp + ray prologue as ONE kernel, both marches, then the weighted sums, the noise colour and the
+                # five tone-mapped outputs as ONE kernel (ops.RbkWarpNdc / ops.BlurMix; the piecewise ops -- mlp_rbk(),
+                # render_train_scene / _noise, rbk_weighted_sum, tonemapping -- stay available and are tested against these)
+                batch, ccw, batch0 = self.mlp_rbk.warp_ndc(rays, rays_info, H, W, float(K[0][0]), kwargs.get('ndc', True),
+                                                            kwargs.get('near', 0.), kwargs.get('far', 1.), grad_mask=mask,
+                                                            hooks=self.hooks)
+                rgb, depth, acc, extras = self._render_train_scene_packed(batch, chunk, **kwargs)
+                noise_raw = self._render_train_noise_packed(batch0, chunk, **kwargs)
+                blur, blur0, rgb_noise, sharp, sharp0 = ops.BlurMix.apply(rgb, extras['rgb0'], ccw, noise_raw, self.gamma)
+                return blur, blur0, {}, rgb_noise, rgb_noise, sharp, sharp0
             kwargs['img_idx'] = rays_info['images_idx'].squeeze(-1)
             (rgb, depth, acc, extras), noise_raw = self.render_infer(H, W, K, chunk, rays, **kwargs)
             rgb_noise = ops.NoiseAct.apply(noise_raw)

@@ -530,6 +530,7 @@ class NoiseMlp(torch.autograd.Function):
 # ----------------------------------------------------------------------------- blur kernel
 RBK_ACT = 512
 RBK_RVW = 32
+RBK_RVW_OFFSET = 480     # include/lush_march.h LUSH_RBK_RVW_OFFSET
 
 
 class RbkWarp(torch.autograd.Function):
@@ -567,20 +568,112 @@ class RbkWarp(torch.autograd.Function):
         mask = t[3] if ctx.has_mask else None
         tensors = list(t[4 if ctx.has_mask else 3:])
         dev = rays.device
-        d_rvw = torch.zeros(num_img, RBK_RVW, dtype=torch.float32, device=dev)
+        # gradients w.r.t. r, v, w accumulate in the zero tail of the activation rows (include/lush_march.h LUSH_RBK_RVW_OFFSET):
+        # no buffer of their own, no zero-fill launch
+        d_rvw = acts.view(-1)[RBK_RVW_OFFSET:]
         drays = torch.empty_like(rays) if ctx.needs_input_grad[0] else None
         lib.call("lush_rbk_warp_bwd", lib.ptr(rays), lib.ptr(idx), N, M, lib.ptr(acts),
-                 lib.ptr(_opt(g_rays)), lib.ptr(_opt(g_ccw)), lib.ptr(mask), lib.ptr(d_rvw), lib.ptr(drays),
+                 lib.ptr(_opt(g_rays)), lib.ptr(_opt(g_ccw)), lib.ptr(mask), lib.ptr(d_rvw), RBK_ACT, lib.ptr(drays),
                  _stream())
-        sink = grad_sink(tensors, ctx.hooks)          # the trainer's flat gradient: add straight into it
-        grads = list(sink) if sink is not None else [torch.empty_like(x) for x in tensors]
-        scratch = torch.empty(num_img, RBK_ACT, dtype=torch.float32, device=dev)
-        st, gs = lib.rbk_struct(tensors), lib.rbk_struct(grads)
-        lib.call("lush_rbk_mlp_bwd", C.byref(st), num_img, M, window, lib.ptr(acts), lib.ptr(d_rvw),
-                 C.byref(gs), lib.ptr(scratch), int(sink is not None), _stream())
-        if sink is not None:
-            grads = [None] * len(grads)
+        grads = _rbk_param_grads(tensors, ctx.hooks, num_img, M, window, acts, d_rvw)
         return (drays, None, None, None, None, None, *grads)
+
+
+def _rbk_param_grads(tensors, hooks, num_img, M, window, acts, d_rvw):
+    """lush_rbk_mlp_bwd into the trainer's flat gradient (hooks.sink: returns Nones) or into fresh tensors."""
+    sink = grad_sink(tensors, hooks)
+    grads = list(sink) if sink is not None else [torch.empty_like(x) for x in tensors]
+    scratch = torch.empty(num_img, RBK_ACT, dtype=torch.float32, device=acts.device)
+    st, gs = lib.rbk_struct(tensors), lib.rbk_struct(grads)
+    lib.call("lush_rbk_mlp_bwd", C.byref(st), num_img, M, window, lib.ptr(acts), lib.ptr(d_rvw), RBK_ACT,
+             C.byref(gs), lib.ptr(scratch), int(sink is not None), _stream())
+    return [None] * len(grads) if sink is not None else grads
+
+
+def _ndc_consts(H, W, focal):
+    cx = float(torch.tensor(-1. / (W / (2. * focal)), dtype=torch.float32))
+    cy = float(torch.tensor(-1. / (H / (2. * focal)), dtype=torch.float32))
+    return cx, cy
+
+
+class RbkWarpNdc(torch.autograd.Function):
+    """RbkWarp followed by PackRays in one kernel per direction (SURVEY.md section 7.2 `rbk_warp_ndc`): View_Embedding +
+    Rigid_Blurring_Kernel.forward (models/lushnerf.py:27-35, 118-153) and the head of render_train_scene / render_train_noise
+    (:772-795, 827-850; ndc_rays helpers:542-562).  rays [N,3,2], images_idx -> ray batch [N*(M+1),11] of the warped rays,
+    ccw [N,M+1], ray batch [N,11] of the input rays (what the noise branch marches; non-differentiable: the reference
+    detaches it, :614).  The warped rays themselves never exist in memory."""
+
+    @staticmethod
+    def forward(ctx, rays, idx, num_motion, window, mask, hooks: Optional[Hooks], H, W, focal, ndc, near, far, *params):
+        rays = _f32(rays).reshape(-1, 3, 2)
+        idx = idx.reshape(-1)
+        if idx.dtype != torch.int64 or not idx.is_contiguous():
+            idx = idx.to(torch.int64).contiguous()
+        tensors = [_f32(p) for p in params]
+        N, M = rays.shape[0], int(num_motion)
+        num_img = tensors[0].shape[0]
+        dev = rays.device
+        acts = torch.empty(num_img, RBK_ACT, dtype=torch.float32, device=dev)
+        st = lib.rbk_struct(tensors)
+        lib.call("lush_rbk_mlp_fwd", C.byref(st), num_img, M, float(window), lib.ptr(acts), _stream())
+        cx, cy = _ndc_consts(H, W, focal)
+        batch = torch.empty(N * (M + 1), 11, dtype=torch.float32, device=dev)
+        ccw = torch.empty(N, M + 1, dtype=torch.float32, device=dev)
+        batch0 = torch.empty(N, 11, dtype=torch.float32, device=dev)
+        lib.call("lush_rbk_warp_ndc_fwd", lib.ptr(rays), lib.ptr(idx), N, M, lib.ptr(acts), int(bool(ndc)), cx, cy, float(near),
+                 float(far), lib.ptr(batch), lib.ptr(ccw), lib.ptr(batch0), _stream())
+        if mask is not None:
+            mask = mask.reshape(-1)
+            if mask.dtype != torch.uint8 or not mask.is_contiguous():
+                mask = mask.to(torch.uint8).contiguous()
+        ctx.save_for_backward(rays, idx, acts, *([mask] if mask is not None else []), *tensors)
+        ctx.has_mask, ctx.hooks = mask is not None, hooks
+        ctx.cfg = (N, M, num_img, float(window), int(bool(ndc)), cx, cy)
+        ctx.mark_non_differentiable(batch0)
+        return batch, ccw, batch0
+
+    @staticmethod
+    def backward(ctx, g_batch, g_ccw, _g_batch0):
+        N, M, num_img, window, ndc, cx, cy = ctx.cfg
+        t = ctx.saved_tensors
+        rays, idx, acts = t[0], t[1], t[2]
+        mask = t[3] if ctx.has_mask else None
+        tensors = list(t[4 if ctx.has_mask else 3:])
+        d_rvw = acts.view(-1)[RBK_RVW_OFFSET:]
+        drays = torch.empty_like(rays) if ctx.needs_input_grad[0] else None
+        lib.call("lush_rbk_warp_ndc_bwd", lib.ptr(rays), lib.ptr(idx), N, M, lib.ptr(acts), ndc, cx, cy, lib.ptr(_opt(g_batch)),
+                 lib.ptr(_opt(g_ccw)), lib.ptr(mask), lib.ptr(d_rvw), RBK_ACT, lib.ptr(drays), _stream())
+        grads = _rbk_param_grads(tensors, ctx.hooks, num_img, M, window, acts, d_rvw)
+        return (drays, None, None, None, None, None, None, None, None, None, None, None, *grads)
+
+
+class BlurMix(torch.autograd.Function):
+    """The tail of NeRFAll.forward's training branch in one kernel per direction (SURVEY.md section 7.2 `blur_mix_tonemap`;
+    models/lushnerf.py:644-654): rbk_weighted_sum of the fine and coarse colours (:100-116), rgb_noise = 0.1 sigmoid(noise_raw),
+    tone mapping (helpers:164-174).  rgb, rgb0 [N*(M+1),3], ccw [N,M+1], noise_raw [N,3] ->
+    (tm(rgb_pure + rgb_noise), tm(rgb0_pure + rgb_noise), rgb_noise, tm(rgb_pure), tm(rgb0_pure))."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb0, ccw, nraw, gamma):
+        rgb, rgb0, ccw, nraw = _f32(rgb), _f32(rgb0), _f32(ccw), _f32(nraw)
+        N, M1 = ccw.shape
+        out = torch.empty(5, N, 3, dtype=torch.float32, device=rgb.device)
+        lib.call("lush_blur_mix_fwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), N, M1, int(bool(gamma)),
+                 *(lib.ptr(out[i]) for i in range(5)), _stream())
+        ctx.save_for_backward(rgb, rgb0, ccw, nraw)
+        ctx.gamma = int(bool(gamma))
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], out[3], out[4]
+
+    @staticmethod
+    def backward(ctx, *g):
+        rgb, rgb0, ccw, nraw = ctx.saved_tensors
+        N, M1 = ccw.shape
+        d_rgb, d_rgb0 = torch.empty_like(rgb), torch.empty_like(rgb0)
+        d_ccw, d_nraw = torch.empty_like(ccw), torch.empty_like(nraw)
+        lib.call("lush_blur_mix_bwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), N, M1, ctx.gamma,
+                 *(lib.ptr(_opt(x)) for x in g), lib.ptr(d_rgb), lib.ptr(d_rgb0), lib.ptr(d_ccw), lib.ptr(d_nraw), _stream())
+        return d_rgb, d_rgb0, d_ccw, d_nraw, None
 
 
 class WSum(torch.autograd.Function):

@@ -21,7 +21,7 @@ for f in glob.glob(os.path.join(src, "p*", "*", "*_counter_collection.csv")):
             if k in r["Kernel_Name"]:
                 agg[name][(r["Counter_Name"], r["Dispatch_Id"])].append(float(r["Counter_Value"]))
 lines = [f"# SQ counters of the MLP kernel groups ({tag})\n",
-         "Command: `rocprofv3 --pmc <set> -- python3 tests/bench_mlp.py` with MODES=h,h WHAT=fwd,chain,weights (fine-pass shape: "
+         "Command: `rocprofv3 --pmc <set> -- python3 tools/bench_mlp.py` with MODES=h,h WHAT=fwd,chain,weights (fine-pass shape: "
          "20 480 rays x 128 samples; two separate passes of 8 SQ counters, no trace domains; `profiles/collect_sq.sh`).  "
          "Per-launch averages.\n"]
 for name, d in agg.items():

@@ -371,6 +371,88 @@ def t_mix():
     rep("noise_act", y, 0.1 * torch.sigmoid(nraw), 2e-6)
 
 
+def t_warp_ndc():
+    """ops.RbkWarpNdc (rbk_warp_ndc_fwd / _bwd_kernel: warp + NDC + view direction + pack in one kernel per direction) against
+    the oracle's rbk_forward followed by pack_rays (models/lushnerf.py:75-98, 118-153, 772-795; helpers:542-562), forward and
+    every gradient, with the allkernel mask; and against the piecewise ops it replaces (RbkWarp -> PackRays)."""
+    g = util.golden("rbk")
+    n, seed = (int(x) for x in g["meta"])
+    b = batch_of(n, seed)
+    mask = b["fq_mask"]
+    for ndc in (True, False):
+        p = util.params(seed, rbk_scale=3.0e5, requires_grad=True)
+        rays = b["rays"].clone().requires_grad_(True)
+        ref_rays, ref_ccw = O.rbk_forward(p, rays, b["images_idx"])
+        m5 = mask.bool().repeat_interleave(5)
+        masked = torch.where(m5[:, None, None], ref_rays, ref_rays.detach())
+        ref_batch = O.pack_rays(H, W, F, masked) if ndc else O.pack_rays(H, W, F, masked, ndc=False, near=2., far=6.)
+        near, far = (0., 1.) if ndc else (2., 6.)
+        tens = [gpu(t.detach()).requires_grad_(True) for t in rbk_tensors(p)]
+        rg = gpu(b["rays"]).requires_grad_(True)
+        batch, ccw, batch0 = ops.RbkWarpNdc.apply(rg, gpu(b["images_idx"]), 4, 0.1, gpu(mask), None, H, W, F, ndc, near, far, *tens)
+        tag = "ndc" if ndc else "no ndc"
+        rep(f"warp_ndc batch ({tag})", batch, ref_batch, 2e-5)
+        rep(f"warp_ndc ccw ({tag})", ccw, ref_ccw, 2e-5)
+        rep(f"warp_ndc batch0 = rows of the input rays ({tag})", batch0, batch.detach().view(n, 5, 11)[:, 0], 0.0)
+        gb = torch.from_numpy(synth.normal(tuple(ref_batch.shape), 65)) * torch.tensor([1., 1., 1., 1., 1., 1., 0., 0., 1., 1., 1.])
+        gc = torch.from_numpy(synth.normal(tuple(ref_ccw.shape), 66))
+        ((ref_batch * gb).sum() + (ref_ccw * gc).sum()).backward()
+        ((batch * gpu(gb)).sum() + (ccw * gpu(gc)).sum()).backward()
+        rep(f"warp_ndc bwd d rays ({tag})", rg.grad, rays.grad, 2e-4)
+        worst = max(util.relerr(t.grad, r.grad) for t, r in zip(tens, rbk_tensors(p)))
+        RESULTS.append((f"warp_ndc worst parameter grad ({tag})", worst, 3e-4, worst <= 3e-4))
+        print(f"{'ok  ' if worst <= 3e-4 else 'FAIL'} warp_ndc worst parameter grad ({tag}) {worst:.2e}")
+        # the piecewise ops on the same inputs: same numbers (the fused kernel runs the same device functions)
+        tens2 = [gpu(t.detach()).requires_grad_(True) for t in rbk_tensors(p)]
+        rg2 = gpu(b["rays"]).requires_grad_(True)
+        nr, cc = ops.RbkWarp.apply(rg2, gpu(b["images_idx"]), 4, 0.1, gpu(mask), None, *tens2)
+        pb = ops.PackRays.apply(nr, H, W, F, ndc, near, far)
+        rep(f"warp_ndc vs RbkWarp -> PackRays, batch ({tag})", batch, pb, 1e-6)
+        ((pb * gpu(gb)).sum() + (cc * gpu(gc)).sum()).backward()
+        rep(f"warp_ndc vs RbkWarp -> PackRays, d rays ({tag})", rg.grad, rg2.grad, 2e-5)
+        worst = max(util.relerr(t.grad, r.grad) for t, r in zip(tens, tens2))
+        RESULTS.append((f"warp_ndc vs piecewise worst parameter grad ({tag})", worst, 2e-5, worst <= 2e-5))
+        print(f"{'ok  ' if worst <= 2e-5 else 'FAIL'} warp_ndc vs piecewise worst parameter grad ({tag}) {worst:.2e}")
+
+
+def t_blur_mix():
+    """ops.BlurMix (blur_mix_fwd / _bwd_kernel) against the oracle's rbk_weighted_sum + 0.1 sigmoid + tonemap
+    (models/lushnerf.py:644-654, 100-116; helpers:164-174): the five outputs, and the gradients of a loss that uses all five."""
+    N, M = 50, 5
+    for gamma in (True, False):
+        x = torch.from_numpy(synth.uniform((N * M, 3), 0.05, 1, 71)).requires_grad_(True)
+        x0 = torch.from_numpy(synth.uniform((N * M, 3), 0.05, 1, 75)).requires_grad_(True)
+        ccw = torch.softmax(torch.from_numpy(synth.normal((N, M), 72)), -1).requires_grad_(True)
+        nraw = torch.from_numpy(synth.normal((N, 3), 73)).requires_grad_(True)
+        tm = O.tonemap if gamma else (lambda v: v)
+        pure, pure0 = O.rbk_weighted_sum(x, ccw), O.rbk_weighted_sum(x0, ccw)
+        nz = 0.1 * torch.sigmoid(nraw)
+        ref = [tm(pure + nz), tm(pure0 + nz), nz, tm(pure), tm(pure0)]
+        gs = [torch.from_numpy(synth.normal((N, 3), 80 + i)) for i in range(5)]
+        sum((r * g).sum() for r, g in zip(ref, gs)).backward()
+        xg, x0g, cg, ng = (gpu(t.detach()).requires_grad_(True) for t in (x, x0, ccw, nraw))
+        got = ops.BlurMix.apply(xg, x0g, cg, ng, gamma)
+        tag = "gamma" if gamma else "none"
+        for name, a, r in zip(("blur", "blur0", "noise", "sharp", "sharp0"), got, ref):
+            rep(f"blur_mix {name} ({tag})", a, r, 2e-6)
+        sum((a * gpu(g)).sum() for a, g in zip(got, gs)).backward()
+        rep(f"blur_mix d rgb ({tag})", xg.grad, x.grad, 2e-5)
+        rep(f"blur_mix d rgb0 ({tag})", x0g.grad, x0.grad, 2e-5)
+        rep(f"blur_mix d ccw ({tag})", cg.grad, ccw.grad, 2e-5)
+        rep(f"blur_mix d noise_raw ({tag})", ng.grad, nraw.grad, 2e-5)
+    # the trainer's case: gradients for blur and blur0 only (the others arrive as None)
+    xg, x0g, cg, ng = (gpu(t.detach()).requires_grad_(True) for t in (x, x0, ccw, nraw))
+    got = ops.BlurMix.apply(xg, x0g, cg, ng, True)
+    tgt = torch.from_numpy(synth.uniform((N, 3), 0, 1, 74))
+    x_, x0_, c_, n_ = (t.detach().clone().requires_grad_(True) for t in (x, x0, ccw, nraw))
+    nz = 0.1 * torch.sigmoid(n_)
+    O.train_loss(O.tonemap(O.rbk_weighted_sum(x_, c_) + nz), O.tonemap(O.rbk_weighted_sum(x0_, c_) + nz), tgt).backward()
+    ops.TrainLoss.apply(got[0], got[1], gpu(tgt)).backward()
+    rep("blur_mix + loss d rgb", xg.grad, x_.grad, 2e-5)
+    rep("blur_mix + loss d ccw", cg.grad, c_.grad, 2e-5)
+    rep("blur_mix + loss d noise_raw", ng.grad, n_.grad, 2e-5)
+
+
 def t_march_e2e():
     from lush_nerf_amd import model as M
     import argparse
@@ -893,7 +975,7 @@ if __name__ == "__main__":
     lib.load()
     print("device:", torch.cuda.get_device_name(0))
     only = sys.argv[1:]
-    for fn in (t_zgrid_pack, t_gen_rays, t_composite, t_sample, t_mlp_fwd, t_mlp_ragged, t_mlp_bwd, t_rbk, t_mix, t_march_e2e, t_train_e2e,
+    for fn in (t_zgrid_pack, t_gen_rays, t_composite, t_sample, t_mlp_fwd, t_mlp_ragged, t_mlp_bwd, t_rbk, t_warp_ndc, t_mix, t_blur_mix, t_march_e2e, t_train_e2e,
                t_lindisp_white, t_eval_forward, t_consistency, t_faults, t_draws, t_train_bench_regime):
         if not only or fn.__name__ in only:
             section(fn)

@@ -20,7 +20,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SECTIONS = ["t_zgrid_pack", "t_gen_rays", "t_composite", "t_sample", "t_mlp_fwd", "t_mlp_ragged", "t_mlp_bwd", "t_rbk", "t_mix",
+SECTIONS = ["t_zgrid_pack", "t_gen_rays", "t_composite", "t_sample", "t_mlp_fwd", "t_mlp_ragged", "t_mlp_bwd", "t_rbk", "t_warp_ndc", "t_mix", "t_blur_mix",
             "t_march_e2e", "t_train_e2e", "t_lindisp_white", "t_eval_forward", "t_consistency", "t_faults", "t_draws"]
 
 
@@ -874,7 +874,7 @@ def test_march_through_the_c_abi_alone(diag):
 
 # Bands of the long-trajectory test.  Over 300 steps the run is chaotic (the reference is fp32 torch on a CPU; here other
 # summation orders, fp32 atomics in another order every run, ReLU kinks, Adam's m / sqrt(v)), so every quantity is a
-# distribution.  Measured in round 3 (tests/traj_dist.py: 24 runs per kernel variant of (h,h), 12 of (2,2) and (2,h)):
+# distribution.  Measured in round 3 (tools/traj_dist.py: 24 runs per kernel variant of (h,h), 12 of (2,2) and (2,h)):
 #   cosine of the fine rgb head's 300-step update with the reference's: (h,h) mean 0.972 .. 0.976, sd 0.009 .. 0.016, min
 #     0.937 -- the SAME for the round-2 and the round-3 kernels (the four forward x backward combinations differ by less than
 #     their standard errors); (2,2) 0.982 (sd 0.008, min 0.957); (2,h) 0.983 (min 0.974)

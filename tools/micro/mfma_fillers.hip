@@ -1,6 +1,6 @@
 // Developer micro-benchmark (needs a GPU): which filler instructions hide behind v_mfma_f32_32x32x16_f16 when ONE wave per
 // SIMD issues them between its MFMAs?  Prints cycles per MFMA for K fillers of each kind per MFMA gap.
-//   hipcc --offload-arch=gfx950 -O3 tests/micro/mfma_fillers.hip -o ab/mfma_fillers && ./ab/mfma_fillers
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_fillers.hip -o ab/mfma_fillers && ./ab/mfma_fillers
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,5 +1,5 @@
 // Developer micro-test (needs a GPU): accuracy of a v_sin_f32 / v_cos_f32 based positional encoding against float64.
-//   hipcc --offload-arch=gfx950 -O3 tests/micro/sincos_hw.hip -o ab/sincos_hw && ./ab/sincos_hw
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/sincos_hw.hip -o ab/sincos_hw && ./ab/sincos_hw
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from lush_nerf_amd import lib, ops, synth
+if os.environ.get("LUSH_SO"):        # developer tool: a variant built by tools/build_variant.py
+    lib.use_library(os.environ["LUSH_SO"])
 from oracle import lush_oracle as O
 dev = torch.device("cuda:0")
 R, S = 20480, 128

@@ -5,7 +5,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/ph_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-MODES="h,h" WHAT=weights REPS=3 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tests/bench_mlp.py > $OUT/log 2>&1
+MODES="h,h" WHAT=weights REPS=3 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/bench_mlp.py > $OUT/log 2>&1
 python3 - <<PY
 import csv,glob
 f=sorted(glob.glob("$OUT/*/*_kernel_stats.csv"))[-1]

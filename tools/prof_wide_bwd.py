@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (needs a GPU and a -DLUSH_PROF build named by LUSH_SO): cycle budget of mlp_wide_bwd_kernel, block 0 / wave 0.
 Since the kernels grew in round 3 the 16 cycle counters no longer fit their scalar registers: the compiler spills SGPRs, such a build
-faulted on the GPU, and lib.build() refuses it (LUSH_ALLOW_SGPR_SPILLS=1 overrides: at your own risk, under `timeout`).  The figures
+faulted on the GPU, and lib.build()'s ISA audit refuses it (isa_check rule R1: spill reload directly in front of an asm VMEM with a scalar base).  The figures
 in DESIGN.md section 4 come from earlier builds of the forward in which the counters fitted; ablation builds (-DLUSH_ABL_*) are
 the tool that still works."""
 import os, sys, ctypes as C
@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from lush_nerf_amd import lib, ops, synth
+if os.environ.get("LUSH_SO"):        # developer tool: a variant built by tools/build_variant.py
+    lib.use_library(os.environ["LUSH_SO"])
 from oracle import lush_oracle as O       # (ray packing of the synthetic batch only)
 
 dev = torch.device("cuda:0")
