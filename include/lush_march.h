@@ -37,8 +37,8 @@ int lush_abi_version(void);   /* 7 (round 3: explicit kernel-variant argument in
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
  * rays [R][11] = [o(3) d(3) near far viewdir(3)]; t_rand [R][S] or NULL
  * (perturb == 0); z [R][S]. */
-int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z,
-               lush_stream_t stream);
+int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, float* zero4,
+               lush_stream_t stream);      /* zero4: NULL, or 4 floats this launch also zeroes (lush_composite_bwd's scale4) */
 /* z of sample `index` of the un-jittered grid (the noise MLP's point,
  * models/lushnerf.py:271, 396, 612): z [R]. */
 int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* z, lush_stream_t stream);
@@ -68,11 +68,18 @@ int lush_composite_fwd(const float* raw, const float* z, const float* rays, int 
                        float* rgb, float* depth, float* acc, float* weights, float* density,
                        int* flags, int flag_shift, lush_stream_t stream);
 /* Backward of the above w.r.t. raw and rays_d.  g_* may be NULL (= 0).
- * draw [R][S][4] overwritten; drays [R][11] accumulate (columns 3..5). */
+ * draw [R][S][4] overwritten; drays [R][11]: columns 3..5 accumulate, or -- init_drays != 0 -- the whole row is written
+ * (zeros elsewhere: the first pass of a march needs no zero-fill of its own).
+ * Folded in so that they cost no launch of their own (any of them may be NULL / 0):
+ *   scale4   {scale, 1/scale, 2 work words} of the loss-scaled fp16 gradient chain: scale = the power of two that puts
+ *            max |d_raw| into [8, 16) (1 when d_raw is all zero or not finite).  The work words must be ZERO on entry
+ *            (lush_zgrid's zero4, or a memset) and are left zero.
+ *   zero_buf / zero_n: floats zeroed by this launch (the scratch a later launch accumulates into). */
 int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S,
                        const float* noise, float noise_std, float near_mask, int white_bkgd,
                        const float* g_rgb, const float* g_depth, const float* g_acc,
-                       float* draw, float* drays, lush_stream_t stream);
+                       float* draw, float* drays, float* scale4, float* zero_buf, long long zero_n, int init_drays,
+                       lush_stream_t stream);
 
 /* ------------------------------------------------------ hierarchical sampling
  * sample_pdf (utils/run_lushnerf_helpers.py:566-609) on bins = mid-points and
@@ -202,20 +209,22 @@ int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_s
 /* The tail of NeRFAll.forward's training branch in ONE kernel per direction (SURVEY.md section 7.2 `blur_mix_tonemap`;
  * models/lushnerf.py:644-654, 100-116; utils/run_lushnerf_helpers.py:164-174): with s = sum_m ccw[n][m] rgb[n*M1+m],
  * s0 the same on rgb0 and nz = 0.1 sigmoid(nraw):  blur = tm(s + nz), blur0 = tm(s0 + nz), noise = nz, sharp = tm(s),
- * sharp0 = tm(s0); tm = x ** (1/2.2) when gamma, else identity.  rgb, rgb0 [N*M1][3]; ccw [N][M1]; nraw [N][3]; outputs [N][3]. */
-int lush_blur_mix_fwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
-                      float* blur, float* blur0, float* noise, float* sharp, float* sharp0, lush_stream_t stream);
-/* g_* [N][3]: gradients of the five outputs, any of them NULL (= 0).  d_rgb, d_rgb0 [N*M1][3], d_ccw [N][M1], d_nraw [N][3]:
- * every element written. */
-int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+ * sharp0 = tm(s0); tm = x ** (1/2.2) when gamma, else identity.  rgb, rgb0 [N*M1][3]; ccw [N][M1]; nraw [N][>=3] with row
+ * stride nraw_ld floats (3, or 4 for the noise MLP's raw output read in place); outputs [N][3]. */
+int lush_blur_mix_fwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int nraw_ld, int N, int M1,
+                      int gamma, float* blur, float* blur0, float* noise, float* sharp, float* sharp0, lush_stream_t stream);
+/* g_* [N][3]: gradients of the five outputs, any of them NULL (= 0).  d_rgb, d_rgb0 [N*M1][3], d_ccw [N][M1], d_nraw [N][4]
+ * (column 3 = 0: the row is the noise MLP's d_raw as lush_mlp_bwd takes it): every element written. */
+int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int nraw_ld, int N, int M1, int gamma,
                       const float* g_blur, const float* g_blur0, const float* g_noise, const float* g_sharp,
                       const float* g_sharp0, float* d_rgb, float* d_rgb0, float* d_ccw, float* d_nraw, lush_stream_t stream);
 /* Training loss of run_lushnerf.py:652-661: sum over the two colours of
  * 0.5*MSE + 0.5*L1 against target [n][3], times `scale` (the share of a micro-batch in the step's
- * mean; 1 for the plain loss).  loss[0] accumulate (zero it first); ga / gb = d loss / d a, d loss / d b
- * (overwritten). */
+ * mean; 1 for the plain loss).  ga / gb = d loss / d a, d loss / d b (overwritten).
+ * work == NULL: loss[0] accumulates (zero it first).  work != NULL: 2 floats of caller-owned scratch, ZERO before the first
+ * call and left zero by every call; loss[0] is then WRITTEN (no zero-fill launch per call). */
 int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float scale, float* loss,
-                      float* ga, float* gb, lush_stream_t stream);
+                      float* ga, float* gb, float* work, lush_stream_t stream);
 
 /* ----------------------------------------------------------------- random draws
  * The four draws of one march in the reference's shapes -- torch.rand [R][Ns] (models/lushnerf.py:515),
@@ -340,7 +349,9 @@ int lush_march_view(const lush_march_cfg* cfg, int which, size_t* offset, size_t
 int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,
                    const lush_march_draws* draws, const lush_march_out* out, void* workspace, int* flags, lush_stream_t stream);
 /* Parameter gradients are ADDED to g_coarse / g_fine (fp32 atomics; same_net: everything goes to g_coarse);
- * drays [R][11] accumulates d loss / d ray batch (columns 0..5, 8..10); z_samples are detached as in the reference (:546). */
+ * drays [R][11] = d loss / d ray batch (columns 0..5, 8..10; 6, 7 zero), WRITTEN by the first pass that runs (ABI 7: the caller
+ * no longer zero-fills it; when no output gradient is given at all nothing runs and drays is left untouched); z_samples are
+ * detached as in the reference (:546).  The passes run one after the other on `stream`: nothing else is created or used. */
 int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,
                    const lush_march_draws* draws, const lush_march_gout* gout, void* workspace, const lush_mlp_grads* g_coarse,
                    const lush_mlp_grads* g_fine, float* drays, lush_stream_t stream);

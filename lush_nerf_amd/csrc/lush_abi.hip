@@ -383,10 +383,12 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
 }
 
+// prepared != 0: the caller's lush_composite_bwd already computed the loss scale into the dstash header and zeroed the
+// feature-factor scratch behind it (lush_march_bwd: no memset, no grad_scale launch here).
 static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                         const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
                         void* dstash, const lush_mlp_grads* g, float* dpts, int variant, lush_stream_t stream, int do_chain,
-                        int do_weights) {
+                        int do_weights, int prepared = 0) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
     const bool x_f16 = planes_f == PLANES_F16;     // the stash was written by the fp16 forward
@@ -423,7 +425,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.dpts = dpts;
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
-    if (do_chain && z_f16) {
+    if (do_chain && z_f16 && !prepared) {
         if (!draw) return set_error("lush_mlp_bwd: draw is required");
         LUSH_HIP(hipMemsetAsync(gscale, 0, 16, st));
         rc = launch_grad_scale(draw, P * 4, gscale, st);
@@ -501,7 +503,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         float* facS = facG + (size_t)grow * n.HW;            // [grow]
         float* facH = facS + grow;                           // [DZV_EXT][HV]
         float* facSH = facH + (size_t)DZV_EXT * n.HV;        // [DZV_EXT]
-        LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(grow * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4, st));
+        if (!prepared) LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(grow * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4, st));
         {
             DwJob& j = job(a.dzv, ldzv, fold && alpha ? grow : n.HV, H(n.NL - 1), n.HW, 0, n.HW, facG, n.HW, 0, facS);
             with_pe(j, PE_X, DV, g->w_views, n.HW + DV, n.HW);
@@ -569,3 +571,32 @@ int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, cons
 }
 
 }  // extern "C"
+
+// ---- for lush_march_bwd (lush_march_abi.hip), whose compositing backward has already prepared the dstash header ----
+namespace lush {
+int mlp_bwd_chain_prepared(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                           const void* packed_b, const void* prm, const float* draw, const void* stash,
+                           void* dstash, float* dpts, int variant, void* stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, (const lush_mlp_params*)prm, draw, stash, dstash, nullptr, dpts,
+                        variant, (lush_stream_t)stream, 1, 0, 1);
+}
+int mlp_bwd_weights_prepared(int net, int planes_f, int planes_b, int R, int S, const void* prm, const float* draw,
+                             const void* stash, void* dstash, const void* g, int variant, void* stream) {
+    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, (const lush_mlp_params*)prm, draw, stash, dstash,
+                        (const lush_mlp_grads*)g, nullptr, variant, (lush_stream_t)stream, 0, 1, 1);
+}
+// where the header of a dstash holds {scale, 1/scale, work, work} and the scratch the weight-gradient launch accumulates into
+bool mlp_dstash_header(int net, int planes_b, long long P, void* dstash, float** scale4, float** zero_buf, long long* zero_n) {
+    NetInfo n;
+    if (!net_info(net, n) || !dstash) return false;
+    const int ns = planes_b == PLANES_F16 ? 1 : planes_b;
+    const DStashLayout D = dstash_layout(n, ns, P);
+    char* db = (char*)dstash;
+    *scale4 = planes_b == PLANES_F16 ? (float*)(db + D.scale) : nullptr;
+    const bool fac = ns <= 2;
+    *zero_buf = fac ? (float*)(db + D.fac) : nullptr;
+    *zero_n = fac ? (long long)((n.HV + DZV_EXT) * (n.HW + 1) + DZV_EXT * (n.HV + 1)) : 0;
+    return true;
+}
+}  // namespace lush
+

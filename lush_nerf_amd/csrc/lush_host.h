@@ -42,6 +42,16 @@ inline int kernel_lds_once(KernelOnce& once, int dev, const void* kernel, size_t
     return 0;
 }
 
+// lush_abi.hip: the halves of lush_mlp_bwd for a caller whose lush_composite_bwd prepared the dstash header (lush_march_bwd)
+// (prm / g are const lush_mlp_params* / const lush_mlp_grads*, stream a hipStream_t: passed untyped so that this header does not
+// depend on include/lush_march.h)
+int mlp_bwd_chain_prepared(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                           const void* packed_b, const void* prm, const float* draw, const void* stash,
+                           void* dstash, float* dpts, int variant, void* stream);
+int mlp_bwd_weights_prepared(int net, int planes_f, int planes_b, int R, int S, const void* prm, const float* draw,
+                             const void* stash, void* dstash, const void* g, int variant, void* stream);
+bool mlp_dstash_header(int net, int planes_b, long long P, void* dstash, float** scale4, float** zero_buf, long long* zero_n);
+
 // lush_mlp.hip
 size_t mlp_fwd_lds_bytes(int hw, int ns, int mt);
 size_t mlp_bwd_lds_bytes(int hw, int ns, int mt, int nthreads);

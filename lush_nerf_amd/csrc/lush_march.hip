@@ -38,8 +38,9 @@ __device__ __forceinline__ float zgrid_at(float near, float far, int i, int S, i
 
 // --------------------------------------------------------------------- z grid
 __global__ void zgrid_kernel(const float* __restrict__ rays, int R, int S, int lindisp,
-                             const float* __restrict__ t_rand, float* __restrict__ z) {
+                             const float* __restrict__ t_rand, float* __restrict__ z, float* __restrict__ zero4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero4 != nullptr && i < 4) zero4[i] = 0.f;      // (the backward's loss-scale words: armed by the march's first kernel)
     if (i >= (long long)R * S) return;
     const int ray = (int)(i / S), s = (int)(i % S);
     const float near = rays[ray * 11 + 6], far = rays[ray * 11 + 7];
@@ -164,13 +165,22 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_fwd_kernel(Comp
     }
 }
 
+// What the backward of a pass needs besides d_raw, folded into this kernel so that it costs no launch of its own (round 4):
+//   scale4   the fp16 gradient chain's loss scale {scale, 1/scale, work, work} from max |d_raw| (grad_scale_kernel's job; the two
+//            work words must be zero on entry and are left zero), or NULL;
+//   zero_buf a scratch the weight-gradient launch accumulates into (the feature-factor block), zeroed here, or NULL;
+//   init_drays: drays is written whole (zeros outside columns 3..5) instead of added to -- the first pass of a march.
+struct CompBwdExtra { float* scale4; float* zero_buf; long long zero_n; int init_drays; };
+
 template <int SPL>
 __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(CompIn c, const float* __restrict__ g_rgb,
         const float* __restrict__ g_depth, const float* __restrict__ g_acc, float* __restrict__ draw,
-        float* __restrict__ drays) {
+        float* __restrict__ drays, CompBwdExtra X) {
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-    if (ray >= c.R) return;
+    if (X.zero_buf != nullptr)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < X.zero_n; i += (long long)gridDim.x * blockDim.x) X.zero_buf[i] = 0.f;
+    float vmax = 0.f;
+  for (int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); ray < c.R; ray += gridDim.x * RAYS_PER_BLOCK) {
     float alpha[SPL], dist[SPL], dens[SPL], gate[SPL], zz[SPL], col[SPL][3], T[SPL], norm;
     comp_load<SPL>(c, ray, lane, alpha, dist, dens, gate, zz, col, norm);
     comp_trans<SPL>(alpha, lane, T);
@@ -219,12 +229,48 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(Comp
                 dnorm += ddist * (dist[e] / (norm > 0.f ? norm : 1.f));
             }
             *reinterpret_cast<float4*>(draw + ((long long)ray * c.S + j) * 4) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
         sfx = G[e] * alpha[e] + (1.f - alpha[e]) * sfx;     // becomes S_{j-1}
     }
     dnorm = wave_sum(dnorm);
-    if (lane < 3 && drays != nullptr && norm > 0.f)
-        drays[(long long)ray * 11 + 3 + lane] += dnorm * c.rays[(long long)ray * 11 + 3 + lane] / norm;   // (the passes of a march run one after the other on one stream)
+    if (drays != nullptr) {     // (the passes of a march run one after the other on one stream)
+        if (X.init_drays) {
+            if (lane < 11) drays[(long long)ray * 11 + lane] = (lane >= 3 && lane < 6 && norm > 0.f) ? dnorm * c.rays[(long long)ray * 11 + lane] / norm : 0.f;
+        } else if (lane < 3 && norm > 0.f) {
+            drays[(long long)ray * 11 + 3 + lane] += dnorm * c.rays[(long long)ray * 11 + 3 + lane] / norm;
+        }
+    }
+  }
+    if (X.scale4 != nullptr) {      // grad_scale_kernel's reduction: the last block to finish writes {scale, 1/scale} and re-arms
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        __shared__ float sm[RAYS_PER_BLOCK];
+        if (lane == 0) sm[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* work = reinterpret_cast<unsigned*>(X.scale4 + 2);
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < RAYS_PER_BLOCK; ++i) m = fmaxf(m, sm[i]);
+            if (!(m <= 3.402823466e38f)) m = 3.402823466e38f * 2.f;      // NaN / Inf: propagate as "not finite"
+            atomicMax(work, __float_as_uint(m));
+            __threadfence();
+            if (atomicAdd(work + 1, 1u) == gridDim.x - 1) {
+                const float mx = __uint_as_float(atomicMax(work, 0u));
+                float sc = 1.f;
+                if (mx > 0.f && mx < 3.0e38f) {
+                    int e;
+                    frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+                    sc = ldexpf(1.f, 4 - e);        // mx * sc in [8, 16)
+                }
+                X.scale4[0] = sc;
+                X.scale4[1] = 1.f / sc;
+                work[0] = 0u;
+                work[1] = 0u;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------ hierarchical sampling
@@ -1058,7 +1104,7 @@ __global__ void noise_act_bwd_kernel(const float* __restrict__ x, int n, const f
 __device__ __forceinline__ float tm_apply(float v, int gamma) { return gamma ? powf(v, INV_GAMMA) : v; }
 __device__ __forceinline__ float tm_slope(float v, int gamma) { return gamma ? INV_GAMMA * powf(v, INV_GAMMA - 1.f) : 1.f; }
 __global__ void blur_mix_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0, const float* __restrict__ ccw,
-                                    const float* __restrict__ nraw, int N, int M1, int gamma, float* __restrict__ blur,
+                                    const float* __restrict__ nraw, int nraw_ld, int N, int M1, int gamma, float* __restrict__ blur,
                                     float* __restrict__ blur0, float* __restrict__ noise, float* __restrict__ sharp,
                                     float* __restrict__ sharp0) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1071,7 +1117,7 @@ __global__ void blur_mix_fwd_kernel(const float* __restrict__ rgb, const float* 
         s += rgb[(n * M1 + m) * 3 + c] * w;
         s0 += rgb0[(n * M1 + m) * 3 + c] * w;
     }
-    const float nz = 0.1f * (1.f / (1.f + expf(-nraw[t])));
+    const float nz = 0.1f * (1.f / (1.f + expf(-nraw[n * nraw_ld + c])));
     blur[t] = tm_apply(s + nz, gamma);
     blur0[t] = tm_apply(s0 + nz, gamma);
     noise[t] = nz;
@@ -1079,9 +1125,10 @@ __global__ void blur_mix_fwd_kernel(const float* __restrict__ rgb, const float* 
     sharp0[t] = tm_apply(s0, gamma);
 }
 // Reverse: one thread per (input ray, motion slot).  Any of the five output gradients may be NULL (= 0).  d_rgb / d_rgb0
-// [N*M1][3], d_ccw [N][M1], d_nraw [N][3] overwritten (d_nraw by the slot-0 thread).
+// [N*M1][3], d_ccw [N][M1], d_nraw [N][4] overwritten (d_nraw by the slot-0 thread; column 3 = 0: the row is the noise MLP's
+// d_raw as it stands).
 __global__ void blur_mix_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0, const float* __restrict__ ccw,
-                                    const float* __restrict__ nraw, int N, int M1, int gamma, const float* __restrict__ g_blur,
+                                    const float* __restrict__ nraw, int nraw_ld, int N, int M1, int gamma, const float* __restrict__ g_blur,
                                     const float* __restrict__ g_blur0, const float* __restrict__ g_noise,
                                     const float* __restrict__ g_sharp, const float* __restrict__ g_sharp0,
                                     float* __restrict__ d_rgb, float* __restrict__ d_rgb0, float* __restrict__ d_ccw,
@@ -1100,7 +1147,7 @@ __global__ void blur_mix_bwd_kernel(const float* __restrict__ rgb, const float* 
             s += rgb[(n * M1 + m) * 3 + c] * wm;
             s0 += rgb0[(n * M1 + m) * 3 + c] * wm;
         }
-        const float sg = 1.f / (1.f + expf(-nraw[n * 3 + c]));
+        const float sg = 1.f / (1.f + expf(-nraw[n * nraw_ld + c]));
         const float nz = 0.1f * sg;
         const float gb = g_blur ? g_blur[n * 3 + c] * tm_slope(s + nz, gamma) : 0.f;
         const float gb0 = g_blur0 ? g_blur0[n * 3 + c] * tm_slope(s0 + nz, gamma) : 0.f;
@@ -1109,13 +1156,17 @@ __global__ void blur_mix_bwd_kernel(const float* __restrict__ rgb, const float* 
         d_rgb[t * 3 + c] = gs * w;
         d_rgb0[t * 3 + c] = gs0 * w;
         dw += gs * rgb[t * 3 + c] + gs0 * rgb0[t * 3 + c];
-        if (slot == 0) d_nraw[n * 3 + c] = (gb + gb0 + (g_noise ? g_noise[n * 3 + c] : 0.f)) * 0.1f * sg * (1.f - sg);
+        if (slot == 0) d_nraw[n * 4 + c] = (gb + gb0 + (g_noise ? g_noise[n * 3 + c] : 0.f)) * 0.1f * sg * (1.f - sg);
     }
+    if (slot == 0) d_nraw[n * 4 + 3] = 0.f;
     d_ccw[t] = dw;
 }
 
+// work == NULL: loss[0] is added to (the caller zeroed it).  work != NULL ({running sum, finished workgroups}, both zero on
+// entry and left zero): loss[0] is WRITTEN by the last workgroup to finish -- no zero-fill launch in front (ABI 7).
 __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ tg,
-                            int n3, float scale, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
+                            int n3, float scale, float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb,
+                            float* __restrict__ work) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0.f;
     if (t < n3) {
@@ -1126,7 +1177,21 @@ __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict
         gb[t] = (db + 0.5f * (db > 0.f ? 1.f : (db < 0.f ? -1.f : 0.f))) * inv;
     }
     l = wave_sum(l);
-    if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+    if (work == nullptr) {
+        if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(loss, l);
+        return;
+    }
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(work, part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        if (atomicAdd(reinterpret_cast<unsigned*>(work) + 1, 1u) == gridDim.x - 1) {
+            loss[0] = atomicExch(work, 0.f);
+            reinterpret_cast<unsigned*>(work)[1] = 0u;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ random draws
@@ -1290,9 +1355,9 @@ extern "C" {
 const char* lush_last_error(void) { return g_err.c_str(); }
 int lush_abi_version(void) { return 7; }
 
-int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
+int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, float* zero4, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
-    hipLaunchKernelGGL(zgrid_kernel, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, S_(st), rays, R, S, lindisp, t_rand, z);
+    hipLaunchKernelGGL(zgrid_kernel, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, S_(st), rays, R, S, lindisp, t_rand, z, zero4);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1318,13 +1383,19 @@ int lush_composite_fwd(const float* raw, const float* z, const float* rays, int 
 }
 int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S, const float* noise,
                        float noise_std, float near_mask, int white_bkgd, const float* g_rgb, const float* g_depth,
-                       const float* g_acc, float* draw, float* drays, lush_stream_t st) {
+                       const float* g_acc, float* draw, float* drays, float* scale4, float* zero_buf, long long zero_n,
+                       int init_drays, lush_stream_t st) {
     if (S < 2 || S > 256) return set_error("lush_composite_bwd: S must be in [2,256]");
+    if (zero_buf != nullptr && zero_n < 0) return set_error("lush_composite_bwd: zero_n must not be negative");
     CompIn c{raw, z, rays, noise, R, S, noise_std, near_mask, white_bkgd};
-    dim3 g(cdiv(R, RAYS_PER_BLOCK)), b(RAYS_PER_BLOCK * 64);
-    if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays);
-    else if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays);
-    else hipLaunchKernelGGL(composite_bwd_kernel<4>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays);
+    const CompBwdExtra x{scale4, zero_buf, zero_buf ? zero_n : 0, init_drays};
+    // at most 1024 workgroups walk the rays: the loss-scale reduction ends in one atomic per workgroup on one word
+    int blocks = cdiv(R, RAYS_PER_BLOCK);
+    if (blocks > 1024) blocks = 1024;
+    dim3 g(blocks), b(RAYS_PER_BLOCK * 64);
+    if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
+    else if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
+    else hipLaunchKernelGGL(composite_bwd_kernel<4>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1448,21 +1519,21 @@ int lush_rbk_warp_ndc_bwd(const float* rays, const int64_t* idx, int N, int M, c
     CHECK_LAUNCH();
     return 0;
 }
-int lush_blur_mix_fwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+int lush_blur_mix_fwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int nraw_ld, int N, int M1, int gamma,
                       float* blur, float* blur0, float* noise, float* sharp, float* sharp0, lush_stream_t st) {
-    if (N < 1 || M1 < 1) return set_error("lush_blur_mix_fwd: empty");
+    if (N < 1 || M1 < 1 || nraw_ld < 3) return set_error("lush_blur_mix_fwd: empty, or a row stride below 3");
     if (!rgb || !rgb0 || !ccw || !nraw || !blur || !blur0 || !noise || !sharp || !sharp0) return set_error("lush_blur_mix_fwd: every pointer is required");
-    hipLaunchKernelGGL(blur_mix_fwd_kernel, dim3(cdiv(3LL * N, 256)), dim3(256), 0, S_(st), rgb, rgb0, ccw, nraw, N, M1, gamma, blur, blur0,
+    hipLaunchKernelGGL(blur_mix_fwd_kernel, dim3(cdiv(3LL * N, 256)), dim3(256), 0, S_(st), rgb, rgb0, ccw, nraw, nraw_ld, N, M1, gamma, blur, blur0,
                        noise, sharp, sharp0);
     CHECK_LAUNCH();
     return 0;
 }
-int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int N, int M1, int gamma,
+int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, const float* nraw, int nraw_ld, int N, int M1, int gamma,
                       const float* g_blur, const float* g_blur0, const float* g_noise, const float* g_sharp, const float* g_sharp0,
                       float* d_rgb, float* d_rgb0, float* d_ccw, float* d_nraw, lush_stream_t st) {
-    if (N < 1 || M1 < 1) return set_error("lush_blur_mix_bwd: empty");
+    if (N < 1 || M1 < 1 || nraw_ld < 3) return set_error("lush_blur_mix_bwd: empty, or a row stride below 3");
     if (!rgb || !rgb0 || !ccw || !nraw || !d_rgb || !d_rgb0 || !d_ccw || !d_nraw) return set_error("lush_blur_mix_bwd: inputs and the four gradient outputs are required");
-    hipLaunchKernelGGL(blur_mix_bwd_kernel, dim3(cdiv((long long)N * M1, 256)), dim3(256), 0, S_(st), rgb, rgb0, ccw, nraw, N, M1, gamma,
+    hipLaunchKernelGGL(blur_mix_bwd_kernel, dim3(cdiv((long long)N * M1, 256)), dim3(256), 0, S_(st), rgb, rgb0, ccw, nraw, nraw_ld, N, M1, gamma,
                        g_blur, g_blur0, g_noise, g_sharp, g_sharp0, d_rgb, d_rgb0, d_ccw, d_nraw);
     CHECK_LAUNCH();
     return 0;
@@ -1501,8 +1572,8 @@ int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_s
     return 0;
 }
 int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float scale, float* loss, float* ga,
-                      float* gb, lush_stream_t st) {
-    hipLaunchKernelGGL(loss_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), a, b, target, 3 * n, scale, loss, ga, gb);
+                      float* gb, float* work, lush_stream_t st) {
+    hipLaunchKernelGGL(loss_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), a, b, target, 3 * n, scale, loss, ga, gb, work);
     CHECK_LAUNCH();
     return 0;
 }

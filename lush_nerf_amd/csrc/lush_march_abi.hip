@@ -102,7 +102,11 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     const float* u = draws && cfg->perturb > 0.f ? draws->u : nullptr;
     const float* noise_f = draws && cfg->raw_noise_std > 0.f ? draws->noise_f : nullptr;
     float* zc = (float*)(w + L.zc);
-    int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, st);
+    // (the backward's loss-scale work words -- head of the shared backward scratch -- are zeroed by this first kernel of the march)
+    float *scale4 = nullptr, *zero_buf = nullptr;
+    long long zero_n = 0;
+    if (cfg->planes_bwd) mlp_dstash_header(0, cfg->planes_bwd, (long long)R * (two ? Sf : S), w + L.dstash, &scale4, &zero_buf, &zero_n);
+    int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, scale4, st);
     if (rc) return rc;
     rc = lush_mlp_pack_for(0, pf, coarse, w + L.pkc, cfg->variant, st);
     if (rc) return rc;
@@ -146,25 +150,32 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     // stream out of one backward scratch.  (Round 3 ran the fine pass's weight gradients on a second stream beside the coarse
     // chain, each on part of the chip: both kernels slowed down side by side -- HBM and power are shared -- and the step
     // gained 0.4 ms on one box and lost 0.3 on two others, the driver's among them; removed in round 4)
+    bool first_pass = true;
     struct Scratch { float* draw; char* dstash; float* dpts; };
     const Scratch x{(float*)(w + L.draw), w + L.dstash, (float*)(w + L.dpts)};
     auto chain = [&](const lush_mlp_params* prm, size_t zoff, size_t rawoff, size_t stashoff, size_t pkoff, size_t pkboff, bool repack,
                      int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc) -> int {
         const float* z = (const float*)(w + zoff);
+        // the compositing backward also finds the fp16 chain's loss scale, zeroes the weight-gradient scratch and, in the
+        // march's first pass, writes d(ray) whole: no grad_scale launch, no memsets, no zero-fill of drays by the caller
+        float *scale4 = nullptr, *zero_buf = nullptr;
+        long long zero_n = 0;
+        if (!mlp_dstash_header(0, pb, (long long)R * Sp, x.dstash, &scale4, &zero_buf, &zero_n)) return set_error("lush_march_bwd: bad backward plane code");
         int rc = lush_composite_bwd((const float*)(w + rawoff), z, rays, R, Sp, noise, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
-                                    g_rgb, g_depth, g_acc, x.draw, drays, st);
+                                    g_rgb, g_depth, g_acc, x.draw, drays, scale4, zero_buf, zero_n, first_pass ? 1 : 0, st);
+        first_pass = false;
         if (rc) return rc;
         if (repack) {       // the backward computes with another plane code than the forward: its own fragments
             rc = lush_mlp_pack_for(0, pb, prm, w + pkboff, cfg->variant, st);
             if (rc) return rc;
         }
-        rc = lush_mlp_bwd_chain(0, sc, pb, rays, z, R, Sp, w + (pb == pf ? pkoff : pkboff), prm, x.draw, w + stashoff, x.dstash, x.dpts,
-                                var, st);
+        rc = mlp_bwd_chain_prepared(0, sc, pb, rays, z, R, Sp, w + (pb == pf ? pkoff : pkboff), prm, x.draw, w + stashoff, x.dstash, x.dpts,
+                                    var, st);
         if (rc) return rc;
         return lush_ray_grad_reduce(x.dpts, z, R, Sp, drays, st);
     };
     auto weights = [&](const lush_mlp_params* prm, const lush_mlp_grads* gr, size_t stashoff, int Sp) -> int {
-        return lush_mlp_bwd_weights(0, sc, pb, R, Sp, prm, x.draw, w + stashoff, x.dstash, gr, var, st);
+        return mlp_bwd_weights_prepared(0, sc, pb, R, Sp, prm, x.draw, w + stashoff, x.dstash, gr, var, st);
     };
     const bool any_main = g->rgb || g->depth || g->acc;
     const bool any_c = two ? (g->rgb0 || g->depth0 || g->acc0) : any_main;

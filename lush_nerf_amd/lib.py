@@ -145,10 +145,10 @@ VIEW_Z, VIEW_RAW, VIEW_WEIGHTS, VIEW_Z_COARSE, VIEW_STASH_COARSE, VIEW_STASH_FIN
 _p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 _SIGS = {
     "lush_abi_version": ([], _i),
-    "lush_zgrid": ([_p, _i, _i, _i, _p, _p, _p], _i),
+    "lush_zgrid": ([_p, _i, _i, _i, _p, _p, _p, _p], _i),
     "lush_zfixed": ([_p, _i, _i, _i, _i, _p, _p], _i),
     "lush_composite_fwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _p], _i),
-    "lush_composite_bwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_composite_bwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p], _i),
     "lush_sample_merge": ([_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
     "lush_pack_rays_fwd": ([_p, _i, _i, _f, _f, _f, _f, _p, _p], _i),
     "lush_pack_rays_bwd": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),
@@ -162,15 +162,15 @@ _SIGS = {
     "lush_rbk_warp_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p], _i),
     "lush_rbk_warp_ndc_fwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _f, _f, _p, _p, _p, _p], _i),
     "lush_rbk_warp_ndc_bwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _p, _p, _p, _p, _i, _p, _p], _i),
-    "lush_blur_mix_fwd": ([_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
-    "lush_blur_mix_bwd": ([_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p], _i),
+    "lush_blur_mix_fwd": ([_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_blur_mix_bwd": ([_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p], _i),
     "lush_wsum_fwd": ([_p, _p, _i, _i, _i, _p, _p], _i),
     "lush_wsum_bwd": ([_p, _p, _i, _i, _i, _p, _p, _p, _p], _i),
     "lush_tonemap_fwd": ([_p, _p, _i, _i, _p, _p], _i),
     "lush_tonemap_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
     "lush_noise_act_fwd": ([_p, _i, _p, _p], _i),
     "lush_noise_act_bwd": ([_p, _i, _p, _p, _p], _i),
-    "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _f, _p, _p, _p, _p], _i),
+    "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _f, _p, _p, _p, _p, _p], _i),
     "lush_draws": ([C.c_ulonglong, C.c_ulonglong, _p, _ll, _p, _ll, _p, _ll, _p, _ll, _p], _i),
     "lush_mlp_packed_bytes": ([_i, _i], _sz),
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
@@ -199,6 +199,7 @@ _SIGS = {
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
 ABI_VERSION = 7
+PLANES_F16 = 17          # include/lush_march.h: plane code of ONE fp16 plane (1..3 = bf16 planes)
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
 VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 64
 # include/lush_march.h: LUSH_FAULT_*

@@ -238,7 +238,7 @@ class MarchCfg:
 def zgrid(batch, S, lindisp, t_rand):
     R = batch.shape[0]
     z = torch.empty(R, S, dtype=torch.float32, device=batch.device)
-    lib.call("lush_zgrid", lib.ptr(batch), R, S, int(lindisp), lib.ptr(t_rand), lib.ptr(z), _stream())
+    lib.call("lush_zgrid", lib.ptr(batch), R, S, int(lindisp), lib.ptr(t_rand), lib.ptr(z), None, _stream())
     return z
 
 
@@ -261,7 +261,7 @@ def composite_bwd(raw, z, batch, noise, cfg: MarchCfg, g_rgb, g_depth, g_acc, dr
     draw = torch.empty(R * S, 4, dtype=torch.float32, device=z.device)
     lib.call("lush_composite_bwd", lib.ptr(raw), lib.ptr(z), lib.ptr(batch), R, S, lib.ptr(noise),
              float(cfg.raw_noise_std), float(cfg.near_mask), int(cfg.white_bkgd), lib.ptr(g_rgb), lib.ptr(g_depth),
-             lib.ptr(g_acc), lib.ptr(draw), lib.ptr(drays), _stream())
+             lib.ptr(g_acc), lib.ptr(draw), lib.ptr(drays), None, None, 0, 0, _stream())
     return draw
 
 
@@ -404,7 +404,8 @@ class March(torch.autograd.Function):
         else:
             buf_c, ret_c = grads_for(coarse, ran_c)
             buf_f, ret_f = grads_for(fine, ran_f)
-        drays = torch.zeros_like(batch)
+        # (the first pass that runs writes d(ray batch) whole: no zero-fill launch; nothing runs when no output gradient arrived)
+        drays = torch.empty_like(batch) if (ran_f or ran_c) else torch.zeros_like(batch)
         dr = lib.MarchDraws(*(None if d.get(k) is None else d[k].data_ptr() for k in ("t_rand", "noise_c", "u", "noise_f")))
         stc, stf = lib.mlp_struct(coarse, _NL[NET_NERF]), lib.mlp_struct(fine, _NL[NET_NERF])
         gc = lib.mlp_struct(buf_c, _NL[NET_NERF]) if buf_c is not None else None
@@ -507,7 +508,7 @@ class NoiseMlp(torch.autograd.Function):
             hooks.keep.update(stash_noise=stash, P_noise=R)
         ctx.save_for_backward(batch, z, *([stash] if stash is not None else []), *tensors)
         ctx.has_stash, ctx.precision, ctx.hooks = stash is not None, precision, hooks
-        return raw[:, :3].contiguous()
+        return raw[:, :3]           # a view of the [R,4] raw output (no copy launch; ops.BlurMix reads it with its row stride)
 
     @staticmethod
     def backward(ctx, g):
@@ -516,8 +517,13 @@ class NoiseMlp(torch.autograd.Function):
         batch, z = t[0], t[1]
         stash = t[2] if ctx.has_stash else None
         tensors = list(t[3 if ctx.has_stash else 2:])
-        draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
-        draw[:, :3] = g
+        base = g._base if g._is_view() else None
+        if base is not None and base.dtype == torch.float32 and tuple(base.shape) == (g.shape[0], 4) and base.is_contiguous() \
+                and g.data_ptr() == base.data_ptr() and tuple(g.stride()) == (4, 1):
+            draw = base             # ops.BlurMix.backward hands over columns 0..2 of a [R,4] buffer whose column 3 it zeroed
+        else:
+            draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
+            draw[:, :3] = g
         pk = mlp_pack(NET_NOISE, pr.bwd, tensors)
         grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, tensors, pk, batch, z, draw, stash,
                                 sink=grad_sink(tensors, ctx.hooks), variant=pr.variant)
@@ -629,6 +635,7 @@ class RbkWarpNdc(torch.autograd.Function):
         ctx.save_for_backward(rays, idx, acts, *([mask] if mask is not None else []), *tensors)
         ctx.has_mask, ctx.hooks = mask is not None, hooks
         ctx.cfg = (N, M, num_img, float(window), int(bool(ndc)), cx, cy)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(batch0)
         return batch, ccw, batch0
 
@@ -650,16 +657,19 @@ class RbkWarpNdc(torch.autograd.Function):
 class BlurMix(torch.autograd.Function):
     """The tail of NeRFAll.forward's training branch in one kernel per direction (SURVEY.md section 7.2 `blur_mix_tonemap`;
     models/lushnerf.py:644-654): rbk_weighted_sum of the fine and coarse colours (:100-116), rgb_noise = 0.1 sigmoid(noise_raw),
-    tone mapping (helpers:164-174).  rgb, rgb0 [N*(M+1),3], ccw [N,M+1], noise_raw [N,3] ->
-    (tm(rgb_pure + rgb_noise), tm(rgb0_pure + rgb_noise), rgb_noise, tm(rgb_pure), tm(rgb0_pure))."""
+    tone mapping (helpers:164-174).  rgb, rgb0 [N*(M+1),3], ccw [N,M+1], noise_raw [N,3] (rows may be strided: the noise MLP's
+    [N,4] raw output is read in place) -> (tm(rgb_pure + rgb_noise), tm(rgb0_pure + rgb_noise), rgb_noise, tm(rgb_pure),
+    tm(rgb0_pure))."""
 
     @staticmethod
     def forward(ctx, rgb, rgb0, ccw, nraw, gamma):
-        rgb, rgb0, ccw, nraw = _f32(rgb), _f32(rgb0), _f32(ccw), _f32(nraw)
+        rgb, rgb0, ccw = _f32(rgb), _f32(rgb0), _f32(ccw)
+        if nraw.dtype != torch.float32 or nraw.dim() != 2 or nraw.stride(1) != 1 or not nraw.is_cuda:
+            nraw = _f32(nraw)
         N, M1 = ccw.shape
         out = torch.empty(5, N, 3, dtype=torch.float32, device=rgb.device)
-        lib.call("lush_blur_mix_fwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), N, M1, int(bool(gamma)),
-                 *(lib.ptr(out[i]) for i in range(5)), _stream())
+        lib.call("lush_blur_mix_fwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), int(nraw.stride(0)), N, M1,
+                 int(bool(gamma)), *(lib.ptr(out[i]) for i in range(5)), _stream())
         ctx.save_for_backward(rgb, rgb0, ccw, nraw)
         ctx.gamma = int(bool(gamma))
         ctx.set_materialize_grads(False)
@@ -670,10 +680,11 @@ class BlurMix(torch.autograd.Function):
         rgb, rgb0, ccw, nraw = ctx.saved_tensors
         N, M1 = ccw.shape
         d_rgb, d_rgb0 = torch.empty_like(rgb), torch.empty_like(rgb0)
-        d_ccw, d_nraw = torch.empty_like(ccw), torch.empty_like(nraw)
-        lib.call("lush_blur_mix_bwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), N, M1, ctx.gamma,
-                 *(lib.ptr(_opt(x)) for x in g), lib.ptr(d_rgb), lib.ptr(d_rgb0), lib.ptr(d_ccw), lib.ptr(d_nraw), _stream())
-        return d_rgb, d_rgb0, d_ccw, d_nraw, None
+        d_ccw = torch.empty_like(ccw)
+        d_nraw4 = torch.empty(N, 4, dtype=torch.float32, device=rgb.device)      # column 3 = 0: the noise MLP's d_raw as it stands
+        lib.call("lush_blur_mix_bwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), int(nraw.stride(0)), N, M1, ctx.gamma,
+                 *(lib.ptr(_opt(x)) for x in g), lib.ptr(d_rgb), lib.ptr(d_rgb0), lib.ptr(d_ccw), lib.ptr(d_nraw4), _stream())
+        return d_rgb, d_rgb0, d_ccw, d_nraw4[:, :3], None
 
 
 class WSum(torch.autograd.Function):
@@ -747,14 +758,16 @@ class NoiseAct(torch.autograd.Function):
         return dx
 
 
-def train_loss_grads(a, b, target, scale: float = 1.0):
+def train_loss_grads(a, b, target, scale: float = 1.0, work: Optional[torch.Tensor] = None):
     """run_lushnerf.py:652-661 without an autograd node: (scale * loss, scale * d loss/d a, scale * d loss/d b) from one
-    kernel.  The trainer feeds the two gradients to torch.autograd.backward itself (no ones-fill, no grad * g kernels)."""
+    kernel.  The trainer feeds the two gradients to torch.autograd.backward itself (no ones-fill, no grad * g kernels).
+    work: 2 floats of scratch owned by the caller, zero before the first call (the kernel leaves them zero): the loss word is
+    then written by the kernel instead of zero-filled here and accumulated."""
     a, b, target = _f32(a.detach()), _f32(b.detach()), _f32(target)
-    loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+    loss = torch.empty(1, dtype=torch.float32, device=a.device) if work is not None else torch.zeros(1, dtype=torch.float32, device=a.device)
     ga, gb = torch.empty_like(a), torch.empty_like(b)
     lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(target), a.shape[0], float(scale), lib.ptr(loss),
-             lib.ptr(ga), lib.ptr(gb), _stream())
+             lib.ptr(ga), lib.ptr(gb), lib.ptr(work), _stream())
     return loss[0], ga, gb
 
 
@@ -767,7 +780,7 @@ class TrainLoss(torch.autograd.Function):
         loss = torch.zeros(1, dtype=torch.float32, device=a.device)
         ga, gb = torch.empty_like(a), torch.empty_like(b)
         lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(target), a.shape[0], 1.0, lib.ptr(loss), lib.ptr(ga),
-                 lib.ptr(gb), _stream())
+                 lib.ptr(gb), None, _stream())
         ctx.save_for_backward(ga, gb)
         return loss[0]
 

@@ -104,6 +104,8 @@ class Trainer:
         self._fwd_bwd = step_fn or self._hip_forward_backward
         self._adam = ops.adam_step
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
+        # scratch of the loss kernel's reduction (zero once, left zero by every launch: no zero-fill per step)
+        self._loss_work = torch.zeros(2, dtype=torch.float32, device=self.flat.param.device) if self.flat.param.is_cuda else None
         self._graph = None                # step_graph: the captured step (graphs, static batch / loss, device step state + host mirror)
         self._graph_eager_left = 2        # plain steps before the capture (every lazy initialisation behind the entry points has run)
         self.sync_replicas()
@@ -150,7 +152,7 @@ class Trainer:
         out = self.model(self.H, self.W, self.K, chunk=self.chunk, rays=rays, rays_info={"images_idx": idx},
                          retraw=True, force_naive=force_naive, allkernel=i < self.allkernel_start_iter,
                          kernel_pixel=batch["fq_mask"][a:b], draws=d, **self.kw)
-        part, ga, gb = ops.train_loss_grads(out[0], out[1], batch["target"][a:b], frac)
+        part, ga, gb = ops.train_loss_grads(out[0], out[1], batch["target"][a:b], frac, work=self._loss_work)
         torch.autograd.backward([out[0], out[1]], [ga, gb])
         return part
 

@@ -830,7 +830,7 @@ def test_march_through_the_c_abi_alone(diag):
     batch = torch.empty(n, 11, device=dev)
     lib.call("lush_pack_rays_fwd", lib.ptr(rays), n, 1, cx, cy, 0.0, 1.0, lib.ptr(batch), stream)
     d = {k: torch.from_numpy(v).to(dev).contiguous() for k, v in synth.draws(n, Ns, Ni, seed).items()}
-    for planes, tol in (((2, 2), 1e-4), ((lib.MarchCfgC.planes_fwd and 17, 17), 1e-4)):
+    for planes, tol in (((2, 2), 1e-4), ((lib.PLANES_F16, lib.PLANES_F16), 1e-4)):
         cfg = lib.MarchCfgC(n, Ns, Ni, 1.0, 1.0, 0, 0, -1.0, planes[0], planes[1], 0, 0)
         nbytes = L.lush_march_workspace_bytes(C.byref(cfg))
         assert nbytes > 0
@@ -856,7 +856,7 @@ def test_march_through_the_c_abi_alone(diag):
         gf = [torch.zeros_like(t) for t in fine]
         ones = torch.ones(n, 3, device=dev)
         go = lib.MarchGout(ones.data_ptr(), None, None, ones.data_ptr(), None, None)
-        drays = torch.zeros(n, 11, device=dev)
+        drays = torch.full((n, 11), float("nan"), device=dev)      # (ABI 7: written whole by the first pass, no zero-fill by the caller)
         sgc, sgf = lib.mlp_struct(gc, 8), lib.mlp_struct(gf, 8)
         lib.call("lush_march_bwd", C.byref(cfg), lib.ptr(batch), C.byref(pc), C.byref(pfn), C.byref(dr), C.byref(go), lib.ptr(ws),
                  C.byref(sgc), C.byref(sgf), lib.ptr(drays), stream)
