@@ -190,7 +190,7 @@ int lush_rbk_warp_ndc_fwd(const float* rays, const int64_t* idx, int N, int M, c
  * (accumulate, as lush_rbk_warp_bwd), drays [N][3][2] (overwritten; may be NULL). */
 int lush_rbk_warp_ndc_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, int ndc, float cx, float cy,
                           const float* dbatch, const float* dccw, const uint8_t* mask, float* d_rvw, int rvw_stride,
-                          float* drays, lush_stream_t stream);
+                          float* drays, int num_img, lush_stream_t stream);       /* num_img: rows of acts / d_rvw; idx < num_img */
 
 /* ------------------------------------------------------- blur mix and tone map
  * rbk_weighted_sum (models/lushnerf.py:100-116): x [N*M][C], ccw [N][M] -> y [N][C]. */
@@ -266,6 +266,20 @@ typedef struct {
 #define LUSH_VARIANT_KERNEL_BITS 0xDF /* every bit above that selects a kernel; anything else in the word is ignored */
 
 size_t lush_mlp_packed_bytes(int net, int planes);
+/* Pack PLANS (ABI 7): the fragments and fp32 blocks of up to 8 (network, plane code) pairs as ONE launch.  A training step
+ * re-packs every network once, after the optimiser moved the parameters (the coarse, fine and noise nets in their forward and,
+ * where it differs, backward plane code): three launches per network and direction become one per step.
+ *   plan = device buffer of lush_pack_plan_bytes(n_jobs) bytes; lush_pack_plan_build fills it from the host (a set-up call: it
+ *   SYNCHRONISES, once per model -- parameter and destination addresses are baked in) and returns the grid size in
+ *   *launch_blocks; lush_pack_plan_run enqueues the one kernel. */
+typedef struct {
+    int net, planes, variant;        /* as lush_mlp_pack_for */
+    const lush_mlp_params* prm;
+    void* packed;                    /* lush_mlp_packed_bytes(net, planes) bytes */
+} lush_pack_job;
+size_t lush_pack_plan_bytes(int n_jobs);
+int lush_pack_plan_build(const lush_pack_job* jobs, int n_jobs, void* plan, size_t plan_bytes, int* launch_blocks);
+int lush_pack_plan_run(const void* plan, int launch_blocks, lush_stream_t stream);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream);
 /* ... only the copies the kernels selected by `variant` read (variant < 0: all of them, as lush_mlp_pack). */
@@ -326,6 +340,11 @@ typedef struct {
     int planes_bwd;                /* plane code of the backward; 0 = inference (nothing is kept, lush_march_bwd refuses) */
     int variant;                   /* LUSH_VARIANT_* bits, 0 = the product's choice */
     int same_net;                  /* the fine pass evaluates the coarse parameters (mlp_fine is None, models/lushnerf.py:214) */
+    /* ABI 7.  Weights already packed by the caller (lush_mlp_pack_for / a pack plan) for plane code planes_fwd, or NULL: the
+     * forward then packs into the workspace itself, per call.  A training step packs every network ONCE (lush_pack_plan_run)
+     * and hands the buffers to each of its marches (micro-batches, the consistency branch).  With planes_bwd != planes_fwd the
+     * backward needs fragments of its own plane code: packed_bwd_* (NULL: packed inside lush_march_bwd). */
+    const void *packed_coarse, *packed_fine, *packed_bwd_coarse, *packed_bwd_fine;
 } lush_march_cfg;
 /* The random draws of a march in the reference's shapes (see lush_draws); NULL = that draw is off. */
 typedef struct { const float *t_rand, *noise_c, *u, *noise_f; } lush_march_draws;

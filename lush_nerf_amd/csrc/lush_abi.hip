@@ -1,6 +1,8 @@
 // lush-march: C ABI of the fused MLP path (pack plan, stash layout, launch order).
 #include "lush_common.h"
 #include "lush_host.h"
+#include <cstring>
+#include <vector>
 #include "../../include/lush_march.h"
 
 using namespace lush;
@@ -269,55 +271,117 @@ size_t lush_mlp_packed_bytes(int net, int planes) {
     return al256((size_t)n.total_entries * nplanes(planes) * 1024 + (size_t)n.f32_total * 4);
 }
 
-int lush_mlp_pack_for(int net, int planes, const lush_mlp_params* prm, void* packed, int variant, lush_stream_t stream) {
+// The fragment tables one (net, plane code, variant) needs, in launch order: what lush_mlp_pack / lush_mlp_pack_for launch
+// one by one and a pack plan (lush_pack_plan_*) holds as one table.  variant < 0: every copy.
+static int collect_pack_tables(int net, int planes, const lush_mlp_params* prm, int variant, std::vector<PackTable>& out,
+                               std::vector<int>& out_blocks) {
+    if (!code_ok(planes)) return set_error("lush_mlp_pack: planes must be 1..3 or 17 (fp16)");
+    if (net != 0 && net != 1) return set_error("lush_mlp_pack: bad net");
+    auto push = [&](const PackTable& T, int blocks) { out.push_back(T); out_blocks.push_back(blocks); };
+    PackTable T;
+    int blocks = 0;
     // the product's kernels for one fp16 plane on the 8x256 net read the two quarter-row streams and the fp32 block only:
     // three launches instead of six (the launch-bound configurations pay for every one of them)
     const int older = LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_BWD_HALF | LUSH_VARIANT_BWD_512;
-    if (net != 0 || planes != PLANES_F16 || variant < 0 || (variant & older)) return lush_mlp_pack(net, planes, prm, packed, stream);
-    PackTable T;
-    int blocks = 0;
-    build_pack_table_wide<NetNerf>(prm, T, blocks);
-    if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
-    int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
-    if (rc) return rc;
-    build_pack_table_wide_bwd<NetNerf>(prm, T, blocks);
-    if (blocks != NetNerf::bwd4_len) return set_error("lush_mlp_pack: transposed quarter-row stream length");
-    rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+    if (net == 0 && planes == PLANES_F16 && variant >= 0 && !(variant & older)) {
+        build_pack_table_wide<NetNerf>(prm, T, blocks);
+        if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
+        push(T, blocks);
+        build_pack_table_wide_bwd<NetNerf>(prm, T, blocks);
+        if (blocks != NetNerf::bwd4_len) return set_error("lush_mlp_pack: transposed quarter-row stream length");
+        push(T, blocks);
+        return 0;
+    }
+    // only the copies the kernels of this plane count read (the rest of the buffer stays unwritten)
+    const bool fc = mlp_fwd_chain_enabled(planes), bc = mlp_bwd_chain_enabled(planes);
+    const int lo = (fc && bc) ? 1 : 0, hi = (fc || bc) ? 1 : 0;
+    if (net == 0) build_pack_table<NetNerf>(prm, T, blocks, lo, hi);
+    else build_pack_table<NetNoise>(prm, T, blocks, lo, hi);
+    push(T, blocks);
+    if (net == 0 && nplanes(planes) == 1) {      // the half-row streams are read by the one-plane chain kernels only
+        build_pack_table_half<NetNerf>(prm, T, blocks);
+        push(T, blocks);
+        if (planes == PLANES_F16) {              // ... and the half-row backward by the fp16 chain only
+            build_pack_table_half_bwd<NetNerf>(prm, T, blocks);
+            push(T, blocks);
+            build_pack_table_wide<NetNerf>(prm, T, blocks);     // quarter-row forward stream (64 points per wave)
+            if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
+            push(T, blocks);
+            build_pack_table_wide_bwd<NetNerf>(prm, T, blocks);     // ... and its transposed twin
+            if (blocks != NetNerf::bwd4_len) return set_error("lush_mlp_pack: transposed quarter-row stream length");
+            push(T, blocks);
+        }
+    }
+    return 0;
+}
+
+int lush_mlp_pack_for(int net, int planes, const lush_mlp_params* prm, void* packed, int variant, lush_stream_t stream) {
+    std::vector<PackTable> tables;
+    std::vector<int> blocks;
+    int rc = collect_pack_tables(net, planes, prm, variant, tables, blocks);
+    for (size_t i = 0; i < tables.size() && !rc; ++i) rc = launch_pack(planes, tables[i], blocks[i], packed, (hipStream_t)stream);
     if (rc) return rc;
     return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
 }
 
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream) {
-    PackTable T;
-    int blocks = 0;
-    if (!code_ok(planes)) return set_error("lush_mlp_pack: planes must be 1..3 or 17 (fp16)");
-    // only the copies the kernels of this plane count read (the rest of the buffer stays unwritten)
-    const bool fc = mlp_fwd_chain_enabled(planes), bc = mlp_bwd_chain_enabled(planes);
-    const int lo = (fc && bc) ? 1 : 0, hi = (fc || bc) ? 1 : 0;
-    if (net == 0) build_pack_table<NetNerf>(prm, T, blocks, lo, hi);
-    else if (net == 1) build_pack_table<NetNoise>(prm, T, blocks, lo, hi);
-    else return set_error("lush_mlp_pack: bad net");
-    int rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
-    if (rc) return rc;
-    if (net == 0 && nplanes(planes) == 1) {      // the half-row streams are read by the one-plane chain kernels only
-        build_pack_table_half<NetNerf>(prm, T, blocks);
-        rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
+    return lush_mlp_pack_for(net, planes, prm, packed, -1, stream);
+}
+
+// ---- pack plans: every network of a training step in ONE launch ----
+size_t lush_pack_plan_bytes(int n_jobs) {
+    if (n_jobs < 1 || n_jobs > PLAN_MAX_NETS) return 0;
+    return al256(sizeof(PlanHeader) + sizeof(MlpParams) * PLAN_MAX_NETS + sizeof(PlanJob) * (size_t)n_jobs * 260);
+}
+
+int lush_pack_plan_build(const lush_pack_job* jobs, int n_jobs, void* plan, size_t plan_bytes, int* launch_blocks) {
+    if (!jobs || !plan || !launch_blocks) return set_error("lush_pack_plan_build: jobs, plan and launch_blocks are required");
+    if (n_jobs < 1 || n_jobs > PLAN_MAX_NETS) return set_error("lush_pack_plan_build: 1 .. 8 jobs");
+    std::vector<PlanJob> pj;
+    std::vector<MlpParams> prms(PLAN_MAX_NETS);
+    int total = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const lush_pack_job& J = jobs[k];
+        if (!J.prm || !J.packed) return set_error("lush_pack_plan_build: a job without parameters or destination");
+        std::vector<PackTable> tables;
+        std::vector<int> blocks;
+        int rc = collect_pack_tables(J.net, J.planes, J.prm, J.variant, tables, blocks);
         if (rc) return rc;
-        if (planes == PLANES_F16) {              // ... and the half-row backward by the fp16 chain only
-            build_pack_table_half_bwd<NetNerf>(prm, T, blocks);
-            rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
-            if (rc) return rc;
-            build_pack_table_wide<NetNerf>(prm, T, blocks);     // quarter-row forward stream (64 points per wave)
-            if (blocks != NetNerf::fwd4_len) return set_error("lush_mlp_pack: quarter-row stream length");
-            rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
-            if (rc) return rc;
-            build_pack_table_wide_bwd<NetNerf>(prm, T, blocks);     // ... and its transposed twin
-            if (blocks != NetNerf::bwd4_len) return set_error("lush_mlp_pack: transposed quarter-row stream length");
-            rc = launch_pack(planes, T, blocks, packed, (hipStream_t)stream);
-            if (rc) return rc;
+        for (size_t t = 0; t < tables.size(); ++t) {
+            for (int i = 0; i < tables[t].n; ++i) {
+                PlanJob q{};
+                q.j = tables[t].j[i];
+                q.j.first_block += total;
+                q.dst = J.packed; q.code = J.planes; q.kind = 0; q.prm_index = k;
+                pj.push_back(q);
+            }
+            total += blocks[t];
         }
+        prms[k] = to_params(J.prm);
+        PlanJob f{};
+        const int f32_total = J.net == 0 ? NetNerf::f32_total : NetNoise::f32_total;
+        const int entries = J.net == 0 ? NetNerf::total_entries : NetNoise::total_entries;
+        f.j.first_block = total;
+        f.dst = reinterpret_cast<float*>(J.packed) + (size_t)entries * nplanes(J.planes) * 256;
+        f.code = J.planes; f.kind = J.net == 0 ? 1 : 2; f.prm_index = k;
+        pj.push_back(f);
+        total += (f32_total + 63) / 64;
     }
-    return launch_pack_f32(net, nplanes(planes), to_params(prm), packed, (hipStream_t)stream);
+    const size_t need = sizeof(PlanHeader) + sizeof(MlpParams) * PLAN_MAX_NETS + sizeof(PlanJob) * pj.size();
+    if (need > plan_bytes) return set_error("lush_pack_plan_build: plan buffer too small (lush_pack_plan_bytes)");
+    std::vector<char> host(need);
+    PlanHeader H{(int)pj.size(), total, n_jobs, 0};
+    memcpy(host.data(), &H, sizeof(H));
+    memcpy(host.data() + sizeof(H), prms.data(), sizeof(MlpParams) * PLAN_MAX_NETS);
+    memcpy(host.data() + sizeof(H) + sizeof(MlpParams) * PLAN_MAX_NETS, pj.data(), sizeof(PlanJob) * pj.size());
+    LUSH_HIP(hipMemcpy(plan, host.data(), need, hipMemcpyHostToDevice));       // (set-up call: synchronous, once per model)
+    *launch_blocks = total;
+    return 0;
+}
+
+int lush_pack_plan_run(const void* plan, int launch_blocks, lush_stream_t stream) {
+    if (!plan || launch_blocks < 1) return set_error("lush_pack_plan_run: no plan");
+    return launch_pack_plan(plan, launch_blocks, (hipStream_t)stream);
 }
 
 size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P) {

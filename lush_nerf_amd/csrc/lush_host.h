@@ -70,6 +70,7 @@ int launch_mlp_wide_fwd(const MlpFwdArgs& a, hipStream_t s);
 // lush_mlp_wide_bwd.hip
 int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s);
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
+int launch_pack_plan(const void* plan, int blocks, hipStream_t s);
 int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s);
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);
 int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16, hipStream_t s);

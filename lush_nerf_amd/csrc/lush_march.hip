@@ -714,61 +714,83 @@ __global__ void rbk_warp_ndc_fwd_kernel(const float* __restrict__ rays, const in
     if (m == 0 && batch0 != nullptr) pack_one(oo, dd, ndc, cx, cy, near, far, batch0 + n * 11);
 }
 
-// Reverse: dbatch [N*(M+1)][11] (may be NULL: only the weights' gradient), dccw [N][M+1] (may be NULL) -> d_rvw [num_img][32]
-// (atomics; zeroed by lush_rbk_mlp_fwd), drays [N][3][2] (overwritten; may be NULL).  mask as in rbk_warp_bwd_kernel.
-__global__ void rbk_warp_ndc_bwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
+// Reverse: dbatch [N*(M+1)][11] (may be NULL: only the weights' gradient), dccw [N][M+1] (may be NULL) -> d_rvw [num_img][stride]
+// (accumulated; zeroed by lush_rbk_mlp_fwd), drays [N][3][2] (overwritten; may be NULL).  mask as in rbk_warp_bwd_kernel.
+// One thread per (input ray, motion slot), RPB rays per workgroup.  The per-image sums are formed in LDS first (up to WN_IMGS
+// images) and leave as one global atomic per touched (image, component) and workgroup: with 4096 rays of 26 images the
+// first version's 119 k atomics on 754 words took 33 us.
+constexpr int WN_IMGS = 64;
+__global__ __launch_bounds__(1024) void rbk_warp_ndc_bwd_kernel(const float* __restrict__ rays, const int64_t* __restrict__ idx, int N, int M,
                                         const float* __restrict__ acts, int ndc, float cx, float cy,
                                         const float* __restrict__ dbatch, const float* __restrict__ dccw,
                                         const uint8_t* __restrict__ mask, float* __restrict__ d_rvw, int rvw_stride,
-                                        float* __restrict__ drays) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+                                        float* __restrict__ drays, int num_img, int RPB) {
+    __shared__ float tab[WN_IMGS][LUSH_RBK_RVW_STRIDE];
+    __shared__ float racc[1024 / 2][6];           // d(o, d) of the workgroup's rays (RPB <= 512: M >= 1)
     const int M1 = M + 1;
-    const long long img = idx[n];
-    float* G = d_rvw + img * rvw_stride;
-    if (dccw)
-        for (int m = 0; m <= M; ++m) atomicAdd(G + 24 + m, dccw[(long long)n * M1 + m]);
-    const bool live = dbatch != nullptr && (mask == nullptr || mask[n] != 0);
-    V3 go = {0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f};
-    if (live) {
-        const float* r6 = rays + (long long)n * 6;
-        const V3 o = {r6[0], r6[2], r6[4]}, d = {r6[1], r6[3], r6[5]};
-        const V3 end = o + d;
-        const float* A = acts + img * LUSH_RBK_ACT_STRIDE;
-        const float* g11 = dbatch + (long long)n * M1 * 11;
-        {   // slot 0: the input ray itself
-            const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-            float a[3], b[3];
-            pack_one_bwd(oo, dd, ndc, cx, cy, g11, a, b);
-            go = {a[0], a[1], a[2]};
-            gd = {b[0], b[1], b[2]};
-        }
-        for (int m = 0; m < M; ++m) {
-            const V3 r = {A[RA_R + m], A[RA_R + M + m], A[RA_R + 2 * M + m]};
-            const V3 v = {A[RA_V + m], A[RA_V + M + m], A[RA_V + 2 * M + m]};
-            const Se3 q = se3_setup(r, v);
-            const V3 wo = se3_apply(q, o), wd = se3_apply(q, end) - wo;     // (recomputed: the warped rays were never stored)
-            const float oo[3] = {wo.x, wo.y, wo.z}, dd[3] = {wd.x, wd.y, wd.z};
-            float a[3], b[3];
-            pack_one_bwd(oo, dd, ndc, cx, cy, g11 + (m + 1) * 11, a, b);
-            const V3 gwo = {a[0], a[1], a[2]}, gwd = {b[0], b[1], b[2]};
-            const V3 gye = gwd, gyo = gwo - gwd;       // wd = we - wo
-            V3 gp_o = {0, 0, 0}, gp_e = {0, 0, 0}, gw = {0, 0, 0}, gnu = {0, 0, 0};
-            float gth = 0.f, gs = 0.f, gc = 0.f;
-            se3_apply_bwd(q, o, gyo, gp_o, gw, gnu, gth, gs, gc);
-            se3_apply_bwd(q, end, gye, gp_e, gw, gnu, gth, gs, gc);
-            V3 gr, gv;
-            se3_finish_bwd(q, r, gw, gnu, gth, gs, gc, gr, gv);
-            go = go + gp_o + gp_e;
-            gd = gd + gp_e;
-            atomicAdd(G + m, gr.x); atomicAdd(G + M + m, gr.y); atomicAdd(G + 2 * M + m, gr.z);
-            atomicAdd(G + 12 + m, gv.x); atomicAdd(G + 12 + M + m, gv.y); atomicAdd(G + 12 + 2 * M + m, gv.z);
+    const bool in_lds = num_img <= WN_IMGS;
+    for (int i = threadIdx.x; i < WN_IMGS * LUSH_RBK_RVW_STRIDE; i += blockDim.x) (&tab[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < RPB * 6; i += blockDim.x) (&racc[0][0])[i] = 0.f;
+    __syncthreads();
+    const int lr = threadIdx.x / M1, slot = threadIdx.x % M1;
+    const long long n = (long long)blockIdx.x * RPB + lr;
+    const long long img = (lr < RPB && n < N) ? idx[n] : -1;
+    if (img >= 0 && img < num_img) {          // (an index outside the table contributes nothing instead of writing outside it)
+        float* G = in_lds ? &tab[img][0] : d_rvw + img * rvw_stride;
+        if (dccw) atomicAdd(G + 24 + slot, dccw[n * M1 + slot]);
+        const bool live = dbatch != nullptr && (mask == nullptr || mask[n] != 0);
+        if (live) {
+            const float* r6 = rays + n * 6;
+            const V3 o = {r6[0], r6[2], r6[4]}, d = {r6[1], r6[3], r6[5]};
+            const float* g11 = dbatch + (n * M1 + slot) * 11;
+            V3 go, gd;
+            if (slot == 0) {    // the input ray itself
+                const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                float a[3], b[3];
+                pack_one_bwd(oo, dd, ndc, cx, cy, g11, a, b);
+                go = {a[0], a[1], a[2]};
+                gd = {b[0], b[1], b[2]};
+            } else {
+                const int m = slot - 1;
+                const V3 end = o + d;
+                const float* A = acts + img * LUSH_RBK_ACT_STRIDE;
+                const V3 r = {A[RA_R + m], A[RA_R + M + m], A[RA_R + 2 * M + m]};
+                const V3 v = {A[RA_V + m], A[RA_V + M + m], A[RA_V + 2 * M + m]};
+                const Se3 q = se3_setup(r, v);
+                const V3 wo = se3_apply(q, o), wd = se3_apply(q, end) - wo;     // (recomputed: the warped rays were never stored)
+                const float oo[3] = {wo.x, wo.y, wo.z}, dd[3] = {wd.x, wd.y, wd.z};
+                float a[3], b[3];
+                pack_one_bwd(oo, dd, ndc, cx, cy, g11, a, b);
+                const V3 gwo = {a[0], a[1], a[2]}, gwd = {b[0], b[1], b[2]};
+                const V3 gye = gwd, gyo = gwo - gwd;       // wd = we - wo
+                V3 gp_o = {0, 0, 0}, gp_e = {0, 0, 0}, gw = {0, 0, 0}, gnu = {0, 0, 0};
+                float gth = 0.f, gs = 0.f, gc = 0.f;
+                se3_apply_bwd(q, o, gyo, gp_o, gw, gnu, gth, gs, gc);
+                se3_apply_bwd(q, end, gye, gp_e, gw, gnu, gth, gs, gc);
+                V3 gr, gv;
+                se3_finish_bwd(q, r, gw, gnu, gth, gs, gc, gr, gv);
+                go = gp_o + gp_e;
+                gd = gp_e;
+                atomicAdd(G + m, gr.x); atomicAdd(G + M + m, gr.y); atomicAdd(G + 2 * M + m, gr.z);
+                atomicAdd(G + 12 + m, gv.x); atomicAdd(G + 12 + M + m, gv.y); atomicAdd(G + 12 + 2 * M + m, gv.z);
+            }
+            if (drays) {
+                atomicAdd(&racc[lr][0], go.x); atomicAdd(&racc[lr][1], gd.x); atomicAdd(&racc[lr][2], go.y);
+                atomicAdd(&racc[lr][3], gd.y); atomicAdd(&racc[lr][4], go.z); atomicAdd(&racc[lr][5], gd.z);
+            }
         }
     }
-    if (drays) {
-        float* out = drays + (long long)n * 6;
-        out[0] = go.x; out[1] = gd.x; out[2] = go.y; out[3] = gd.y; out[4] = go.z; out[5] = gd.z;
-    }
+    __syncthreads();
+    if (in_lds)
+        for (int i = threadIdx.x; i < num_img * LUSH_RBK_RVW_STRIDE; i += blockDim.x) {
+            const float v = (&tab[0][0])[i];
+            if (v != 0.f) atomicAdd(d_rvw + (long long)(i / LUSH_RBK_RVW_STRIDE) * rvw_stride + i % LUSH_RBK_RVW_STRIDE, v);
+        }
+    if (drays)
+        for (int i = threadIdx.x; i < RPB * 6; i += blockDim.x) {
+            const long long nn = (long long)blockIdx.x * RPB + i / 6;
+            if (nn < N) drays[nn * 6 + i % 6] = (&racc[0][0])[i];
+        }
 }
 
 // ------------------------------------------------------------------- RBK MLP
@@ -1389,9 +1411,10 @@ int lush_composite_bwd(const float* raw, const float* z, const float* rays, int 
     if (zero_buf != nullptr && zero_n < 0) return set_error("lush_composite_bwd: zero_n must not be negative");
     CompIn c{raw, z, rays, noise, R, S, noise_std, near_mask, white_bkgd};
     const CompBwdExtra x{scale4, zero_buf, zero_buf ? zero_n : 0, init_drays};
-    // at most 1024 workgroups walk the rays: the loss-scale reduction ends in one atomic per workgroup on one word
+    // at most 2048 workgroups (8 per CU: what is resident at once) walk the rays: the loss-scale reduction ends in one atomic
+    // per workgroup on one word.  (1024 left half the chip's wave slots empty: 81 instead of 27 us on the fine pass.)
     int blocks = cdiv(R, RAYS_PER_BLOCK);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     dim3 g(blocks), b(RAYS_PER_BLOCK * 64);
     if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
     else if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
@@ -1510,12 +1533,16 @@ int lush_rbk_warp_ndc_fwd(const float* rays, const int64_t* idx, int N, int M, c
 }
 int lush_rbk_warp_ndc_bwd(const float* rays, const int64_t* idx, int N, int M, const float* acts, int ndc, float cx, float cy,
                           const float* dbatch, const float* dccw, const uint8_t* mask, float* d_rvw, int rvw_stride, float* drays,
-                          lush_stream_t st) {
+                          int num_img, lush_stream_t st) {
     if (N < 1 || M < 1 || M > 4) return set_error("lush_rbk_warp_ndc_bwd: need N >= 1 and 1 <= num_motion <= 4");
     if (!rays || !idx || !acts || !d_rvw) return set_error("lush_rbk_warp_ndc_bwd: rays, idx, acts and d_rvw are required");
     if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_warp_ndc_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
-    hipLaunchKernelGGL(rbk_warp_ndc_bwd_kernel, dim3(cdiv(N, 128)), dim3(128), 0, S_(st), rays, idx, N, M, acts, ndc, cx, cy, dbatch,
-                       dccw, mask, d_rvw, rvw_stride, drays);
+    if (num_img < 1) return set_error("lush_rbk_warp_ndc_bwd: num_img (the number of rows of acts / d_rvw) must be given");
+    const int M1 = M + 1;
+    int rpb = 256 / M1;                        // ~256 threads per workgroup: enough workgroups to spread over the chip
+    if (rpb > N) rpb = N;
+    hipLaunchKernelGGL(rbk_warp_ndc_bwd_kernel, dim3(cdiv(N, rpb)), dim3(rpb * M1), 0, S_(st), rays, idx, N, M, acts, ndc, cx, cy, dbatch,
+                       dccw, mask, d_rvw, rvw_stride, drays, num_img, rpb);
     CHECK_LAUNCH();
     return 0;
 }

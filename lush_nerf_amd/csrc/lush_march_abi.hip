@@ -108,9 +108,14 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     if (cfg->planes_bwd) mlp_dstash_header(0, cfg->planes_bwd, (long long)R * (two ? Sf : S), w + L.dstash, &scale4, &zero_buf, &zero_n);
     int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, scale4, st);
     if (rc) return rc;
-    rc = lush_mlp_pack_for(0, pf, coarse, w + L.pkc, cfg->variant, st);
-    if (rc) return rc;
-    rc = lush_mlp_fwd(0, pf, sc, rays, zc, R, S, w + L.pkc, coarse, (float*)(w + L.rawc), w + L.stashc, var, st);
+    // weights: packed by the caller once per step (cfg->packed_*), or here into the workspace
+    const void* pkc = cfg->packed_coarse;
+    if (!pkc) {
+        rc = lush_mlp_pack_for(0, pf, coarse, w + L.pkc, cfg->variant, st);
+        if (rc) return rc;
+        pkc = w + L.pkc;
+    }
+    rc = lush_mlp_fwd(0, pf, sc, rays, zc, R, S, pkc, coarse, (float*)(w + L.rawc), w + L.stashc, var, st);
     if (rc) return rc;
     // the coarse pass's results are rgb0 .. when a fine pass follows, else the final ones
     rc = lush_composite_fwd((const float*)(w + L.rawc), zc, rays, R, S, noise_c, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
@@ -120,11 +125,13 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     float* zf = (float*)(w + L.zf);
     rc = lush_sample_merge(zc, (const float*)(w + L.wc), R, S, Ni, u, zf, (float*)(w + L.zs), out->z_std, flags, st);
     if (rc) return rc;
-    if (!cfg->same_net) {
+    const void* pkf = cfg->same_net ? pkc : cfg->packed_fine;
+    if (!pkf) {
         rc = lush_mlp_pack_for(0, pf, pfine, w + L.pkf, cfg->variant, st);
         if (rc) return rc;
+        pkf = w + L.pkf;
     }
-    rc = lush_mlp_fwd(0, pf, sc, rays, zf, R, Sf, w + L.pkf, pfine, (float*)(w + L.rawf), w + L.stashf, var, st);
+    rc = lush_mlp_fwd(0, pf, sc, rays, zf, R, Sf, pkf, pfine, (float*)(w + L.rawf), w + L.stashf, var, st);
     if (rc) return rc;
     return lush_composite_fwd((const float*)(w + L.rawf), zf, rays, R, Sf, noise_f, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
                               out->rgb, out->depth, out->acc, (float*)(w + L.wf), out->density, flags, 0, st);
@@ -153,7 +160,9 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     bool first_pass = true;
     struct Scratch { float* draw; char* dstash; float* dpts; };
     const Scratch x{(float*)(w + L.draw), w + L.dstash, (float*)(w + L.dpts)};
-    auto chain = [&](const lush_mlp_params* prm, size_t zoff, size_t rawoff, size_t stashoff, size_t pkoff, size_t pkboff, bool repack,
+    // fragments of the backward's plane code: the caller's (cfg->packed_*), else the forward's copy in the workspace when the
+    // codes agree, else packed here
+    auto chain = [&](const lush_mlp_params* prm, size_t zoff, size_t rawoff, size_t stashoff, const void* pk_ready, size_t pkboff, bool repack,
                      int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc) -> int {
         const float* z = (const float*)(w + zoff);
         // the compositing backward also finds the fp16 chain's loss scale, zeroes the weight-gradient scratch and, in the
@@ -165,12 +174,15 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
                                     g_rgb, g_depth, g_acc, x.draw, drays, scale4, zero_buf, zero_n, first_pass ? 1 : 0, st);
         first_pass = false;
         if (rc) return rc;
-        if (repack) {       // the backward computes with another plane code than the forward: its own fragments
-            rc = lush_mlp_pack_for(0, pb, prm, w + pkboff, cfg->variant, st);
-            if (rc) return rc;
+        const void* pk = pk_ready;
+        if (!pk) {
+            if (repack) {       // the backward computes with another plane code than the forward: its own fragments
+                rc = lush_mlp_pack_for(0, pb, prm, w + pkboff, cfg->variant, st);
+                if (rc) return rc;
+            }
+            pk = w + pkboff;
         }
-        rc = mlp_bwd_chain_prepared(0, sc, pb, rays, z, R, Sp, w + (pb == pf ? pkoff : pkboff), prm, x.draw, w + stashoff, x.dstash, x.dpts,
-                                    var, st);
+        rc = mlp_bwd_chain_prepared(0, sc, pb, rays, z, R, Sp, pk, prm, x.draw, w + stashoff, x.dstash, x.dpts, var, st);
         if (rc) return rc;
         return lush_ray_grad_reduce(x.dpts, z, R, Sp, drays, st);
     };
@@ -183,15 +195,18 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
         return set_error("lush_march_bwd: gradient buffers of a pass that received output gradients are required");
     int rc = 0;
     bool packed_b_c = false;
+    // (pb == pf: the forward's fragments serve -- the caller's buffer if it packed, else the workspace copy at L.pkbc / L.pkbf = L.pkc / L.pkf)
+    const void* ready_c = pb == pf ? cfg->packed_coarse : cfg->packed_bwd_coarse;
+    const void* ready_f = cfg->same_net ? ready_c : (pb == pf ? cfg->packed_fine : cfg->packed_bwd_fine);
     if (two && any_main) {
-        rc = chain(pfine, L.zf, L.rawf, L.stashf, L.pkf, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc);
+        rc = chain(pfine, L.zf, L.rawf, L.stashf, ready_f, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc);
         if (rc) return rc;
         packed_b_c = cfg->same_net && pb != pf;     // the shared net's backward fragments are packed now
         rc = weights(pfine, gfine, L.stashf, Sf);
         if (rc) return rc;
     }
     if (any_c) {
-        rc = chain(coarse, L.zc, L.rawc, L.stashc, L.pkc, L.pkbc, pb != pf && !packed_b_c, S, noise_c, two ? g->rgb0 : g->rgb,
+        rc = chain(coarse, L.zc, L.rawc, L.stashc, ready_c, L.pkbc, pb != pf && !packed_b_c, S, noise_c, two ? g->rgb0 : g->rgb,
                    two ? g->depth0 : g->depth, two ? g->acc0 : g->acc);
         if (rc) return rc;
         rc = weights(coarse, g_coarse, L.stashc, S);

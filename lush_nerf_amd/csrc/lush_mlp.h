@@ -129,6 +129,22 @@ struct PackTable {
     int n;
 };
 
+// A pack PLAN: every fragment segment and fp32 block of SEVERAL networks / plane codes as one device-resident table, so that
+// a training step re-packs all its weights with ONE launch (pack_plan_kernel) instead of three per network and direction.
+struct PlanJob {
+    PackJob j;           // first_block = prefix sum over the whole plan; dst_entry relative to `dst`
+    void* dst;           // the packed buffer this job writes into
+    int code;            // plane code of that buffer (1..3 bf16 planes, PLANES_F16)
+    int kind;            // 0 = fragments; 1 / 2 = fp32 block of a NetNerf / NetNoise (64 elements per block), params = prm[prm_index]
+    int prm_index;
+    int pad;
+};
+constexpr int PLAN_MAX_NETS = 8;
+struct PlanHeader {
+    int n_jobs, total_blocks, n_prm, pad;
+    // followed by MlpParams prm[PLAN_MAX_NETS], then PlanJob jobs[n_jobs]
+};
+
 struct MlpParams {       // device pointers to the fp32 nn.Linear parameters
     const float* w[NET_MAX_LAYERS];
     const float* b[NET_MAX_LAYERS];

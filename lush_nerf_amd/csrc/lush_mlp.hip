@@ -33,13 +33,9 @@ constexpr int DW_THREADS = 256;           // weight-gradient GEMM / reductions: 
 // ----------------------------------------------------------------------------
 // weight packing
 // ----------------------------------------------------------------------------
+// entry e of segment J -> its 64 x 8 fragment (NS planes) in dst
 template <int NS, int DT>
-__global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __restrict__ dst) {
-    int b = blockIdx.x;
-    int j = 0;
-    while (j + 1 < T.n && T.j[j + 1].first_block <= b) ++j;
-    const PackJob J = T.j[j];
-    const int e = b - J.first_block;          // entry inside the segment = kk*nrb + rb
+__device__ __forceinline__ void pack_entry(const PackJob& J, int e, __bf16* __restrict__ dst) {
     const int kk = e / J.nrb, rb = e % J.nrb;
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int row = rb * 32 + (J.perm ? chain_row(r) : r);
@@ -64,11 +60,18 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __r
     }
 }
 
+template <int NS, int DT>
+__global__ __launch_bounds__(64) void pack_kernel(const PackTable T, __bf16* __restrict__ dst) {
+    int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < T.n && T.j[j + 1].first_block <= b) ++j;
+    const PackJob J = T.j[j];
+    pack_entry<NS, DT>(J, b - J.first_block, dst);
+}
+
 // fp32 block behind the fragments: biases + the two K<=3 head matrices (offsets: NetT::f32_*)
 template <class N>
-__global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N::f32_total) return;
+__device__ __forceinline__ float pack_f32_value(const MlpParams& P, int i) {
     float v = 0.f;
     if (i < N::f32_b_feat) v = P.b[i / N::HW][i % N::HW];
     else if (i < N::f32_b_alpha) v = P.b_feat[i - N::f32_b_feat];
@@ -77,7 +80,40 @@ __global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
     else if (i < N::f32_w_rgb) v = (i - N::f32_b_rgb < 3) ? P.b_rgb[i - N::f32_b_rgb] : 0.f;
     else if (i < N::f32_w_alpha) v = P.w_rgb[i - N::f32_w_rgb];
     else v = P.w_alpha[i - N::f32_w_alpha];
-    dst[i] = v;
+    return v;
+}
+template <class N>
+__global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N::f32_total) return;
+    dst[i] = pack_f32_value<N>(P, i);
+}
+
+// The whole plan in one launch: block b -> its job by binary search over the prefix sums.
+__global__ __launch_bounds__(64) void pack_plan_kernel(const PlanHeader* __restrict__ H) {
+    const MlpParams* prm = reinterpret_cast<const MlpParams*>(H + 1);
+    const PlanJob* jobs = reinterpret_cast<const PlanJob*>(prm + PLAN_MAX_NETS);
+    const int b = blockIdx.x;
+    int lo = 0, hi = H->n_jobs - 1;
+    while (lo < hi) {                      // last job with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].j.first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const PlanJob& PJ = jobs[lo];
+    const int e = b - PJ.j.first_block;
+    if (PJ.kind == 0) {
+        const PackJob J = PJ.j;
+        __bf16* dst = reinterpret_cast<__bf16*>(PJ.dst);
+        if (PJ.code == PLANES_F16) pack_entry<1, DT_F16>(J, e, dst);
+        else if (PJ.code == 1) pack_entry<1, DT_BF16>(J, e, dst);
+        else if (PJ.code == 2) pack_entry<2, DT_BF16>(J, e, dst);
+        else pack_entry<3, DT_BF16>(J, e, dst);
+    } else {
+        const int i = e * 64 + threadIdx.x;
+        float* dst = reinterpret_cast<float*>(PJ.dst);
+        if (PJ.kind == 1) { if (i < NetNerf::f32_total) dst[i] = pack_f32_value<NetNerf>(prm[PJ.prm_index], i); }
+        else if (i < NetNoise::f32_total) dst[i] = pack_f32_value<NetNoise>(prm[PJ.prm_index], i);
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -1478,6 +1514,12 @@ int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStre
         float* dst = reinterpret_cast<float*>(packed) + (size_t)NetNoise::total_entries * ns * 256;
         hipLaunchKernelGGL(pack_f32_kernel<NetNoise>, dim3((NetNoise::f32_total + 255) / 256), dim3(256), 0, s, prm, dst);
     }
+    LUSH_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pack_plan(const void* plan, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(blocks), dim3(64), 0, s, reinterpret_cast<const PlanHeader*>(plan));
     LUSH_HIP(hipGetLastError());
     return 0;
 }

@@ -125,7 +125,13 @@ class RbkParams(C.Structure):
 class MarchCfgC(C.Structure):       # include/lush_march.h: lush_march_cfg
     _fields_ = [("R", C.c_int), ("N_samples", C.c_int), ("N_importance", C.c_int), ("perturb", C.c_float),
                 ("raw_noise_std", C.c_float), ("white_bkgd", C.c_int), ("lindisp", C.c_int), ("near_mask", C.c_float),
-                ("planes_fwd", C.c_int), ("planes_bwd", C.c_int), ("variant", C.c_int), ("same_net", C.c_int)]
+                ("planes_fwd", C.c_int), ("planes_bwd", C.c_int), ("variant", C.c_int), ("same_net", C.c_int),
+                ("packed_coarse", C.c_void_p), ("packed_fine", C.c_void_p), ("packed_bwd_coarse", C.c_void_p),
+                ("packed_bwd_fine", C.c_void_p)]
+
+
+class PackJobC(C.Structure):        # include/lush_march.h: lush_pack_job
+    _fields_ = [("net", C.c_int), ("planes", C.c_int), ("variant", C.c_int), ("prm", C.POINTER(MlpParams)), ("packed", C.c_void_p)]
 
 
 class MarchDraws(C.Structure):
@@ -161,7 +167,7 @@ _SIGS = {
     "lush_rbk_warp_fwd": ([_p, _p, _i, _i, _p, _p, _p, _p], _i),
     "lush_rbk_warp_bwd": ([_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p], _i),
     "lush_rbk_warp_ndc_fwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _f, _f, _p, _p, _p, _p], _i),
-    "lush_rbk_warp_ndc_bwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _p, _p, _p, _p, _i, _p, _p], _i),
+    "lush_rbk_warp_ndc_bwd": ([_p, _p, _i, _i, _p, _i, _f, _f, _p, _p, _p, _p, _i, _p, _i, _p], _i),
     "lush_blur_mix_fwd": ([_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
     "lush_blur_mix_bwd": ([_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p], _i),
     "lush_wsum_fwd": ([_p, _p, _i, _i, _i, _p, _p], _i),
@@ -173,6 +179,9 @@ _SIGS = {
     "lush_loss_fwd_bwd": ([_p, _p, _p, _i, _f, _p, _p, _p, _p, _p], _i),
     "lush_draws": ([C.c_ulonglong, C.c_ulonglong, _p, _ll, _p, _ll, _p, _ll, _p, _ll, _p], _i),
     "lush_mlp_packed_bytes": ([_i, _i], _sz),
+    "lush_pack_plan_bytes": ([_i], _sz),
+    "lush_pack_plan_build": ([_p, _i, _p, _sz, _p], _i),
+    "lush_pack_plan_run": ([_p, _i, _p], _i),
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
     "lush_mlp_pack_for": ([_i, _i, C.POINTER(MlpParams), _p, _i, _p], _i),
     "lush_mlp_stash_bytes": ([_i, _i, _i, _ll], _sz),

@@ -250,6 +250,8 @@ class NeRFAll(nn.Module):
         return None if draws is None else {k: v[i:j] for k, v in draws.items()}
 
     def _chunks(self, fn, batch, chunk, draws):
+        if batch.shape[0] <= chunk:         # one chunk: no slice node (its backward is a zero-fill plus a copy of the whole gradient)
+            return [fn(batch, draws)]
         outs = []
         for i in range(0, batch.shape[0], chunk):
             outs.append(fn(batch[i:i + chunk], self._slice_draws(draws, i, i + chunk)))

@@ -106,6 +106,8 @@ class Hooks:
       sink:  Trainer.step -- parameter gradients are accumulated by the weight-gradient kernels' own atomics straight
              into each parameter's existing .grad buffer (the trainer's flat gradient) and autograd receives None for
              them: no per-tensor temporaries, zero-fills or `grad += tmp` kernels on the step;
+      packed: Trainer.step -- the networks' MFMA fragments, packed once per step by one launch (PackPlan) and valid until the
+             optimiser moves the parameters: the marches and the noise MLP of the step take them instead of re-packing per call;
       draw_offset: Philox offset of the next lush_draws call (march_draws);
       state: Trainer.step_graph -- the device step state (include/lush_march.h lush_step_state_*): draws then take the
              state's counter plus `draw_delta`, the number of the call inside the step, so a step captured in a HIP graph
@@ -113,9 +115,51 @@ class Hooks:
     timer: Optional[KernelTimer] = None
     keep: Optional[dict] = None
     sink: bool = False
+    packed: Optional[dict] = None      # Trainer.step: {(data_ptr of a net's first weight, plane code): packed fragments} of THIS step
     draw_offset: int = 0
     state: Optional[torch.Tensor] = None
     draw_delta: int = 0
+
+
+class PackPlan:
+    """Every network of a training step re-packed by ONE launch (include/lush_march.h lush_pack_plan_*): entries =
+    [(net, plane code, parameter tensors, variant)].  Parameter and destination addresses are baked into the device-resident
+    plan at construction (a synchronising set-up call); run() enqueues the one kernel; buffers maps
+    (data_ptr of the net's first weight, plane code) -> packed fragments, what ops.Hooks.packed holds during a step."""
+
+    def __init__(self, entries):
+        L = lib.load()
+        n = len(entries)
+        dev = entries[0][2][0].device
+        self.buffers: Dict[tuple, torch.Tensor] = {}
+        self._keep = []
+        jobs = (lib.PackJobC * n)()
+        for i, (net, planes, tensors, variant) in enumerate(entries):
+            buf = torch.empty(L.lush_mlp_packed_bytes(net, planes), dtype=torch.uint8, device=dev)
+            st = lib.mlp_struct(tensors, _NL[net])
+            self._keep.append(st)
+            jobs[i].net, jobs[i].planes, jobs[i].variant = int(net), int(planes), int(variant)
+            jobs[i].prm = C.pointer(st)
+            jobs[i].packed = buf.data_ptr()
+            self.buffers[(tensors[0].data_ptr(), int(planes))] = buf
+        nbytes = L.lush_pack_plan_bytes(n)
+        if nbytes == 0:
+            raise RuntimeError("lush_pack_plan_bytes: 1 .. 8 jobs")
+        self.plan = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        blocks = C.c_int(0)
+        lib.call("lush_pack_plan_build", jobs, n, lib.ptr(self.plan), nbytes, C.byref(blocks))
+        self.blocks = int(blocks.value)
+        self.signature = tuple((int(net), int(planes), int(variant), tuple(t.data_ptr() for t in tensors)) for net, planes, tensors, variant in entries)
+
+    def run(self):
+        lib.call("lush_pack_plan_run", lib.ptr(self.plan), self.blocks, _stream())
+
+
+def _packed_for(hooks, tensors, planes):
+    """The step's packed fragments of (network, plane code) if the trainer packed them (ops.Hooks.packed), else None."""
+    if hooks is None or hooks.packed is None:
+        return None
+    return hooks.packed.get((tensors[0].data_ptr(), int(planes)))
 
 
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0, variant: int = 0,
@@ -334,10 +378,23 @@ class March(torch.autograd.Function):
 
     # ------------------------------------------------------------------ one call per direction
     @staticmethod
-    def _c_cfg(cfg: MarchCfg, R: int, same: bool, need_grad: bool):
+    def _c_cfg(cfg: MarchCfg, R: int, same: bool, need_grad: bool, coarse=None, fine=None):
         pf, pb = cfg.precision.fwd, cfg.precision.bwd
-        return lib.MarchCfgC(R, cfg.N_samples, cfg.N_importance, float(cfg.perturb), float(cfg.raw_noise_std), int(cfg.white_bkgd),
-                             int(cfg.lindisp), float(cfg.near_mask), pf, pb if need_grad else 0, int(cfg.precision.variant), int(same))
+        c = lib.MarchCfgC(R, cfg.N_samples, cfg.N_importance, float(cfg.perturb), float(cfg.raw_noise_std), int(cfg.white_bkgd),
+                          int(cfg.lindisp), float(cfg.near_mask), pf, pb if need_grad else 0, int(cfg.precision.variant), int(same))
+        keep = []
+        if coarse is not None and cfg.hooks is not None and cfg.hooks.packed is not None:      # packed once per step by the trainer
+            def p(tensors, planes):
+                t = _packed_for(cfg.hooks, tensors, planes)
+                if t is not None:
+                    keep.append(t)
+                return None if t is None else t.data_ptr()
+            c.packed_coarse = p(coarse, pf)
+            c.packed_fine = None if same else p(fine, pf)
+            if need_grad and pb != pf:
+                c.packed_bwd_coarse = p(coarse, pb)
+                c.packed_bwd_fine = None if same else p(fine, pb)
+        return c
 
     @staticmethod
     def _view(ws, c, which, shape):
@@ -349,7 +406,7 @@ class March(torch.autograd.Function):
     def _forward_fused(ctx, batch, cfg, d, coarse, fine, same, need_grad):
         R, S, Ni, dev = batch.shape[0], cfg.N_samples, cfg.N_importance, batch.device
         Sl = S + Ni
-        c = March._c_cfg(cfg, R, same, need_grad)
+        c = March._c_cfg(cfg, R, same, need_grad, coarse, fine)
         nbytes = lib.load().lush_march_workspace_bytes(C.byref(c))
         if nbytes == 0:
             raise RuntimeError("lush_march_workspace_bytes: bad configuration")
@@ -383,7 +440,7 @@ class March(torch.autograd.Function):
         cfg = ctx.cfg
         (ws,) = saved
         R, fine_on = batch.shape[0], cfg.N_importance > 0
-        c = March._c_cfg(cfg, R, ctx.same, True)
+        c = March._c_cfg(cfg, R, ctx.same, True, coarse, fine)
         gp = [_opt(g[0]), _opt(g[1]), _opt(g[2])] + ([_opt(g[7]), _opt(g[8]), _opt(g[9])] if fine_on else [None, None, None])
         go = lib.MarchGout(*(None if t is None else t.data_ptr() for t in gp))
         any_main = any(t is not None for t in gp[:3])
@@ -500,7 +557,9 @@ class NoiseMlp(torch.autograd.Function):
         R = batch.shape[0]
         z = torch.empty(R, 1, dtype=torch.float32, device=batch.device)
         lib.call("lush_zfixed", lib.ptr(batch), R, int(N_samples), int(index), int(lindisp), lib.ptr(z), _stream())
-        pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
+        pk = _packed_for(hooks, tensors, precision.fwd)
+        if pk is None:
+            pk = mlp_pack(NET_NOISE, precision.fwd, tensors)
         need = bool(want_grad) and any(ctx.needs_input_grad)
         raw, stash = mlp_forward(NET_NOISE, precision.fwd, tensors, pk, batch, z, need, stash_code(precision.fwd, precision.bwd),
                                  precision.variant, hooks.timer if hooks is not None else None)
@@ -524,7 +583,9 @@ class NoiseMlp(torch.autograd.Function):
         else:
             draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
             draw[:, :3] = g
-        pk = mlp_pack(NET_NOISE, pr.bwd, tensors)
+        pk = _packed_for(ctx.hooks, tensors, pr.bwd)
+        if pk is None:
+            pk = mlp_pack(NET_NOISE, pr.bwd, tensors)
         grads, _ = mlp_backward(NET_NOISE, stash_code(pr.fwd, pr.bwd), pr.bwd, tensors, pk, batch, z, draw, stash,
                                 sink=grad_sink(tensors, ctx.hooks), variant=pr.variant)
         o = 2 * _NL[NET_NOISE] + 4   # alpha_linear is dead in NeRF_Noise (helpers:496,505,512): grad None
@@ -649,7 +710,7 @@ class RbkWarpNdc(torch.autograd.Function):
         d_rvw = acts.view(-1)[RBK_RVW_OFFSET:]
         drays = torch.empty_like(rays) if ctx.needs_input_grad[0] else None
         lib.call("lush_rbk_warp_ndc_bwd", lib.ptr(rays), lib.ptr(idx), N, M, lib.ptr(acts), ndc, cx, cy, lib.ptr(_opt(g_batch)),
-                 lib.ptr(_opt(g_ccw)), lib.ptr(mask), lib.ptr(d_rvw), RBK_ACT, lib.ptr(drays), _stream())
+                 lib.ptr(_opt(g_ccw)), lib.ptr(mask), lib.ptr(d_rvw), RBK_ACT, lib.ptr(drays), num_img, _stream())
         grads = _rbk_param_grads(tensors, ctx.hooks, num_img, M, window, acts, d_rvw)
         return (drays, None, None, None, None, None, None, None, None, None, None, None, *grads)
 

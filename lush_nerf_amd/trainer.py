@@ -106,6 +106,7 @@ class Trainer:
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
         # scratch of the loss kernel's reduction (zero once, left zero by every launch: no zero-fill per step)
         self._loss_work = torch.zeros(2, dtype=torch.float32, device=self.flat.param.device) if self.flat.param.is_cuda else None
+        self._pack_plan = None            # ops.PackPlan of the model's networks in the current precision mode
         self._graph = None                # step_graph: the captured step (graphs, static batch / loss, device step state + host mirror)
         self._graph_eager_left = 2        # plain steps before the capture (every lazy initialisation behind the entry points has run)
         self.sync_replicas()
@@ -141,6 +142,34 @@ class Trainer:
         lrate * 0.1**((g-1)/decay), and the very first step the constructor's lrate."""
         g = max(self.global_step - 1, 0)
         return self.lrate * (0.1 ** (g / (self.lrate_decay * 1000)))
+
+    # ------------------------------------------------------------------ weights packed once per step
+    def _pack_entries(self):
+        pr = self.model.precision
+        pn = pr.noise()
+        ent = [(ops.NET_NERF, pr.fwd, self.model.mlp_coarse.tensors(), pr.variant)]
+        if self.model.mlp_fine is not None:
+            ent.append((ops.NET_NERF, pr.fwd, self.model.mlp_fine.tensors(), pr.variant))
+        if pr.bwd != pr.fwd:
+            ent.append((ops.NET_NERF, pr.bwd, self.model.mlp_coarse.tensors(), pr.variant))
+            if self.model.mlp_fine is not None:
+                ent.append((ops.NET_NERF, pr.bwd, self.model.mlp_fine.tensors(), pr.variant))
+        ent.append((ops.NET_NOISE, pn.fwd, self.model.mlp_noise_coarse.tensors(), -1))
+        if pn.bwd != pn.fwd:
+            ent.append((ops.NET_NOISE, pn.bwd, self.model.mlp_noise_coarse.tensors(), -1))
+        return ent
+
+    def _pack_weights(self):
+        """ONE launch re-packs every network's MFMA fragments for this step (ops.PackPlan; the plan is rebuilt when the precision
+        mode or a parameter's address changes) and hands them to the step's ops through the model's hooks."""
+        if not self.flat.param.is_cuda or self._fwd_bwd != self._hip_forward_backward:
+            return
+        ent = self._pack_entries()
+        sig = tuple((int(n), int(p), int(v), tuple(t.data_ptr() for t in ts)) for n, p, ts, v in ent)
+        if self._pack_plan is None or self._pack_plan.signature != sig:
+            self._pack_plan = ops.PackPlan(ent)
+        self._pack_plan.run()
+        self.model.hooks.packed = self._pack_plan.buffers
 
     # ------------------------------------------------------------------ one slice on the GPU
     def _hip_forward_backward(self, batch, a, b, i, draws, frac, force_naive):
@@ -180,6 +209,7 @@ class Trainer:
         hooks = self.model.hooks
         sink_before, hooks.sink = hooks.sink, True
         try:      # dW kernels add straight into the flat gradient (p.grad are views of it)
+            self._pack_weights()
             for a in range(0, N, mb):
                 b = min(a + mb, N)
                 part = self._fwd_bwd(batch, a, b, i, draws, (b - a) / N, force_naive)
@@ -189,7 +219,7 @@ class Trainer:
                 w = 1e-2 if i > self.noisenerf_start_iter else 0.0
                 loss = loss + w * self._consistency(consist, w)
         finally:
-            hooks.sink = sink_before
+            hooks.sink, hooks.packed = sink_before, None
         if self.distributed:
             self._all_reduce()          # RCCL sum over xGMI; the 1/world mean is folded into Adam
         lr = self.lr() if self._lr_next is None else self._lr_next
@@ -226,12 +256,13 @@ class Trainer:
         sink_before, hooks.sink = hooks.sink, True
         hooks.state, hooks.draw_delta = state, 0
         try:
+            self._pack_weights()
             for a in range(0, N, mb):
                 b = min(a + mb, N)
                 part = self._fwd_bwd(batch, a, b, i, None, (b - a) / N, force_naive)
                 loss = part if loss is None else loss + part
         finally:
-            hooks.sink, hooks.state = sink_before, None
+            hooks.sink, hooks.state, hooks.packed = sink_before, None, None
         return loss, hooks.draw_delta
 
     def _body_update(self, force_naive, state, calls):

@@ -699,6 +699,44 @@ def test_step_graph_resynchronises_with_the_host(diag, mode, tmp_path):
     print(f"step_graph after a checkpoint load: losses within {worst:.1e} of the eager steps, parameters within {dp:.1e}")
 
 
+@pytest.mark.parametrize("planes", ["h,h", "2,h", "2,2"])
+def test_pack_plan_equals_per_network_packing(diag, planes):
+    """ops.PackPlan (lush_pack_plan_*: every network of a step re-packed by ONE launch) writes, byte for byte, what
+    lush_mlp_pack_for writes network by network -- the fragments of both directions and the fp32 block, for the NeRF and the
+    noise net in every plane code the mode uses -- and a Trainer.step that takes its weights from the plan gives the loss of a
+    step that packs inside every march."""
+    from lush_nerf_amd import ops, synth
+    from lush_nerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    prec = ops.parse_planes(planes)
+    net = _model(precision=prec, seed=2)
+    tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64)
+    ent = tr._pack_entries()
+    plan = ops.PackPlan(ent)
+    for t in plan.buffers.values():
+        t.zero_()
+    plan.run()
+    for n_, p_, tensors, variant in ent:
+        nbytes = diag.lib.load().lush_mlp_packed_bytes(n_, p_)
+        ref = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        st = diag.lib.mlp_struct(tensors, 8 if n_ == 0 else 4)
+        import ctypes as C
+        diag.lib.call("lush_mlp_pack_for", n_, p_, C.byref(st), diag.lib.ptr(ref), int(variant), ops._stream())
+        got = plan.buffers[(tensors[0].data_ptr(), int(p_))]
+        assert got.numel() == nbytes and torch.equal(got, ref), (n_, p_, variant)
+    # a step through the plan == a step that packs per march
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(64, 9).items()}
+    d = {k: torch.from_numpy(v).to(dev) for k, v in synth.draws(64 * 5, 64, 64, 9).items()}
+    l1 = float(tr.step(b, 0, draws=d))
+    g1 = tr.flat.grad.clone()
+    net2 = _model(precision=prec, seed=2)
+    tr2 = Trainer(net2, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64)
+    tr2._pack_weights = lambda: None           # every march packs for itself
+    l2 = float(tr2.step(b, 0, draws=d))
+    assert abs(l1 - l2) <= 1e-6 * abs(l2), (l1, l2)
+    assert diag.util.relerr(g1, tr2.flat.grad) < 2e-4
+
+
 def test_wide_backward_rows_match_the_half_row_kernel(diag):
     """mlp_wide_bwd_kernel against mlp_chain_bwd_half_kernel (LUSH_VARIANT_BWD_HALF), element by element on what the chain
     leaves behind: every dZ_l row the weight-gradient GEMMs read, the dZv rows with the head gradients in their extra columns,
