@@ -37,8 +37,8 @@ int lush_abi_version(void);   /* 7 (round 3: explicit kernel-variant argument in
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
  * rays [R][11] = [o(3) d(3) near far viewdir(3)]; t_rand [R][S] or NULL
  * (perturb == 0); z [R][S]. */
-int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, float* zero4,
-               lush_stream_t stream);      /* zero4: NULL, or 4 floats this launch also zeroes (lush_composite_bwd's scale4) */
+int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z,
+               lush_stream_t stream);
 /* z of sample `index` of the un-jittered grid (the noise MLP's point,
  * models/lushnerf.py:271, 396, 612): z [R]. */
 int lush_zfixed(const float* rays, int R, int S, int index, int lindisp, float* z, lush_stream_t stream);
@@ -71,15 +71,18 @@ int lush_composite_fwd(const float* raw, const float* z, const float* rays, int 
  * draw [R][S][4] overwritten; drays [R][11]: columns 3..5 accumulate, or -- init_drays != 0 -- the whole row is written
  * (zeros elsewhere: the first pass of a march needs no zero-fill of its own).
  * Folded in so that they cost no launch of their own (any of them may be NULL / 0):
- *   scale4   {scale, 1/scale, 2 work words} of the loss-scaled fp16 gradient chain: scale = the power of two that puts
- *            max |d_raw| into [8, 16) (1 when d_raw is all zero or not finite).  The work words must be ZERO on entry
- *            (lush_zgrid's zero4, or a memset) and are left zero.
+ *   block_max  [lush_composite_bwd_blocks(R)] floats: per-workgroup max |d_raw|, from which lush_loss_scale (one small launch)
+ *              makes the loss scale of the fp16 gradient chain -- instead of a pass of its own over d_raw;
  *   zero_buf / zero_n: floats zeroed by this launch (the scratch a later launch accumulates into). */
+int lush_composite_bwd_blocks(int R);
 int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S,
                        const float* noise, float noise_std, float near_mask, int white_bkgd,
                        const float* g_rgb, const float* g_depth, const float* g_acc,
-                       float* draw, float* drays, float* scale4, float* zero_buf, long long zero_n, int init_drays,
+                       float* draw, float* drays, float* block_max, float* zero_buf, long long zero_n, int init_drays,
                        lush_stream_t stream);
+/* scale2 = {s, 1/s}: s = the power of two that puts max(block_max[0..n)) into [8, 16); 1 when the maximum is 0 or not finite
+ * (the rule of the loss-scaled fp16 gradient chain). */
+int lush_loss_scale(const float* block_max, int n, float* scale2, lush_stream_t stream);
 
 /* ------------------------------------------------------ hierarchical sampling
  * sample_pdf (utils/run_lushnerf_helpers.py:566-609) on bins = mid-points and

@@ -38,9 +38,8 @@ __device__ __forceinline__ float zgrid_at(float near, float far, int i, int S, i
 
 // --------------------------------------------------------------------- z grid
 __global__ void zgrid_kernel(const float* __restrict__ rays, int R, int S, int lindisp,
-                             const float* __restrict__ t_rand, float* __restrict__ z, float* __restrict__ zero4) {
+                             const float* __restrict__ t_rand, float* __restrict__ z) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero4 != nullptr && i < 4) zero4[i] = 0.f;      // (the backward's loss-scale words: armed by the march's first kernel)
     if (i >= (long long)R * S) return;
     const int ray = (int)(i / S), s = (int)(i % S);
     const float near = rays[ray * 11 + 6], far = rays[ray * 11 + 7];
@@ -166,11 +165,12 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_fwd_kernel(Comp
 }
 
 // What the backward of a pass needs besides d_raw, folded into this kernel so that it costs no launch of its own (round 4):
-//   scale4   the fp16 gradient chain's loss scale {scale, 1/scale, work, work} from max |d_raw| (grad_scale_kernel's job; the two
-//            work words must be zero on entry and are left zero), or NULL;
+//   block_max  per-workgroup max |d_raw| (one float per workgroup of this launch, plain stores), or NULL: loss_scale_kernel turns
+//            them into the fp16 gradient chain's loss scale.  (A first version ended in the "last workgroup to finish" pattern
+//            of grad_scale_kernel: 2 x 2048 atomics on one word took this kernel from 27 to 127 us.)
 //   zero_buf a scratch the weight-gradient launch accumulates into (the feature-factor block), zeroed here, or NULL;
 //   init_drays: drays is written whole (zeros outside columns 3..5) instead of added to -- the first pass of a march.
-struct CompBwdExtra { float* scale4; float* zero_buf; long long zero_n; int init_drays; };
+struct CompBwdExtra { float* block_max; float* zero_buf; long long zero_n; int init_drays; };
 
 template <int SPL>
 __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(CompIn c, const float* __restrict__ g_rgb,
@@ -242,34 +242,44 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void composite_bwd_kernel(Comp
         }
     }
   }
-    if (X.scale4 != nullptr) {      // grad_scale_kernel's reduction: the last block to finish writes {scale, 1/scale} and re-arms
+    if (X.block_max != nullptr) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
         __shared__ float sm[RAYS_PER_BLOCK];
         if (lane == 0) sm[threadIdx.x >> 6] = vmax;
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned* work = reinterpret_cast<unsigned*>(X.scale4 + 2);
             float m = 0.f;
 #pragma unroll
             for (int i = 0; i < RAYS_PER_BLOCK; ++i) m = fmaxf(m, sm[i]);
-            if (!(m <= 3.402823466e38f)) m = 3.402823466e38f * 2.f;      // NaN / Inf: propagate as "not finite"
-            atomicMax(work, __float_as_uint(m));
-            __threadfence();
-            if (atomicAdd(work + 1, 1u) == gridDim.x - 1) {
-                const float mx = __uint_as_float(atomicMax(work, 0u));
-                float sc = 1.f;
-                if (mx > 0.f && mx < 3.0e38f) {
-                    int e;
-                    frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
-                    sc = ldexpf(1.f, 4 - e);        // mx * sc in [8, 16)
-                }
-                X.scale4[0] = sc;
-                X.scale4[1] = 1.f / sc;
-                work[0] = 0u;
-                work[1] = 0u;
-            }
+            X.block_max[blockIdx.x] = m;
         }
+    }
+}
+
+// {scale, 1/scale} of the loss-scaled fp16 gradient chain from n per-workgroup maxima of |d_raw|: the power of two that puts
+// the maximum into [8, 16); 1 when d_raw is all zero or not finite (grad_scale_kernel's rule).  One workgroup.
+__global__ __launch_bounds__(256) void loss_scale_kernel(const float* __restrict__ block_max, int n, float* __restrict__ scale2) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = block_max[i];
+        m = (v <= 3.402823466e38f) ? fmaxf(m, v) : __int_as_float(0x7f800000);      // (Inf stays Inf; NaN cannot come out of fmaxf)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        float sc = 1.f;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int e;
+            frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+            sc = ldexpf(1.f, 4 - e);        // mx * sc in [8, 16)
+        }
+        scale2[0] = sc;
+        scale2[1] = 1.f / sc;
     }
 }
 
@@ -1377,9 +1387,9 @@ extern "C" {
 const char* lush_last_error(void) { return g_err.c_str(); }
 int lush_abi_version(void) { return 7; }
 
-int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, float* zero4, lush_stream_t st) {
+int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
-    hipLaunchKernelGGL(zgrid_kernel, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, S_(st), rays, R, S, lindisp, t_rand, z, zero4);
+    hipLaunchKernelGGL(zgrid_kernel, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, S_(st), rays, R, S, lindisp, t_rand, z);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1403,22 +1413,31 @@ int lush_composite_fwd(const float* raw, const float* z, const float* rays, int 
     CHECK_LAUNCH();
     return 0;
 }
+static int composite_bwd_blocks(int R) {
+    // at most 2048 workgroups (8 per CU: what is resident at once) walk the rays
+    int blocks = cdiv(R, RAYS_PER_BLOCK);
+    return blocks > 2048 ? 2048 : blocks;
+}
+int lush_composite_bwd_blocks(int R) { return R > 0 ? composite_bwd_blocks(R) : 0; }
+
 int lush_composite_bwd(const float* raw, const float* z, const float* rays, int R, int S, const float* noise,
                        float noise_std, float near_mask, int white_bkgd, const float* g_rgb, const float* g_depth,
-                       const float* g_acc, float* draw, float* drays, float* scale4, float* zero_buf, long long zero_n,
+                       const float* g_acc, float* draw, float* drays, float* block_max, float* zero_buf, long long zero_n,
                        int init_drays, lush_stream_t st) {
     if (S < 2 || S > 256) return set_error("lush_composite_bwd: S must be in [2,256]");
     if (zero_buf != nullptr && zero_n < 0) return set_error("lush_composite_bwd: zero_n must not be negative");
     CompIn c{raw, z, rays, noise, R, S, noise_std, near_mask, white_bkgd};
-    const CompBwdExtra x{scale4, zero_buf, zero_buf ? zero_n : 0, init_drays};
-    // at most 2048 workgroups (8 per CU: what is resident at once) walk the rays: the loss-scale reduction ends in one atomic
-    // per workgroup on one word.  (1024 left half the chip's wave slots empty: 81 instead of 27 us on the fine pass.)
-    int blocks = cdiv(R, RAYS_PER_BLOCK);
-    if (blocks > 2048) blocks = 2048;
-    dim3 g(blocks), b(RAYS_PER_BLOCK * 64);
+    const CompBwdExtra x{block_max, zero_buf, zero_buf ? zero_n : 0, init_drays};
+    dim3 g(composite_bwd_blocks(R)), b(RAYS_PER_BLOCK * 64);
     if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
     else if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
     else hipLaunchKernelGGL(composite_bwd_kernel<4>, g, b, 0, S_(st), c, g_rgb, g_depth, g_acc, draw, drays, x);
+    CHECK_LAUNCH();
+    return 0;
+}
+int lush_loss_scale(const float* block_max, int n, float* scale2, lush_stream_t st) {
+    if (!block_max || n < 1 || !scale2) return set_error("lush_loss_scale: maxima and destination are required");
+    hipLaunchKernelGGL(loss_scale_kernel, dim3(1), dim3(256), 0, S_(st), block_max, n, scale2);
     CHECK_LAUNCH();
     return 0;
 }

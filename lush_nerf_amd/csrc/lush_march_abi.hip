@@ -102,11 +102,7 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     const float* u = draws && cfg->perturb > 0.f ? draws->u : nullptr;
     const float* noise_f = draws && cfg->raw_noise_std > 0.f ? draws->noise_f : nullptr;
     float* zc = (float*)(w + L.zc);
-    // (the backward's loss-scale work words -- head of the shared backward scratch -- are zeroed by this first kernel of the march)
-    float *scale4 = nullptr, *zero_buf = nullptr;
-    long long zero_n = 0;
-    if (cfg->planes_bwd) mlp_dstash_header(0, cfg->planes_bwd, (long long)R * (two ? Sf : S), w + L.dstash, &scale4, &zero_buf, &zero_n);
-    int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, scale4, st);
+    int rc = lush_zgrid(rays, R, S, cfg->lindisp, t_rand, zc, st);
     if (rc) return rc;
     // weights: packed by the caller once per step (cfg->packed_*), or here into the workspace
     const void* pkc = cfg->packed_coarse;
@@ -165,15 +161,21 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     auto chain = [&](const lush_mlp_params* prm, size_t zoff, size_t rawoff, size_t stashoff, const void* pk_ready, size_t pkboff, bool repack,
                      int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc) -> int {
         const float* z = (const float*)(w + zoff);
-        // the compositing backward also finds the fp16 chain's loss scale, zeroes the weight-gradient scratch and, in the
-        // march's first pass, writes d(ray) whole: no grad_scale launch, no memsets, no zero-fill of drays by the caller
+        // the compositing backward also leaves the per-workgroup maxima of |d_raw| (in the d(point) array, which the chain only
+        // writes afterwards) for the fp16 chain's loss scale, zeroes the weight-gradient scratch and, in the march's first pass,
+        // writes d(ray) whole: no pass over d_raw for the scale, no memsets, no zero-fill of drays by the caller
         float *scale4 = nullptr, *zero_buf = nullptr;
         long long zero_n = 0;
         if (!mlp_dstash_header(0, pb, (long long)R * Sp, x.dstash, &scale4, &zero_buf, &zero_n)) return set_error("lush_march_bwd: bad backward plane code");
+        float* block_max = scale4 ? x.dpts : nullptr;
         int rc = lush_composite_bwd((const float*)(w + rawoff), z, rays, R, Sp, noise, cfg->raw_noise_std, cfg->near_mask, cfg->white_bkgd,
-                                    g_rgb, g_depth, g_acc, x.draw, drays, scale4, zero_buf, zero_n, first_pass ? 1 : 0, st);
+                                    g_rgb, g_depth, g_acc, x.draw, drays, block_max, zero_buf, zero_n, first_pass ? 1 : 0, st);
         first_pass = false;
         if (rc) return rc;
+        if (scale4) {
+            rc = lush_loss_scale(block_max, lush_composite_bwd_blocks(R), scale4, st);
+            if (rc) return rc;
+        }
         const void* pk = pk_ready;
         if (!pk) {
             if (repack) {       // the backward computes with another plane code than the forward: its own fragments

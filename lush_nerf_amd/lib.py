@@ -151,10 +151,12 @@ VIEW_Z, VIEW_RAW, VIEW_WEIGHTS, VIEW_Z_COARSE, VIEW_STASH_COARSE, VIEW_STASH_FIN
 _p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 _SIGS = {
     "lush_abi_version": ([], _i),
-    "lush_zgrid": ([_p, _i, _i, _i, _p, _p, _p, _p], _i),
+    "lush_zgrid": ([_p, _i, _i, _i, _p, _p, _p], _i),
     "lush_zfixed": ([_p, _i, _i, _i, _i, _p, _p], _i),
     "lush_composite_fwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _p], _i),
     "lush_composite_bwd": ([_p, _p, _p, _i, _i, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p], _i),
+    "lush_composite_bwd_blocks": ([_i], _i),
+    "lush_loss_scale": ([_p, _i, _p, _p], _i),
     "lush_sample_merge": ([_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p], _i),
     "lush_pack_rays_fwd": ([_p, _i, _i, _f, _f, _f, _f, _p, _p], _i),
     "lush_pack_rays_bwd": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),

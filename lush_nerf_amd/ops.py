@@ -282,7 +282,7 @@ class MarchCfg:
 def zgrid(batch, S, lindisp, t_rand):
     R = batch.shape[0]
     z = torch.empty(R, S, dtype=torch.float32, device=batch.device)
-    lib.call("lush_zgrid", lib.ptr(batch), R, S, int(lindisp), lib.ptr(t_rand), lib.ptr(z), None, _stream())
+    lib.call("lush_zgrid", lib.ptr(batch), R, S, int(lindisp), lib.ptr(t_rand), lib.ptr(z), _stream())
     return z
 
 
