@@ -296,6 +296,8 @@ size_t lush_mlp_dstash_bytes(int net, int planes, long long P);
  * the first stash_planes (<= planes) bf16 planes of every activation (the backward only needs as
  * many planes as it computes with) plus the encoded inputs.  stash_planes = 0 is inference:
  * the buffer is then only the kernel's gamma-row workspace and nothing is kept for a backward. */
+/* LIMIT: R * S < 2^27 points per launch (forward and backward: the kernels address per-point rows by 32-bit byte offsets from
+ * a scalar base); more is REFUSED with an error -- split the ray batch (the stash of 2^27 points would be 590 GB anyway). */
 int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
                  const void* packed, const lush_mlp_params* prm, float* raw, void* stash, int variant,
                  lush_stream_t stream);

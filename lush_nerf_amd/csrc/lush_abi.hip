@@ -418,7 +418,9 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     if (!stash) return set_error("lush_mlp_fwd: stash (or the inference workspace) is required");
     if (R <= 0 || S <= 0) return set_error("lush_mlp_fwd: empty batch");
     const long long P = (long long)R * S;
-    if (P > 0x7fffffffLL) return set_error("lush_mlp_fwd: too many points for one launch");
+    // the 64-points-per-wave kernels address d_raw / the point rows by 32-bit byte offsets from a scalar base (16 .. 32 bytes per
+    // point): one launch takes at most 2^27 - 1 points (whose stash alone would be 590 GB); split the rays above that
+    if (P >= (1LL << 27)) return set_error("lush_mlp_fwd: at most 2^27 - 1 points per launch (split the ray batch)");
     const StashLayout L = stash_layout(n, nplanes(planes), stash_planes, P);
     const bool chain = mlp_fwd_chain_enabled(planes);
     const int mt = chain ? 128 : (planes == PLANES_F16 ? 64 : mlp_fwd_tile(planes));
@@ -463,6 +465,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     if (planes_b < 1 || planes_b > planes_f || planes_f > 3) return set_error("lush_mlp_bwd: need 1 <= planes_b <= planes_f <= 3");
     if (!stash || !dstash) return set_error("lush_mlp_bwd: stash and dstash are required");
     const long long P = (long long)R * S;
+    if (R <= 0 || S <= 0 || P >= (1LL << 27)) return set_error("lush_mlp_bwd: 1 .. 2^27 - 1 points per launch (32-bit byte offsets; split the ray batch)");
     const StashLayout L = stash_layout(n, planes_f, planes_f, P);   // gamma rows come last: their plane count does not move the others
     const DStashLayout D = dstash_layout(n, planes_b, P);
     hipStream_t st = (hipStream_t)stream;

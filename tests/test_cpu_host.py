@@ -373,3 +373,50 @@ def test_sample_merge_refuses_sizes_beyond_its_lds_arrays():
         rc = l.lush_sample_merge(None, None, 4, S, Ni, None, None, None, None, None, None)
         assert rc != 0, (S, Ni)
         assert b"lush_sample_merge" in l.lush_last_error(), l.lush_last_error()
+
+
+def test_mlp_launch_refuses_more_points_than_its_32_bit_offsets_reach():
+    """The 64-points-per-wave kernels address per-point rows by 32-bit byte offsets from a scalar base: R * S >= 2^27 points in
+    one launch must be refused on the host, before anything is launched (include/lush_march.h, LIMIT at lush_mlp_fwd)."""
+    from lush_nerf_amd import lib
+    l = lib.load()
+    st = lib.MlpParams()
+    one = ctypes.c_void_p(8)        # any non-null pointer: the refusal comes before it is looked at
+    rc = l.lush_mlp_fwd(0, 17, 1, one, one, 1 << 20, 128, one, ctypes.byref(st), one, one, 0, None)
+    assert rc != 0 and b"2^27" in l.lush_last_error(), l.lush_last_error()
+    rc = l.lush_mlp_bwd_chain(0, 17, 17, one, one, 1 << 20, 128, one, ctypes.byref(st), one, one, one, one, 0, None)
+    assert rc != 0 and b"2^27" in l.lush_last_error(), l.lush_last_error()
+
+
+def test_bench_self_launch_builds_the_documented_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` as a CHILD (never an exec) and exits with its code; the
+    subprocess call is replaced here, nothing is launched."""
+    import argparse
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(argparse.Namespace(gpus=4))
+    assert e.value.code == 7                                  # the child's exit code
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # fewer devices than ranks: refused before anything is started
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(argparse.Namespace(gpus=4))
+    assert "only 1 GPU" in str(e.value.code) and not seen
