@@ -44,8 +44,8 @@ if stats:
         for r in rows:
             w.writerow([r["Name"], r["Calls"], f'{float(r["TotalDurationNs"]) / 1e6:.3f}',
                         f'{float(r["AverageNs"]) / 1e6:.4f}', r["Percentage"]])
-    lines.append(f"## rocprofv3 --kernel-trace --stats of `bench.py --variant 32` (planes {planes}, {steps} steps incl. warm-up; "
-                 "LUSH_VARIANT_NO_OVERLAP: kernels one at a time, as in bench.py's kernel-group timing pass)\n")
+    lines.append(f"## rocprofv3 --kernel-trace --stats of the default `bench.py` command (planes {planes}, {steps} steps incl. warm-up and "
+                 f"the kernel-group timing pass; {bench.get('value', '?')} rays/s, {bench.get('ms_per_step', '?')} ms/step inside the profiler)\n")
     lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
     for r in rows[:14]:
         lines.append(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e6:.3f} | '
@@ -53,30 +53,6 @@ if stats:
     if bench.get("kernels"):
         lines.append("\nHIP-event timing inside the same run (bench.py `kernels`): " +
                      ", ".join(f'{k}: {v["avg_ms"]} ms/launch-group' for k, v in bench["kernels"].items()))
-
-# the default command: lush_march_bwd runs the fine pass's weight gradients beside the coarse pass's chain
-ov = sorted(glob.glob(os.path.join(src, "trace_overlap", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
-if ov:
-    try:
-        bo = json.loads([l for l in open(os.path.join(src, "bench_overlap.json")) if l.startswith("{")][-1])
-    except Exception:
-        bo = {}
-    rows = sorted(csv.DictReader(open(ov[0])), key=lambda r: int(r["Start_Timestamp"]))
-    big = [r for r in rows if ("dw_group_kernel<true" in r["Kernel_Name"] or "mlp_wide_bwd_kernel" in r["Kernel_Name"])]
-    pairs = []
-    for i, r in enumerate(big):
-        if "dw_group" in r["Kernel_Name"]:
-            for q in big[i + 1:i + 3]:
-                if "mlp_wide_bwd" in q["Kernel_Name"] and int(q["Start_Timestamp"]) < int(r["End_Timestamp"]):
-                    pairs.append((r, q))
-    lines.append(f"\n## The default command (`bench.py`: {bo.get('value', '?')} rays/s, {bo.get('ms_per_step', '?')} ms/step; calibration "
-                 f"{json.dumps(bo.get('backward_overlap', {}))})\n")
-    lines.append(f"lush_march_bwd ran the fine pass's weight gradients (second stream) beside the coarse pass's chain in {len(pairs)} steps of the trace:\n")
-    lines.append("| step | dw_group (fine) start .. end ms, workgroups, queue | mlp_wide_bwd (coarse) start .. end ms, workgroups, queue |\n|---|---|---|")
-    for n, (r, q) in enumerate(pairs[-4:]):
-        t0 = int(r["Start_Timestamp"])
-        f = lambda x: f'{(int(x["Start_Timestamp"]) - t0) / 1e6:.3f} .. {(int(x["End_Timestamp"]) - t0) / 1e6:.3f}, {int(x["Grid_Size_X"]) // int(x["Workgroup_Size_X"])}, {x["Queue_Id"]}'
-        lines.append(f"| {n} | {f(r)} | {f(q)} |")
 
 traffic = {}
 per = {}
