@@ -50,6 +50,9 @@ if stats:
     for r in rows[:14]:
         lines.append(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e6:.3f} | '
                      f'{float(r["TotalDurationNs"]) / 1e6:.1f} | {r["Percentage"]} |')
+    lines.append("\n(The `__amd_rocclr_fillBufferAligned` / `copyBuffer` rows belong to the kernel-group timing pass: its steps run the march "
+                 "kernel group by kernel group from Python, with torch allocations in between.  The launches of a step of the TIMED "
+                 f"region are listed in `profiles/{tag}_step_trace.txt`.)")
     if bench.get("kernels"):
         lines.append("\nHIP-event timing inside the same run (bench.py `kernels`): " +
                      ", ".join(f'{k}: {v["avg_ms"]} ms/launch-group' for k, v in bench["kernels"].items()))
@@ -88,5 +91,7 @@ if per:
                                     "hbm_bytes_per_step": round(fe + wr), "algorithmic_bytes_per_step": alg[g],
                                     "source": f"profiles/{tag}_summary.md"}
     json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+if bench:
+    json.dump(bench, open(os.path.join(root, "profiles", f"{tag}_bench_line.json"), "w"), indent=1)
 open(os.path.join(root, "profiles", f"{tag}_summary.md"), "w").write("# Profile summary " + tag + "\n\n" + "\n".join(lines) + "\n")
 print("\n".join(lines))

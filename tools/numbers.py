@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""One source of truth for the numbers quoted in DESIGN.md and README.md.
+
+  python tools/numbers.py            # rewrites the blocks between <!-- numbers:NAME --> ... <!-- /numbers:NAME -->
+  python tools/numbers.py --check    # exit 1 if a block is out of date (tests/test_cpu_host.py runs this)
+
+Sources, nothing else: the driver's latest BENCH_rNN.json at the repo root (the HEADLINE: what the driver measured on its
+own box at the end of the previous round), and this round's committed profile artefacts under profiles/ (rNN_bench_line.json =
+the bench line of the profiled run, rNN_bench_kernel_stats.csv, rNN_sq_counters.md, pmc_traffic.json, rNN_step_trace.txt).
+Boxes differ by 2-4 % on the same binary, so a figure always names its source."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PEAK_TF, PEAK_GBS = 2500.0, 8000.0
+
+
+def latest(pattern):
+    fs = sorted(glob.glob(os.path.join(ROOT, pattern)))
+    return fs[-1] if fs else None
+
+
+PIN = None      # --check: the BENCH file the committed status block names (a newer one appears when the driver ends a round)
+
+
+def driver_bench():
+    f = os.path.join(ROOT, PIN) if PIN and os.path.exists(os.path.join(ROOT, PIN)) else latest("BENCH_r[0-9][0-9].json")
+    if not f:
+        return None, None
+    d = json.load(open(f))
+    return os.path.basename(f), d.get("parsed") or d
+
+
+def profile_tag():
+    f = latest("profiles/r[0-9][0-9]_bench_line.json")
+    return os.path.basename(f)[:3] if f else None
+
+
+def blocks():
+    out = {}
+    name, drv = driver_bench()
+    tag = profile_tag()
+    line = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_line.json"))) if tag else {}
+    # ---- status line (README)
+    s = []
+    if drv:
+        evals = drv["config"].get("mlp_evals_per_step", 3932160)
+        frac = 6 * 593408 * evals / (drv["ms_per_step"] * 1e-3) / 1e12 / PEAK_TF        # fwd + dX + dW, algorithmic, of the dense bf16 peak
+        cpu = drv.get("cpu_baseline") or {}
+        s.append(f"**Headline (the driver's own run, `{name}`): {drv['value']:,.0f} input rays/s, {drv['ms_per_step']:.3f} ms/step** "
+                 f"(BASELINE config 2, 1 x MI355X, mode `{drv['config'].get('planes_fwd', '?')}` / `{drv['config'].get('planes_bwd', '?')}`; "
+                 f"whole step {frac:.2f} of the dense bf16 MFMA peak; dominant kernel `{drv['roofline']['kernel']}` at {drv['roofline']['frac']:.2f} of "
+                 f"the {drv['roofline']['bound'].upper()} roof; CPU oracle on the box's {cpu.get('cores', '?')} host threads {cpu.get('value', 0):.1f} rays/s).")
+    if line:
+        s.append(f"This round's profiled run (`profiles/{tag}_bench_line.json`, another box, inside `rocprofv3`): {line['value']:,.0f} rays/s, "
+                 f"{line['ms_per_step']:.3f} ms/step; un-profiled runs of the same tree on this round's boxes: DESIGN.md section 5.")
+    out["status"] = "\n".join(s)
+    # ---- kernel table
+    if line:
+        rows = ["| group | launches / step | avg launch ms (HIP events) | algorithmic TFLOP/s (of 2.5 PF) | algorithmic HBM GB/s (of 8 TB/s) | PMC HBM GB / step (algorithmic) |",
+                "|---|---|---|---|---|---|"]
+        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json")) else {}
+        label = {"mlp_bwd_weights": "dW (`dw_group_kernel`)", "mlp_fwd": "forward (`mlp_wide_fwd_kernel`)", "mlp_bwd_chain": "dX chain (`mlp_wide_bwd_kernel`)"}
+        for g in ("mlp_bwd_weights", "mlp_fwd", "mlp_bwd_chain"):
+            k = line["kernels"][g]
+            t = tr.get(f"{g}:h,h", {})
+            rows.append(f"| {label[g]} | {k['launches_per_step']:.0f} | {k['avg_ms']:.3f} | {k['tflops_algorithmic']:.0f} ({k['frac_mfma']:.2f}) | "
+                        f"{k['hbm_gbs_algorithmic']:.0f} ({k['frac_hbm']:.2f}) | {t.get('hbm_bytes_per_step', 0) / 1e9:.1f} ({t.get('algorithmic_bytes_per_step', 0) / 1e9:.1f}) |")
+        stats = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv")
+        if os.path.exists(stats):
+            avg = {r["kernel"]: float(r["avg_ms"]) for r in csv.DictReader(open(stats))}
+            pick = lambda key: next((v for k, v in avg.items() if key in k), None)
+            rows.append("")
+            rows.append(f"`rocprofv3 --kernel-trace --stats` of the same run (`profiles/{tag}_bench_kernel_stats.csv`), average launch: "
+                        f"`dw_group_kernel<true,true,1>` {pick('dw_group_kernel<true'):.3f} ms, `mlp_wide_fwd_kernel` {pick('mlp_wide_fwd_kernel'):.3f} ms, "
+                        f"`mlp_wide_bwd_kernel` {pick('mlp_wide_bwd_kernel'):.3f} ms.")
+        k = line["kernels"]
+        big = sum(v["ms_per_step"] for v in k.values())
+        rows.append(f"Whole step: {line['step_tflops_algorithmic']:.0f} TFLOP/s algorithmic = {line['step_frac_mfma']:.2f} of the dense bf16 MFMA peak; "
+                    f"the three groups sum to {big:.2f} of the step's {line['ms_per_step']:.2f} ms.")
+        out["kernels"] = "\n".join(rows)
+    # ---- SQ counters
+    sq = os.path.join(ROOT, "profiles", f"{tag}_sq_counters.md") if tag else None
+    if sq and os.path.exists(sq):
+        txt = open(sq).read()
+        rows = ["| kernel | non-MFMA instructions per MFMA | matrix pipe busy / wave cycles | issuing | issue-stalled | parked in waits | LDS conflict share |", "|---|---|---|---|---|---|---|"]
+        for m in re.finditer(r"## (\S+)[^\n]*\n(?:.*\n)*?Derived: ([^\n]*)", txt):
+            d = m.group(2)
+            g = lambda pat: (re.search(pat, d) or [None, "?"])[1]
+            cols = [g(r"per MFMA ([\d.]+)"), g(r"wave cycles = ([\d.]+)"), g(r"issuing (\d+%)"), g(r"issue-stalled (\d+%)"),
+                    g(r"s_barrier (\d+%)"), g(r"active cycles ([\d.]+%)")]
+            rows.append("| `" + m.group(1) + "` | " + " | ".join(cols) + " |")
+        rows.append(f"\n(`profiles/{tag}_sq_counters.md`, `profiles/summarize_sq.py`; per-launch counter values, fine-pass shape.)")
+        out["sq"] = "\n".join(rows)
+    # ---- launches of one timed step
+    st = os.path.join(ROOT, "profiles", f"{tag}_step_trace.txt") if tag else None
+    if st and os.path.exists(st):
+        head = open(st).read().split("\n")[:2]
+        out["step"] = "`profiles/%s_step_trace.txt` (one step of the timed region, `tools/trace_step.py`): %s; %s." % (tag, head[0].strip(), head[1].strip())
+    return out
+
+
+def rewrite(path, blk, check):
+    s = open(path).read()
+    changed = False
+    for name, body in blk.items():
+        pat = re.compile(r"(<!-- numbers:%s -->\n)(.*?)(<!-- /numbers:%s -->)" % (name, name), re.S)
+        m = pat.search(s)
+        if not m:
+            continue
+        body = body + "\n"
+        if m.group(2) != body:
+            changed = True
+            s = s[:m.start(2)] + body + s[m.end(2):]
+    if changed and not check:
+        open(path, "w").write(s)
+    return changed
+
+
+if __name__ == "__main__":
+    check = "--check" in sys.argv
+    if check:      # the committed text is checked against the driver file IT names: the driver adds a newer one after the round
+        m = re.search(r"the driver's own run, `(BENCH_r\d\d\.json)`", open(os.path.join(ROOT, "README.md")).read())
+        PIN = m.group(1) if m else None
+    blk = blocks()
+    stale = [f for f in ("DESIGN.md", "README.md") if rewrite(os.path.join(ROOT, f), blk, check)]
+    if check and stale:
+        print("out of date (run tools/numbers.py):", stale)
+        sys.exit(1)
+    print("up to date" if not stale else f"rewrote {stale}")
