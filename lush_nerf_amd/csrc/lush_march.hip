@@ -811,34 +811,48 @@ __global__ __launch_bounds__(1024) void rbk_warp_ndc_bwd_kernel(const float* __r
 // table directly: every one of its ~20 dependent stages paid global-memory latency (0.47 ms for a few MFLOP).
 constexpr int RBK_LS = LUSH_RBK_ACT_STRIDE + 1;
 
-__device__ void rbk_dense(const float* W, const float* b, const float* x, float* y, int n, int IN, int OUT, int relu) {
+// A stage's weight matrix goes global -> LDS once, coalesced (row pitch IN + 1), one stage AHEAD of its use (two staging
+// buffers): the dense loops then read weights and activations from LDS only.  Round 3 read W[o][k] from L2 inside the k loop:
+// ~20 dependent stages each paid several L2 round trips (36 us forward, 79 us backward for a few MFLOP).
+constexpr int RBK_WB = 64 * 65;                 // floats per staging buffer (the largest stage: 64 x 64)
+__device__ __forceinline__ void rbk_stage_w(const float* __restrict__ W, float* __restrict__ wb, int IN, int OUT) {
+    for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) wb[(t / IN) * (IN + 1) + t % IN] = W[t];
+}
+// y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]) from the staged W (same summation order as before: bias first, k ascending)
+__device__ __forceinline__ void rbk_dense_lds(const float* __restrict__ wb, const float* __restrict__ b, const float* x, float* y, int n,
+                                              int IN, int OUT, int relu) {
     for (int t = threadIdx.x; t < n * OUT; t += blockDim.x) {
         const int i = t % n, o = t / n;
         float s = b[o];
-        const float* w = W + o * IN;
+        const float* w = wb + o * (IN + 1);
         const float* xi = x + i * RBK_LS;
         for (int k = 0; k < IN; ++k) s += w[k] * xi[k];
         y[i * RBK_LS + o] = relu ? fmaxf(s, 0.f) : s;
     }
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
                                                           float* __restrict__ acts) {
-    extern __shared__ float rbk_lds[];          // [n][RBK_LS]
+    extern __shared__ float rbk_lds[];          // [n][RBK_LS] activations, then two weight staging buffers
     float* A = rbk_lds;
+    float* wb[2] = {rbk_lds + n * RBK_LS, rbk_lds + n * RBK_LS + RBK_WB};
     const int ST = LUSH_RBK_ACT_STRIDE;
+    // the ten dense stages in order; stage s + 1's weights are staged while stage s computes
+    const float* W[10] = {p.w_trunk[0], p.w_trunk[1], p.w_trunk[2], p.w_trunk[3], p.w_rb, p.w_vb, p.w_wb, p.w_r, p.w_v, p.w_w};
+    const float* B[10] = {p.b_trunk[0], p.b_trunk[1], p.b_trunk[2], p.b_trunk[3], p.b_rb, p.b_vb, p.b_wb, p.b_r, p.b_v, p.b_w};
+    const int XO[10] = {RA_E, RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_H0 + 192, RA_H0 + 192, RA_HR, RA_HV, RA_HW};
+    const int YO[10] = {RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_HR, RA_HV, RA_HW, RA_R, RA_V, RA_WS};
+    const int IN[10] = {64, 64, 64, 64, 64, 64, 64, 32, 32, 32};
+    const int OUT[10] = {64, 64, 64, 64, 32, 32, 32, 3 * M, 3 * M, M + 1};
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) A[(t / 64) * RBK_LS + RA_E + (t % 64)] = p.embed[t];
+    rbk_stage_w(W[0], wb[0], IN[0], OUT[0]);
     __syncthreads();
-    for (int l = 0; l < 4; ++l)
-        rbk_dense(p.w_trunk[l], p.b_trunk[l], A + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1)), A + RA_H0 + 64 * l, n, 64, 64, 1);
-    const float* h3 = A + RA_H0 + 192;
-    rbk_dense(p.w_rb, p.b_rb, h3, A + RA_HR, n, 64, 32, 1);
-    rbk_dense(p.w_vb, p.b_vb, h3, A + RA_HV, n, 64, 32, 1);
-    rbk_dense(p.w_wb, p.b_wb, h3, A + RA_HW, n, 64, 32, 1);
-    rbk_dense(p.w_r, p.b_r, A + RA_HR, A + RA_R, n, 32, 3 * M, 0);
-    rbk_dense(p.w_v, p.b_v, A + RA_HV, A + RA_V, n, 32, 3 * M, 0);
-    rbk_dense(p.w_w, p.b_w, A + RA_HW, A + RA_WS, n, 32, M + 1, 0);
+#pragma unroll
+    for (int st = 0; st < 10; ++st) {
+        if (st + 1 < 10) rbk_stage_w(W[st + 1], wb[(st + 1) & 1], IN[st + 1], OUT[st + 1]);
+        rbk_dense_lds(wb[st & 1], B[st], A + XO[st], A + YO[st], n, IN[st], OUT[st], st < 7);
+        __syncthreads();
+    }
     for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
         const int i = t / (3 * M), o = t % (3 * M);
         A[i * RBK_LS + RA_R + o] *= window;
@@ -857,24 +871,18 @@ __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, in
     for (int t = threadIdx.x; t < n * ST; t += blockDim.x) acts[t] = (t % ST) < RA_WN + 8 ? A[(t / ST) * RBK_LS + (t % ST)] : 0.f;
 }
 
-// dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
-__device__ void rbk_dense_bwd_x(const float* W, const float* dz, float* dx, const float* gate, int n, int IN, int OUT,
-                                int accumulate) {
+// dx[i][k] = [gate[i][k] > 0] * (sum_o W[o][k] dz[i][o] (+ dx[i][k])) from the staged W (row pitch IN + 1); o ascending, the
+// previous value added last, the gate applied to the total -- the arithmetic of round 3's separate passes
+__device__ __forceinline__ void rbk_dense_bwd_x_lds(const float* __restrict__ wb, const float* dz, float* dx, const float* gate, int n,
+                                                    int IN, int OUT, int accumulate) {
     for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
         const int i = t % n, k = t / n;
         float s = 0.f;
         const float* zi = dz + i * RBK_LS;
-        for (int o = 0; o < OUT; ++o) s += W[o * IN + k] * zi[o];
+        for (int o = 0; o < OUT; ++o) s += wb[o * (IN + 1) + k] * zi[o];
         if (accumulate) s += dx[i * RBK_LS + k];
+        if (gate && !(gate[i * RBK_LS + k] > 0.f)) s = 0.f;
         dx[i * RBK_LS + k] = s;
-    }
-    __syncthreads();
-    if (gate) {
-        for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
-            const int i = t % n, k = t / n;
-            if (!(gate[i * RBK_LS + k] > 0.f)) dx[i * RBK_LS + k] = 0.f;
-        }
-        __syncthreads();
     }
 }
 __device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, float* db, int n, int IN, int OUT, int accumulate) {
@@ -901,6 +909,7 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
     extern __shared__ float rbk_lds[];
     float* A = rbk_lds;
     float* sc = rbk_lds + n * RBK_LS;
+    float* wb[2] = {rbk_lds + 2 * n * RBK_LS, rbk_lds + 2 * n * RBK_LS + RBK_WB};
     const int ST = LUSH_RBK_ACT_STRIDE;
     for (int t = threadIdx.x; t < n * ST; t += blockDim.x) {
         A[(t / ST) * RBK_LS + (t % ST)] = acts[t];
@@ -922,25 +931,26 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
         }
     }
     __syncthreads();
-    rbk_dense_bwd_w(sc + RA_R, A + RA_HR, g.w_r, g.b_r, n, 32, 3 * M, accumulate);
-    rbk_dense_bwd_w(sc + RA_V, A + RA_HV, g.w_v, g.b_v, n, 32, 3 * M, accumulate);
-    rbk_dense_bwd_w(sc + RA_WS, A + RA_HW, g.w_w, g.b_w, n, 32, M + 1, accumulate);
-    rbk_dense_bwd_x(p.w_r, sc + RA_R, sc + RA_HR, A + RA_HR, n, 32, 3 * M, 0);
-    rbk_dense_bwd_x(p.w_v, sc + RA_V, sc + RA_HV, A + RA_HV, n, 32, 3 * M, 0);
-    rbk_dense_bwd_x(p.w_w, sc + RA_WS, sc + RA_HW, A + RA_HW, n, 32, M + 1, 0);
-    const float* h3 = A + RA_H0 + 192;
-    rbk_dense_bwd_w(sc + RA_HR, h3, g.w_rb, g.b_rb, n, 64, 32, accumulate);
-    rbk_dense_bwd_w(sc + RA_HV, h3, g.w_vb, g.b_vb, n, 64, 32, accumulate);
-    rbk_dense_bwd_w(sc + RA_HW, h3, g.w_wb, g.b_wb, n, 64, 32, accumulate);
-    float* dh3 = sc + RA_H0 + 192;
-    rbk_dense_bwd_x(p.w_rb, sc + RA_HR, dh3, nullptr, n, 64, 32, 0);
-    rbk_dense_bwd_x(p.w_vb, sc + RA_HV, dh3, nullptr, n, 64, 32, 1);
-    rbk_dense_bwd_x(p.w_wb, sc + RA_HW, dh3, h3, n, 64, 32, 1);
-    for (int l = 3; l >= 0; --l) {
-        const float* x = A + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_w(sc + RA_H0 + 64 * l, x, g.w_trunk[l], g.b_trunk[l], n, 64, 64, accumulate);
-        float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_x(p.w_trunk[l], sc + RA_H0 + 64 * l, dx, l == 0 ? nullptr : x, n, 64, 64, 0);
+    // ten dx stages (heads r, v, w; branches rb, vb, wb into one d h3; trunk 3..0), each from weights staged one stage ahead;
+    // the weight gradients of a stage read LDS only and need no barrier of their own
+    const float* W[10] = {p.w_r, p.w_v, p.w_w, p.w_rb, p.w_vb, p.w_wb, p.w_trunk[3], p.w_trunk[2], p.w_trunk[1], p.w_trunk[0]};
+    const int IN[10] = {32, 32, 32, 64, 64, 64, 64, 64, 64, 64};
+    const int OUT[10] = {3 * M, 3 * M, M + 1, 32, 32, 32, 64, 64, 64, 64};
+    const int ZO[10] = {RA_R, RA_V, RA_WS, RA_HR, RA_HV, RA_HW, RA_H0 + 192, RA_H0 + 128, RA_H0 + 64, RA_H0};
+    const int XO[10] = {RA_HR, RA_HV, RA_HW, RA_H0 + 192, RA_H0 + 192, RA_H0 + 192, RA_H0 + 128, RA_H0 + 64, RA_H0, RA_E};
+    const int GATE[10] = {1, 1, 1, 0, 0, 1, 1, 1, 1, 0};       // ReLU gate of the stage's input activations (d h3: after the third addend)
+    const int ACC[10] = {0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
+    float* gw[10] = {g.w_r, g.w_v, g.w_w, g.w_rb, g.w_vb, g.w_wb, g.w_trunk[3], g.w_trunk[2], g.w_trunk[1], g.w_trunk[0]};
+    float* gb[10] = {g.b_r, g.b_v, g.b_w, g.b_rb, g.b_vb, g.b_wb, g.b_trunk[3], g.b_trunk[2], g.b_trunk[1], g.b_trunk[0]};
+    rbk_stage_w(W[0], wb[0], IN[0], OUT[0]);
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 10; ++st) {
+        if (st + 1 < 10) rbk_stage_w(W[st + 1], wb[(st + 1) & 1], IN[st + 1], OUT[st + 1]);
+        // dW / db of this stage: dz (complete since the previous barrier) x the stage's input activations
+        rbk_dense_bwd_w(sc + ZO[st], A + XO[st], gw[st], gb[st], n, IN[st], OUT[st], accumulate);
+        rbk_dense_bwd_x_lds(wb[st & 1], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, n, IN[st], OUT[st], ACC[st]);
+        __syncthreads();
     }
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {
         const float v = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
@@ -1502,7 +1512,7 @@ int lush_consist_loss_fwd_bwd(const float* rgb, const float* cert, int V, int ns
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_fwd: no images");
-    const size_t lds = (size_t)num_img * RBK_LS * sizeof(float);
+    const size_t lds = ((size_t)num_img * RBK_LS + 2 * RBK_WB) * sizeof(float);
     if (lds > 160 * 1024) {     // table larger than the LDS: global-memory stages
         hipLaunchKernelGGL(rbk_mlp_fwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts);
     } else {
@@ -1517,7 +1527,7 @@ int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window,
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
     if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_mlp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
-    const size_t lds = (size_t)2 * num_img * RBK_LS * sizeof(float);
+    const size_t lds = ((size_t)2 * num_img * RBK_LS + 2 * RBK_WB) * sizeof(float);
     if (lds > 160 * 1024) {
         hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate, rvw_stride);
     } else {
