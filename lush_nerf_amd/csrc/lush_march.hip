@@ -812,8 +812,10 @@ __global__ __launch_bounds__(1024) void rbk_warp_ndc_bwd_kernel(const float* __r
 constexpr int RBK_LS = LUSH_RBK_ACT_STRIDE + 1;
 
 // A stage's weight matrix goes global -> LDS once, coalesced (row pitch IN + 1), one stage AHEAD of its use (two staging
-// buffers): the dense loops then read weights and activations from LDS only.  Round 3 read W[o][k] from L2 inside the k loop:
-// ~20 dependent stages each paid several L2 round trips (36 us forward, 79 us backward for a few MFLOP).
+// buffers): the dense loops then read weights and activations from LDS only.  (Measured: no faster than reading W[o][k] from L2
+// inside the k loop, 38 / 80 us forward / backward either way -- the ten stages are bound by the ONE CU's LDS port at 4-byte
+// reads, 2 per multiply-add: 16 waves x 256 ds_read_b32 x 2 cycles = 3.4 us per 64 x 64 stage.  What would move it is the
+// exact-fp32 MFMA (32x32x2) for these 30 x 64 x 64 products)
 constexpr int RBK_WB = 64 * 65;                 // floats per staging buffer (the largest stage: 64 x 64)
 __device__ __forceinline__ void rbk_stage_w(const float* __restrict__ W, float* __restrict__ wb, int IN, int OUT) {
     for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) wb[(t / IN) * (IN + 1) + t % IN] = W[t];
