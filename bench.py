@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="developer A/B: lib.VARIANT_* bits, an older kernel for the same work "
                     "(include/lush_march.h); 0 = the product's choice, the only value a reported line may carry")
+    ap.add_argument("--so", type=str, default=None, help="developer A/B: another build of the library (tools/build_variant.py); the line "
+                    "then carries its path under `library` -- a reported line has none")
     ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
     ap.add_argument("--config", type=str, default="C2", choices=["C2", "C3", "C5"],
                     help="BASELINE config timed as the headline workload (C2 = the one the metric is quoted on)")
@@ -225,6 +227,8 @@ def main():
 
     from lush_nerf_amd import lib, ops, synth
     from lush_nerf_amd.trainer import Trainer
+    if a.so:
+        lib.use_library(a.so)
     lib.load()
     t_start = time.perf_counter()
 
@@ -298,17 +302,19 @@ def main():
         """BASELINE config 1 (N_rand 256, 32+0, naive): NeRFAll.forward cannot take N_importance = 0 (it indexes
         extras['rgb0']), so the entry is render_infer, as in the reference's own CPU-runnable case."""
         c = CONFIGS["C1"]
-        batches = make_batches(c["n_rand"])
+        from lush_nerf_amd.trainer import BlobBatch
+        batches = [BlobBatch(b) for b in make_batches(c["n_rand"])]      # per-step inputs in one buffer: one copy per replay
         net = make_model(model_args(0), dev, ops.Precision(pf, pb)).train()
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, c["ns"], 0, kernel_start_iter=1 << 30, distributed=True)
         K = tr.K
 
         state = torch.zeros(lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
-        static = {k: v.clone() for k, v in batches[0].items()}
+        static = batches[0].clone_static()
 
         def one(i, graph_body=False):
             b = static if graph_body else batches[i % n_batches]
             tr.flat.grad.zero_()
+            tr._pack_weights()                   # one launch for every network (ops.PackPlan), as Trainer.step does
             rays = ops.gen_rays(b["c2w"], b["view"], b["px"], b["py"], K)
             if graph_body:      # rate, Adam step count and draw counter from the device step state (include/lush_march.h)
                 net.hooks.state, net.hooks.draw_delta = state, 0
@@ -316,7 +322,10 @@ def main():
                 synth.H_DEF, synth.W_DEF, K, 1 << 15, rays=rays, perturb=1., N_importance=0, N_samples=c["ns"],
                 use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., retraw=True)
             tm = net.tonemapping(rgb)
-            ops.TrainLoss.apply(tm, tm, b["target"]).backward()
+            # the loss and its gradient in one kernel, fed to autograd directly (run_lushnerf.py:652-661 with rgb0 = rgb: N_importance = 0)
+            _, ga, gb = ops.train_loss_grads(tm, tm, b["target"], 1.0, work=tr._loss_work)
+            tm.backward(ga + gb)
+            net.hooks.packed = None
             a0, a1 = tr.flat.segments[0]
             if graph_body:
                 calls, net.hooks.state = net.hooks.draw_delta, None
@@ -347,8 +356,7 @@ def main():
                 one(0, graph_body=True)
 
             def replay(i):
-                for k, v in batches[i % n_batches].items():
-                    static[k].copy_(v, non_blocking=True)
+                static.load(batches[i % n_batches])
                 graph.replay()
             for i in range(warmup):
                 replay(i)
@@ -359,6 +367,7 @@ def main():
             sync()
         finally:
             net.hooks.sink = False
+            net.hooks.packed = None
         dt = time.perf_counter() - t0
         del tr, net, graph
         return dt, dt_eager
@@ -505,6 +514,8 @@ def main():
                  "h,1": "forward ONE fp16 plane (outputs within 3e-5 of fp32: inside the 1e-4 bound; end-to-end "
                         "gradients 4e-2..7e-2 from the reference fixtures because the larger forward rounding flips "
                         "more ReLU kinks), backward plain bf16 -- optional faster mode, not the headline"}
+        if a.so:
+            out["library"] = os.path.abspath(a.so)
         if others:
             out["modes"] = {m: {"value": round(a.n_rand * world * osteps / odt, 1),
                                 "ms_per_step": round(odt / osteps * 1e3, 3),

@@ -254,9 +254,12 @@ void build_pack_table_half_bwd(const lush_mlp_params* p, PackTable& T, int& bloc
 int dw_splits(long long Ppad) {
     int dev = 0, s = 256;      // one 256x256-tile workgroup per CU of the calling thread's device
     if (current_device_cus(dev, s) != 0) s = 256;
-    // every workgroup ends a layer with 256 KB of atomics and starts it with a ring refill: give it at least 128
-    // points (the 4096-point noise net ran 128 workgroups of one tile each: 189 us for 7 tiny GEMMs)
-    const long long max_s = Ppad / 128 > 0 ? Ppad / 128 : 1;
+    // every workgroup ends a layer with 256 KB of atomics and starts it with a ring refill: give it at least LUSH_DW_MIN_PTS
+    // points (the 4096-point noise net ran 128 workgroups of one tile each: 189 us for 7 tiny GEMMs; 128 points each: 69 us)
+#ifndef LUSH_DW_MIN_PTS
+#define LUSH_DW_MIN_PTS 128
+#endif
+    const long long max_s = Ppad / LUSH_DW_MIN_PTS > 0 ? Ppad / LUSH_DW_MIN_PTS : 1;
     if (s > max_s) s = (int)max_s;
     return s < 1 ? 1 : s;
 }

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: build a VARIANT of liblush_march.so next to the product (profiling / timing-ablation builds).
 
-  python tools/build_variant.py --out build/wide_prof.so --flags "-DLUSH_PROF"
-  python tools/build_variant.py --out build/noconv.so --flags "-DLUSH_ABL_NOCONV" [--no-audit]
+  python tools/build_variant.py --out build/wide_prof.so --flags=-DLUSH_PROF            (note the "=": the value starts with a dash)
+  python tools/build_variant.py --out build/noconv.so "--flags=-DLUSH_ABL_NOCONV -DX=1" [--no-audit]
 
 The product build (lib.build(), __graft_entry__.build()) takes no flags from anywhere; this is the only way to compile the
 -DLUSH_ABL_* branches (wrong results by construction: timing only) and it never writes the product's path.  The ISA audit
