@@ -149,6 +149,54 @@ def cpu_baseline(n_rand, n_samples, n_importance, steps=5, warmup=2, c1_steps=5,
                                   f"backward, median of {c1_steps} after {warmup} warm-up"}}
 
 
+def measure_traffic(argv_tail, kernel_key, progress=None, timeout=240):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this very command under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains: MI355X_MICROARCH.md, TCC slots), each
+    a fresh process started as a CHILD (the parent keeps running; nothing is exec'ed).  FETCH_SIZE is doubled (gfx950 reports
+    half of a wide coalesced stream); both counters are in KiB.  Returns a dict, or None when rocprofv3 is missing or a pass
+    fails (the caller then quotes profiles/pmc_traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None           # this process already runs under a profiler: no nested tool
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="lush_pmc_", dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp", MASTER_PORT=str(29600 + os.getpid() % 300))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = [prof, "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), *argv_tail]
+            if progress:
+                progress(f"  rocprofv3 --pmc {c} pass of the same command (child process)")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            total, launches = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if kernel_key in row["Kernel_Name"] and row["Counter_Name"] == c:
+                    total += float(row["Counter_Value"]) * 1024.0 * (2.0 if c == "FETCH_SIZE" else 1.0)
+                    launches.add(row["Dispatch_Id"])
+            if not launches:
+                return None
+            out[c] = total / len(launches)
+            out[c + "_launches"] = len(launches)
+    return {"hbm_bytes_per_launch": round(out["FETCH_SIZE"] + out["WRITE_SIZE"]), "fetch_bytes_per_launch": round(out["FETCH_SIZE"]),
+            "write_bytes_per_launch": round(out["WRITE_SIZE"]), "launches_counted": out["FETCH_SIZE_launches"],
+            "source": "measured in this run: child `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same command "
+                      "(FETCH_SIZE x2: gfx950 correction), average over the kernel's launches"}
+
+
 CONFIGS = {   # BASELINE.json configs (SURVEY 8d): input rays per GPU, N_samples, N_importance, blur kernel on, micro-batch
     "C1": dict(n_rand=256, ns=32, ni=0, kernel=False, micro=0),
     "C2": dict(n_rand=4096, ns=64, ni=64, kernel=True, micro=0),
@@ -192,6 +240,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="developer A/B: lib.VARIANT_* bits, an older kernel for the same work "
                     "(include/lush_march.h); 0 = the product's choice, the only value a reported line may carry")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second, kernel-group-timed pass over the steps (profiling "
+                    "runs: the process then launches exactly what the timed region launches; the line carries no `kernels` / `roofline`)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic (two child rocprofv3 --pmc passes of this "
+                    "command, rank 0, N = 1 only); quote profiles/pmc_traffic.json instead")
     ap.add_argument("--so", type=str, default=None, help="developer A/B: another build of the library (tools/build_variant.py); the line "
                     "then carries its path under `library` -- a reported line has none")
     ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
@@ -281,11 +333,13 @@ def main():
         # kernel groups: the SAME steps once more with HIP events around each MLP kernel group on the launch stream.  The
         # timed region above runs the march as one C-ABI call per direction (lush_march_fwd / lush_march_bwd); with the
         # timer set the same kernels are launched group by group through the piecewise entry points.
-        timer = net.hooks.timer = ops.KernelTimer()
-        for i in range(steps):
-            tr.step(batches[(warmup + i) % n_batches], warmup + steps + i)
-        sync()
-        net.hooks.timer = None
+        timer = ops.KernelTimer()
+        if not a.no_kernel_pass:
+            net.hooks.timer = timer
+            for i in range(steps):
+                tr.step(batches[(warmup + i) % n_batches], warmup + steps + i)
+            sync()
+            net.hooks.timer = None
         tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)       # the slowest rank's clock
         dt = float(tdt.item())
@@ -464,15 +518,26 @@ def main():
         if dom:
             k = kern[dom]
             hbm_bound = k["frac_hbm"] >= k["frac_mfma_executed"]      # the roof this kernel would hit first
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):     # per-launch HBM bytes from the separate rocprofv3 --pmc passes of THIS command
-                traffic = json.load(open(tpath)).get(f"{dom}:{a.planes}")
+            traffic, traffic_source = None, None
+            dom_kernel = {"mlp_bwd_weights": "dw_group_kernel<true", "mlp_fwd": "mlp_wide_fwd_kernel", "mlp_bwd_chain": "mlp_wide_bwd_kernel"}.get(dom)
+            if world == 1 and not a.no_traffic and dom_kernel and a.planes == "h,h":
+                tail = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--also=", "--extra=", "--no-kernel-pass", "--no-traffic",
+                        "--planes", a.planes, "--config", a.config, "--variant", str(a.variant)] + (["--so", a.so] if a.so else [])
+                torch.cuda.empty_cache()
+                traffic = measure_traffic(tail, dom_kernel, progress)
+                if traffic:
+                    traffic_source = traffic.pop("source")
+                    traffic["algorithmic_bytes_per_launch"] = round(k["hbm_gbs_algorithmic"] * 1e9 * k["avg_ms"] * 1e-3)
+            if traffic is None:
+                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(tpath):     # per-launch HBM bytes from the separate rocprofv3 --pmc passes of profiles/collect.sh
+                    traffic = json.load(open(tpath)).get(f"{dom}:{a.planes}")
+                traffic_source = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; not re-measured in this run)"
             roof = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": k["hbm_gbs_algorithmic"] if hbm_bound else k["tflops_algorithmic"],
                     "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": k["frac_hbm"] if hbm_bound else k["frac_mfma"], "traffic": traffic,
-                    "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; not re-measured in this run)",
+                    "traffic_source": traffic_source,
                     "executed_mfma_frac": k["frac_mfma_executed"],
                     "note": "dominant kernel group by time; achieved = algorithmic bytes (or 2*593408 FLOP) per MLP "
                             "evaluation x evaluations per launch / average launch time from HIP events on the launch stream; "
