@@ -833,8 +833,14 @@ __device__ __forceinline__ void rbk_dense_lds(const float* __restrict__ wb, cons
     }
 }
 
-__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n, int M, float window,
-                                                          float* __restrict__ acts) {
+// Images are independent in the forward, so workgroup b takes images [b ipb, b ipb + ipb): the ten stages of ONE workgroup were
+// bound by its CU's LDS port (38 us for 30 images); eight workgroups of four images take ~1/6 of that.
+__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n_all, int M, float window,
+                                                          float* __restrict__ acts, int ipb) {
+    const int img0 = blockIdx.x * ipb;
+    const int n = n_all - img0 < ipb ? n_all - img0 : ipb;
+    p.embed += (long long)img0 * 64;
+    acts += (long long)img0 * LUSH_RBK_ACT_STRIDE;
     extern __shared__ float rbk_lds[];          // [n][RBK_LS] activations, then two weight staging buffers
     float* A = rbk_lds;
     float* wb[2] = {rbk_lds + n * RBK_LS, rbk_lds + n * RBK_LS + RBK_WB};
@@ -887,26 +893,37 @@ __device__ __forceinline__ void rbk_dense_bwd_x_lds(const float* __restrict__ wb
         dx[i * RBK_LS + k] = s;
     }
 }
+// accumulate: 0 = overwrite, 1 = add (one workgroup), 2 = atomic add (several workgroups, each with its own images)
 __device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, float* db, int n, int IN, int OUT, int accumulate) {
     for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
         const int o = t / IN, k = t % IN;
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o] * x[i * RBK_LS + k];
-        dW[t] = accumulate ? dW[t] + s : s;
+        if (accumulate == 2) atomicAdd(dW + t, s);
+        else dW[t] = accumulate ? dW[t] + s : s;
     }
     for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o];
-        db[o] = accumulate ? db[o] + s : s;
+        if (accumulate == 2) atomicAdd(db + o, s);
+        else db[o] = accumulate ? db[o] + s : s;
     }
     // (no barrier: dW / db are outputs only; the adjoints a later stage overwrites are guarded by that stage's barrier)
 }
 
-__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n, int M, float window,
+// Workgroup b takes images [b ipb, b ipb + ipb): d(activation) is per image, the weight gradients are sums over the images and
+// leave by atomics when there are several workgroups (only when adding into buffers that hold values: accumulate != 0).
+__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n_all, int M, float window,
                                                           const float* __restrict__ acts,
                                                           const float* __restrict__ d_rvw, lush_rbk_grads g,
                                                           float* __restrict__ /*scratch: unused since the LDS version*/, int accumulate,
-                                                          int RS /* floats between two images' rows of d_rvw */) {
+                                                          int RS /* floats between two images' rows of d_rvw */, int ipb) {
+    const int img0 = blockIdx.x * ipb;
+    const int n = n_all - img0 < ipb ? n_all - img0 : ipb;
+    acts += (long long)img0 * LUSH_RBK_ACT_STRIDE;
+    d_rvw += (long long)img0 * RS;
+    g.embed += (long long)img0 * 64;
+    if (gridDim.x > 1) accumulate = 2;
     // LDS: activations [n][RBK_LS] then adjoints of the pre-activations in the same per-image layout
     extern __shared__ float rbk_lds[];
     float* A = rbk_lds;
@@ -954,57 +971,14 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
         rbk_dense_bwd_x_lds(wb[st & 1], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, n, IN[st], OUT[st], ACC[st]);
         __syncthreads();
     }
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {
+    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {      // (an image's embedding row belongs to one workgroup)
         const float v = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
         g.embed[t] = accumulate ? g.embed[t] + v : v;
     }
 }
 
-// Fallback for image counts whose tables do not fit the LDS (num_img > 39): the same stages on the global tables.
-__device__ void rbk_dense_g(const float* W, const float* b, const float* x, int xs, float* y, int ys, int n, int IN,
-                          int OUT, int relu) {
-    for (int t = threadIdx.x; t < n * OUT; t += blockDim.x) {
-        const int i = t / OUT, o = t % OUT;
-        float s = b[o];
-        for (int k = 0; k < IN; ++k) s += W[o * IN + k] * x[i * xs + k];
-        y[i * ys + o] = relu ? fmaxf(s, 0.f) : s;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel_g(lush_rbk_params p, int n, int M, float window,
-                                                          float* __restrict__ acts) {
-    const int ST = LUSH_RBK_ACT_STRIDE;
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) acts[(t / 64) * ST + RA_E + (t % 64)] = p.embed[t];
-    __syncthreads();
-    for (int l = 0; l < 4; ++l)
-        rbk_dense_g(p.w_trunk[l], p.b_trunk[l], acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1)), ST,
-                  acts + RA_H0 + 64 * l, ST, n, 64, 64, 1);
-    const float* h3 = acts + RA_H0 + 192;
-    rbk_dense_g(p.w_rb, p.b_rb, h3, ST, acts + RA_HR, ST, n, 64, 32, 1);
-    rbk_dense_g(p.w_vb, p.b_vb, h3, ST, acts + RA_HV, ST, n, 64, 32, 1);
-    rbk_dense_g(p.w_wb, p.b_wb, h3, ST, acts + RA_HW, ST, n, 64, 32, 1);
-    rbk_dense_g(p.w_r, p.b_r, acts + RA_HR, ST, acts + RA_R, ST, n, 32, 3 * M, 0);
-    rbk_dense_g(p.w_v, p.b_v, acts + RA_HV, ST, acts + RA_V, ST, n, 32, 3 * M, 0);
-    rbk_dense_g(p.w_w, p.b_w, acts + RA_HW, ST, acts + RA_WS, ST, n, 32, M + 1, 0);
-    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
-        const int i = t / (3 * M), o = t % (3 * M);
-        acts[i * ST + RA_R + o] *= window;
-        acts[i * ST + RA_V + o] *= window;
-    }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float sum = 0.f;
-        for (int m = 0; m <= M; ++m) {
-            const float s = 1.f / (1.f + expf(-acts[i * ST + RA_WS + m]));
-            acts[i * ST + RA_WS + m] = s;
-            sum += s;
-        }
-        for (int m = 0; m <= M; ++m) acts[i * ST + RA_WN + m] = acts[i * ST + RA_WS + m] / (sum + 1e-10f);
-    }
-    for (int t = threadIdx.x; t < n * (ST - RA_WN - 8); t += blockDim.x)       // the row tail is zero (as the LDS version leaves it):
-        acts[(t / (ST - RA_WN - 8)) * ST + RA_WN + 8 + t % (ST - RA_WN - 8)] = 0.f;   // LUSH_RBK_RVW_OFFSET.. may hold d_rvw
-}
-
+// Fallback of the BACKWARD for image counts whose tables do not fit one workgroup's LDS (overwriting mode, num_img > 35): the same
+// stages on the global tables.  (The forward, and the backward that adds into existing buffers, split the images over workgroups.)
 // dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
 __device__ void rbk_dense_bwd_x_g(const float* W, const float* dz, int zs, float* dx, int xs, const float* gate,
                                 int gs, int n, int IN, int OUT, int accumulate) {
@@ -1511,16 +1485,14 @@ int lush_consist_loss_fwd_bwd(const float* rgb, const float* cert, int V, int ns
     return 0;
 }
 
+constexpr int RBK_IPB = 4;        // images per workgroup of the split launches
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_fwd: no images");
-    const size_t lds = ((size_t)num_img * RBK_LS + 2 * RBK_WB) * sizeof(float);
-    if (lds > 160 * 1024) {     // table larger than the LDS: global-memory stages
-        hipLaunchKernelGGL(rbk_mlp_fwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts);
-    } else {
-        LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts);
-    }
+    const int ipb = num_img < RBK_IPB ? num_img : RBK_IPB;
+    const size_t lds = ((size_t)ipb * RBK_LS + 2 * RBK_WB) * sizeof(float);
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(cdiv(num_img, ipb)), dim3(256), lds, S_(st), *p, num_img, M, window, acts, ipb);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1529,12 +1501,16 @@ int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window,
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
     if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_mlp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
-    const size_t lds = ((size_t)2 * num_img * RBK_LS + 2 * RBK_WB) * sizeof(float);
+    // adding into buffers that hold values (the trainer's flat gradient): images split over workgroups, sums by atomics;
+    // overwriting: one workgroup for all images (LDS tables, or the global-memory stages when they do not fit)
+    const int ipb = accumulate ? (num_img < RBK_IPB ? num_img : RBK_IPB) : num_img;
+    const size_t lds = ((size_t)2 * ipb * RBK_LS + 2 * RBK_WB) * sizeof(float);
     if (lds > 160 * 1024) {
         hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate, rvw_stride);
     } else {
         LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(1), dim3(1024), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate, rvw_stride);
+        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(cdiv(num_img, ipb)), dim3(accumulate ? 256 : 1024), lds, S_(st), *p, num_img, M, window, acts,
+                           d_rvw, *g, scratch, accumulate, rvw_stride, ipb);
     }
     CHECK_LAUNCH();
     return 0;
