@@ -164,8 +164,9 @@ typedef struct {
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts,
                      lush_stream_t stream);
 /* d_rvw [num_img][rvw_stride >= 32] = gradients w.r.t. r(12), v(12), normalised w(5) in the first 29 floats of a row.
- * `g` is overwritten, or added to when accumulate != 0 (gradient buffers that already hold a slice's
- * contribution); scratch >= num_img*512 floats. */
+ * `g` is added to when accumulate != 0 (gradient buffers that already hold a slice's contribution), else overwritten (the
+ * entry point zeroes it first: the images are split over workgroups and the sums leave by atomics either way).  `scratch` is
+ * unused since ABI 7 and may be NULL. */
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
                      const float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate,
                      lush_stream_t stream);

@@ -816,7 +816,7 @@ constexpr int RBK_LS = LUSH_RBK_ACT_STRIDE + 1;
 // inside the k loop, 38 / 80 us forward / backward either way -- the ten stages are bound by the ONE CU's LDS port at 4-byte
 // reads, 2 per multiply-add: 16 waves x 256 ds_read_b32 x 2 cycles = 3.4 us per 64 x 64 stage.  What would move it is the
 // exact-fp32 MFMA (32x32x2) for these 30 x 64 x 64 products)
-constexpr int RBK_WB = 64 * 65;                 // floats per staging buffer (the largest stage: 64 x 64)
+constexpr int RBK_WALL = 4 * 64 * 65 + 3 * 32 * 65 + 29 * 33;      // floats of every stage's matrix at row pitch IN + 1 (num_motion <= 4)
 __device__ __forceinline__ void rbk_stage_w(const float* __restrict__ W, float* __restrict__ wb, int IN, int OUT) {
     for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) wb[(t / IN) * (IN + 1) + t % IN] = W[t];
 }
@@ -852,9 +852,9 @@ __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, in
     acts += (long long)img0 * LUSH_RBK_ACT_STRIDE;
     extern __shared__ float rbk_lds[];          // [n][RBK_LS] activations, then two weight staging buffers
     float* A = rbk_lds;
-    float* wb[2] = {rbk_lds + n * RBK_LS, rbk_lds + n * RBK_LS + RBK_WB};
+    float* wall = rbk_lds + ipb * RBK_LS;       // every stage's matrix (row pitch IN + 1), loaded once at the head of the kernel
     const int ST = LUSH_RBK_ACT_STRIDE;
-    // the ten dense stages in order; stage s + 1's weights are staged while stage s computes
+    // the ten dense stages in order
     const float* W[10] = {p.w_trunk[0], p.w_trunk[1], p.w_trunk[2], p.w_trunk[3], p.w_rb, p.w_vb, p.w_wb, p.w_r, p.w_v, p.w_w};
     const float* B[10] = {p.b_trunk[0], p.b_trunk[1], p.b_trunk[2], p.b_trunk[3], p.b_rb, p.b_vb, p.b_wb, p.b_r, p.b_v, p.b_w};
     const int XO[10] = {RA_E, RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_H0 + 192, RA_H0 + 192, RA_HR, RA_HV, RA_HW};
@@ -862,12 +862,24 @@ __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, in
     const int IN[10] = {64, 64, 64, 64, 64, 64, 64, 32, 32, 32};
     const int OUT[10] = {64, 64, 64, 64, 32, 32, 32, 3 * M, 3 * M, M + 1};
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) A[(t / 64) * RBK_LS + RA_E + (t % 64)] = p.embed[t];
-    rbk_stage_w(W[0], wb[0], IN[0], OUT[0]);
-    __syncthreads();
+    int WO[10];
+    {   // all the matrices in flight at once: ONE global-memory latency for the kernel instead of one per stage (measured: a 64 x 64
+        // stage cost 4 us with its matrix staged one stage ahead -- the load, not the arithmetic)
+        int off = 0;
 #pragma unroll
-    for (int st = 0; st < 10; ++st) {
-        if (st + 1 < 10) rbk_stage_w(W[st + 1], wb[(st + 1) & 1], IN[st + 1], OUT[st + 1]);
-        rbk_dense_lds(wb[st & 1], B[st], A + XO[st], A + YO[st], n, IN[st], OUT[st], st < 7);
+        for (int st = 0; st < 10; ++st) {
+            WO[st] = off;
+            rbk_stage_w(W[st], wall + off, IN[st], OUT[st]);
+            off += OUT[st] * (IN[st] + 1);
+        }
+    }
+    __syncthreads();
+#ifndef LUSH_ABL_RBK_STAGES       // timing ablation only (wrong results): fewer stages
+#define LUSH_ABL_RBK_STAGES 10
+#endif
+#pragma unroll
+    for (int st = 0; st < LUSH_ABL_RBK_STAGES; ++st) {
+        rbk_dense_lds(wall + WO[st], B[st], A + XO[st], A + YO[st], n, IN[st], OUT[st], st < 7);
         __syncthreads();
     }
     for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
@@ -944,8 +956,8 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
     // LDS: activations [n][RBK_LS] then adjoints of the pre-activations in the same per-image layout
     extern __shared__ float rbk_lds[];
     float* A = rbk_lds;
-    float* sc = rbk_lds + n * RBK_LS;
-    float* wb[2] = {rbk_lds + 2 * n * RBK_LS, rbk_lds + 2 * n * RBK_LS + RBK_WB};
+    float* sc = rbk_lds + ipb * RBK_LS;
+    float* wall = rbk_lds + 2 * ipb * RBK_LS;   // every stage's matrix, loaded once (see the forward)
     const int ST = LUSH_RBK_ACT_STRIDE;
     for (int t = threadIdx.x; t < n * ST; t += blockDim.x) {
         A[(t / ST) * RBK_LS + (t % ST)] = acts[t];
@@ -978,102 +990,26 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
     const int ACC[10] = {0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
     float* gw[10] = {g.w_r, g.w_v, g.w_w, g.w_rb, g.w_vb, g.w_wb, g.w_trunk[3], g.w_trunk[2], g.w_trunk[1], g.w_trunk[0]};
     float* gb[10] = {g.b_r, g.b_v, g.b_w, g.b_rb, g.b_vb, g.b_wb, g.b_trunk[3], g.b_trunk[2], g.b_trunk[1], g.b_trunk[0]};
-    rbk_stage_w(W[0], wb[0], IN[0], OUT[0]);
+    int WO[10];
+    {
+        int off = 0;
+#pragma unroll
+        for (int st = 0; st < 10; ++st) {
+            WO[st] = off;
+            rbk_stage_w(W[st], wall + off, IN[st], OUT[st]);
+            off += OUT[st] * (IN[st] + 1);
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int st = 0; st < 10; ++st) {
-        if (st + 1 < 10) rbk_stage_w(W[st + 1], wb[(st + 1) & 1], IN[st + 1], OUT[st + 1]);
         // dW / db of this stage: dz (complete since the previous barrier) x the stage's input activations
         rbk_dense_bwd_w(sc + ZO[st], A + XO[st], gw[st], gb[st], n, IN[st], OUT[st], accumulate);
-        rbk_dense_bwd_x_lds(wb[st & 1], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, n, IN[st], OUT[st], ACC[st]);
+        rbk_dense_bwd_x_lds(wall + WO[st], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, n, IN[st], OUT[st], ACC[st]);
         __syncthreads();
     }
     for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {      // (an image's embedding row belongs to one workgroup)
         const float v = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
-        g.embed[t] = accumulate ? g.embed[t] + v : v;
-    }
-}
-
-// Fallback of the BACKWARD for image counts whose tables do not fit one workgroup's LDS (overwriting mode, num_img > 35): the same
-// stages on the global tables.  (The forward, and the backward that adds into existing buffers, split the images over workgroups.)
-// dx[i][k] = sum_o W[o][k] dz[i][o], optionally gated by x[i][k] > 0 and added to dx
-__device__ void rbk_dense_bwd_x_g(const float* W, const float* dz, int zs, float* dx, int xs, const float* gate,
-                                int gs, int n, int IN, int OUT, int accumulate) {
-    for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
-        const int i = t / IN, k = t % IN;
-        float s = 0.f;
-        for (int o = 0; o < OUT; ++o) s += W[o * IN + k] * dz[i * zs + o];
-        if (accumulate) s += dx[i * xs + k];
-        dx[i * xs + k] = s;
-    }
-    __syncthreads();
-    if (gate) {
-        for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
-            const int i = t / IN, k = t % IN;
-            if (!(gate[i * gs + k] > 0.f)) dx[i * xs + k] = 0.f;
-        }
-        __syncthreads();
-    }
-}
-__device__ void rbk_dense_bwd_w_g(const float* dz, int zs, const float* x, int xs, float* dW, float* db, int n, int IN,
-                                int OUT, int accumulate) {
-    for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
-        const int o = t / IN, k = t % IN;
-        float s = 0.f;
-        for (int i = 0; i < n; ++i) s += dz[i * zs + o] * x[i * xs + k];
-        dW[t] = accumulate ? dW[t] + s : s;
-    }
-    for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
-        float s = 0.f;
-        for (int i = 0; i < n; ++i) s += dz[i * zs + o];
-        db[o] = accumulate ? db[o] + s : s;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel_g(lush_rbk_params p, int n, int M, float window,
-                                                          const float* __restrict__ acts,
-                                                          const float* __restrict__ d_rvw, lush_rbk_grads g,
-                                                          float* __restrict__ sc, int accumulate, int RS) {
-    // scratch uses the same per-image layout as acts, holding adjoints of the pre-activations
-    const int ST = LUSH_RBK_ACT_STRIDE;
-    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
-        const int i = t / (3 * M), o = t % (3 * M);
-        sc[i * ST + RA_R + o] = d_rvw[i * RS + o] * window;
-        sc[i * ST + RA_V + o] = d_rvw[i * RS + 12 + o] * window;
-    }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float sum = 1e-10f, dotp = 0.f;
-        for (int m = 0; m <= M; ++m) { sum += acts[i * ST + RA_WS + m]; dotp += d_rvw[i * RS + 24 + m] * acts[i * ST + RA_WS + m]; }
-        for (int m = 0; m <= M; ++m) {
-            const float ws = acts[i * ST + RA_WS + m];
-            const float dws = d_rvw[i * RS + 24 + m] / sum - dotp / (sum * sum);
-            sc[i * ST + RA_WS + m] = dws * ws * (1.f - ws);
-        }
-    }
-    __syncthreads();
-    rbk_dense_bwd_w_g(sc + RA_R, ST, acts + RA_HR, ST, g.w_r, g.b_r, n, 32, 3 * M, accumulate);
-    rbk_dense_bwd_w_g(sc + RA_V, ST, acts + RA_HV, ST, g.w_v, g.b_v, n, 32, 3 * M, accumulate);
-    rbk_dense_bwd_w_g(sc + RA_WS, ST, acts + RA_HW, ST, g.w_w, g.b_w, n, 32, M + 1, accumulate);
-    rbk_dense_bwd_x_g(p.w_r, sc + RA_R, ST, sc + RA_HR, ST, acts + RA_HR, ST, n, 32, 3 * M, 0);
-    rbk_dense_bwd_x_g(p.w_v, sc + RA_V, ST, sc + RA_HV, ST, acts + RA_HV, ST, n, 32, 3 * M, 0);
-    rbk_dense_bwd_x_g(p.w_w, sc + RA_WS, ST, sc + RA_HW, ST, acts + RA_HW, ST, n, 32, M + 1, 0);
-    const float* h3 = acts + RA_H0 + 192;
-    rbk_dense_bwd_w_g(sc + RA_HR, ST, h3, ST, g.w_rb, g.b_rb, n, 64, 32, accumulate);
-    rbk_dense_bwd_w_g(sc + RA_HV, ST, h3, ST, g.w_vb, g.b_vb, n, 64, 32, accumulate);
-    rbk_dense_bwd_w_g(sc + RA_HW, ST, h3, ST, g.w_wb, g.b_wb, n, 64, 32, accumulate);
-    float* dh3 = sc + RA_H0 + 192;
-    rbk_dense_bwd_x_g(p.w_rb, sc + RA_HR, ST, dh3, ST, nullptr, 0, n, 64, 32, 0);
-    rbk_dense_bwd_x_g(p.w_vb, sc + RA_HV, ST, dh3, ST, nullptr, 0, n, 64, 32, 1);
-    rbk_dense_bwd_x_g(p.w_wb, sc + RA_HW, ST, dh3, ST, h3, ST, n, 64, 32, 1);
-    for (int l = 3; l >= 0; --l) {
-        const float* x = acts + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_w_g(sc + RA_H0 + 64 * l, ST, x, ST, g.w_trunk[l], g.b_trunk[l], n, 64, 64, accumulate);
-        float* dx = sc + (l == 0 ? RA_E : RA_H0 + 64 * (l - 1));
-        rbk_dense_bwd_x_g(p.w_trunk[l], sc + RA_H0 + 64 * l, ST, dx, ST, l == 0 ? nullptr : x, ST, n, 64, 64, 0);
-    }
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {
-        const float v = sc[(t / 64) * ST + RA_E + (t % 64)];
         g.embed[t] = accumulate ? g.embed[t] + v : v;
     }
 }
@@ -1507,7 +1443,7 @@ int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window,
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_fwd: no images");
     const int ipb = num_img < RBK_IPB ? num_img : RBK_IPB;
-    const size_t lds = ((size_t)ipb * RBK_LS + 2 * RBK_WB) * sizeof(float);
+    const size_t lds = ((size_t)ipb * RBK_LS + RBK_WALL) * sizeof(float);
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(cdiv(num_img, ipb)), dim3(256), lds, S_(st), *p, num_img, M, window, acts, ipb);
     CHECK_LAUNCH();
@@ -1518,17 +1454,30 @@ int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window,
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
     if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_mlp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
-    // adding into buffers that hold values (the trainer's flat gradient): images split over workgroups, sums by atomics;
-    // overwriting: one workgroup for all images (LDS tables, or the global-memory stages when they do not fit)
-    const int ipb = accumulate ? (num_img < RBK_IPB ? num_img : RBK_IPB) : num_img;
-    const size_t lds = ((size_t)2 * ipb * RBK_LS + 2 * RBK_WB) * sizeof(float);
-    if (lds > 160 * 1024) {
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel_g, dim3(1), dim3(1024), 0, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, accumulate, rvw_stride);
-    } else {
-        LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(cdiv(num_img, ipb)), dim3(accumulate ? 256 : 1024), lds, S_(st), *p, num_img, M, window, acts,
-                           d_rvw, *g, scratch, accumulate, rvw_stride, ipb);
+    // images split over workgroups, the weight gradients summed by atomics into buffers that hold values -- the trainer's flat
+    // gradient (accumulate != 0), or zeros written here first (accumulate == 0: 19 small memsets, not a path a training step takes)
+    if (!accumulate) {
+        const size_t f = sizeof(float);
+        LUSH_HIP(hipMemsetAsync(g->embed, 0, (size_t)num_img * 64 * f, S_(st)));
+        for (int l = 0; l < 4; ++l) {
+            LUSH_HIP(hipMemsetAsync(g->w_trunk[l], 0, 64 * 64 * f, S_(st)));
+            LUSH_HIP(hipMemsetAsync(g->b_trunk[l], 0, 64 * f, S_(st)));
+        }
+        float* w32[3] = {g->w_rb, g->w_vb, g->w_wb};
+        float* b32[3] = {g->b_rb, g->b_vb, g->b_wb};
+        for (int i = 0; i < 3; ++i) {
+            LUSH_HIP(hipMemsetAsync(w32[i], 0, 32 * 64 * f, S_(st)));
+            LUSH_HIP(hipMemsetAsync(b32[i], 0, 32 * f, S_(st)));
+        }
+        LUSH_HIP(hipMemsetAsync(g->w_r, 0, (size_t)3 * M * 32 * f, S_(st))); LUSH_HIP(hipMemsetAsync(g->b_r, 0, (size_t)3 * M * f, S_(st)));
+        LUSH_HIP(hipMemsetAsync(g->w_v, 0, (size_t)3 * M * 32 * f, S_(st))); LUSH_HIP(hipMemsetAsync(g->b_v, 0, (size_t)3 * M * f, S_(st)));
+        LUSH_HIP(hipMemsetAsync(g->w_w, 0, (size_t)(M + 1) * 32 * f, S_(st))); LUSH_HIP(hipMemsetAsync(g->b_w, 0, (size_t)(M + 1) * f, S_(st)));
     }
+    const int ipb = num_img < RBK_IPB ? num_img : RBK_IPB;
+    const size_t lds = ((size_t)2 * ipb * RBK_LS + RBK_WALL) * sizeof(float);
+    LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(cdiv(num_img, ipb)), dim3(256), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, 1,
+                       rvw_stride, ipb);
     CHECK_LAUNCH();
     return 0;
 }
