@@ -804,90 +804,140 @@ __global__ __launch_bounds__(1024) void rbk_warp_ndc_bwd_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------- RBK MLP
-// One workgroup; num_img rows.  y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]).
-// The activation table (num_img x 512 floats) lives in LDS for the whole kernel with an ODD row stride (RBK_LS), so
-// the per-image column reads of 64 lanes hit 64 different banks; the dense loops read weights from L2 with the image
-// index fastest across lanes (one weight broadcast per wave instruction).  The first version worked on the global
-// table directly: every one of its ~20 dependent stages paid global-memory latency (0.47 ms for a few MFLOP).
+// y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]) for a few dozen images through ten small dense stages (4 MFLOP in all).
+// A workgroup of RBK_NT threads takes RBK_IPB images; their activation rows (512 floats each) live in LDS for the whole
+// kernel with an ODD row stride (RBK_LS), and every stage's matrix is copied into LDS once at the head of the kernel.
+//
+// What these kernels cost was never arithmetic or LDS bandwidth but DEPENDENT LATENCIES IN SERIES, one wave per SIMD with
+// nothing to switch to: as `for (t = threadIdx.x; t < count; t += blockDim.x) lds[..] = W[t]` with a run-time trip count the
+// compiler emits load, s_waitcnt vmcnt(0), ds_write per iteration, so the 23.8 K weight floats were 93 global-memory round
+// trips one after the other (0.3-0.4 us each: the 37 us of the forward, whatever the number of workgroups, staging depth or
+// summation batching -- round 4 measured five such variants at 36-39 us before finding this), and the per-image sums of
+// the backward's weight gradients were 16 x 4 LDS round trips in series per stage.  Hence the compile-time thread count and
+// image count below: every loop has a constant trip count, is fully unrolled with its loads in front of its uses, and rows
+// of absent images (n < RBK_IPB) hold zeros instead of shortening a loop.
 constexpr int RBK_LS = LUSH_RBK_ACT_STRIDE + 1;
-
-// A stage's weight matrix goes global -> LDS once, coalesced (row pitch IN + 1), one stage AHEAD of its use (two staging
-// buffers): the dense loops then read weights and activations from LDS only.  (Measured: no faster than reading W[o][k] from L2
-// inside the k loop, 38 / 80 us forward / backward either way -- the ten stages are bound by the ONE CU's LDS port at 4-byte
-// reads, 2 per multiply-add: 16 waves x 256 ds_read_b32 x 2 cycles = 3.4 us per 64 x 64 stage.  What would move it is the
-// exact-fp32 MFMA (32x32x2) for these 30 x 64 x 64 products)
+constexpr int RBK_NT = 256;       // threads per workgroup
+constexpr int RBK_IPB = 4;        // images per workgroup
 constexpr int RBK_WALL = 4 * 64 * 65 + 3 * 32 * 65 + 29 * 33;      // floats of every stage's matrix at row pitch IN + 1 (num_motion <= 4)
-__device__ __forceinline__ void rbk_stage_w(const float* __restrict__ W, float* __restrict__ wb, int IN, int OUT) {
-    for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) wb[(t / IN) * (IN + 1) + t % IN] = W[t];
-}
-// y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]) from the staged W (same summation order as before: bias first, k ascending)
-__device__ __forceinline__ void rbk_dense_lds(const float* __restrict__ wb, const float* __restrict__ b, const float* x, float* y, int n,
-                                              int IN, int OUT, int relu) {
-    for (int t = threadIdx.x; t < n * OUT; t += blockDim.x) {
-        const int i = t % n, o = t / n;
-        float s = b[o];
-        const float* w = wb + o * (IN + 1);
-        const float* xi = x + i * RBK_LS;
-        // (operands of 16 terms fetched before they are summed: as `s += w[k] * xi[k]` with a run-time trip count every term waited
-        // for its own two LDS reads -- 64 x ~110 cycles per stage, which is what the 36 / 73 us of these kernels were, whatever
-        // the number of workgroups; the order of the sum is unchanged)
-        for (int k0 = 0; k0 < IN; k0 += 16) {
-            float wv[16], xv[16];
+constexpr int RBK_FETCH = 16;     // floats per thread of one matrix fetch (64 x 64 / RBK_NT)
+
+// global -> registers (up to RBK_FETCH x RBK_NT floats of W, coalesced), then registers -> LDS at row pitch IN + 1: two calls,
+// so that the fetches of SEVERAL matrices are all in flight before the first one is waited for
+template <int IN>
+__device__ __forceinline__ void rbk_fetch(const float* __restrict__ W, int OUT, float (&v)[RBK_FETCH]) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { wv[j] = w[k0 + j]; xv[j] = xi[k0 + j]; }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s += wv[j] * xv[j];
-        }
-        y[i * RBK_LS + o] = relu ? fmaxf(s, 0.f) : s;
+    for (int j = 0; j < RBK_FETCH; ++j) {
+        const int t = j * RBK_NT + threadIdx.x;
+        v[j] = t < OUT * IN ? W[t] : 0.f;
     }
 }
-
-// Images are independent in the forward, so workgroup b takes images [b ipb, b ipb + ipb): the ten stages of ONE workgroup were
-// bound by its CU's LDS port (38 us for 30 images); eight workgroups of four images take ~1/6 of that.
-__global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n_all, int M, float window,
-                                                          float* __restrict__ acts, int ipb) {
-    const int img0 = blockIdx.x * ipb;
-    const int n = n_all - img0 < ipb ? n_all - img0 : ipb;
-    p.embed += (long long)img0 * 64;
-    acts += (long long)img0 * LUSH_RBK_ACT_STRIDE;
-    extern __shared__ float rbk_lds[];          // [n][RBK_LS] activations, then two weight staging buffers
-    float* A = rbk_lds;
-    float* wall = rbk_lds + ipb * RBK_LS;       // every stage's matrix (row pitch IN + 1), loaded once at the head of the kernel
-    const int ST = LUSH_RBK_ACT_STRIDE;
-    // the ten dense stages in order
-    const float* W[10] = {p.w_trunk[0], p.w_trunk[1], p.w_trunk[2], p.w_trunk[3], p.w_rb, p.w_vb, p.w_wb, p.w_r, p.w_v, p.w_w};
-    const float* B[10] = {p.b_trunk[0], p.b_trunk[1], p.b_trunk[2], p.b_trunk[3], p.b_rb, p.b_vb, p.b_wb, p.b_r, p.b_v, p.b_w};
-    const int XO[10] = {RA_E, RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_H0 + 192, RA_H0 + 192, RA_HR, RA_HV, RA_HW};
-    const int YO[10] = {RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_HR, RA_HV, RA_HW, RA_R, RA_V, RA_WS};
-    const int IN[10] = {64, 64, 64, 64, 64, 64, 64, 32, 32, 32};
-    const int OUT[10] = {64, 64, 64, 64, 32, 32, 32, 3 * M, 3 * M, M + 1};
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) A[(t / 64) * RBK_LS + RA_E + (t % 64)] = p.embed[t];
-    int WO[10];
-    {   // all the matrices in flight at once: ONE global-memory latency for the kernel instead of one per stage (measured: a 64 x 64
-        // stage cost 4 us with its matrix staged one stage ahead -- the load, not the arithmetic)
-        int off = 0;
+template <int IN>
+__device__ __forceinline__ void rbk_put(float* __restrict__ wb, int OUT, const float (&v)[RBK_FETCH]) {
+#pragma unroll
+    for (int j = 0; j < RBK_FETCH; ++j) {
+        const int t = j * RBK_NT + threadIdx.x;
+        if (t < OUT * IN) wb[(t / IN) * (IN + 1) + t % IN] = v[j];
+    }
+}
+struct RbkStages {       // the ten matrices of one pass in the order the pass uses them
+    const float* W[10];
+    const float* B[10];      // biases (forward only): kept in the pad column of the staged matrix, wb[o * (IN + 1) + IN]
+    int OUT[10];
+    int WO[10];              // float offset of the staged matrix in the wall
+};
+// IN of stage st is 64 for st in [first64, first64 + 7), 32 for the other three (forward: 64s first; backward: 32s first)
+template <bool BIAS, int FIRST64>
+__device__ __forceinline__ void rbk_stage_all(RbkStages& S, float* __restrict__ wall) {
+    int off = 0;
+#pragma unroll
+    for (int st = 0; st < 10; ++st) {
+        S.WO[st] = off;
+        off += S.OUT[st] * ((st >= FIRST64 && st < FIRST64 + 7 ? 64 : 32) + 1);
+    }
+    float bias[10];
+    if (BIAS) {
+#pragma unroll
+        for (int st = 0; st < 10; ++st) bias[st] = (int)threadIdx.x < S.OUT[st] ? S.B[st][threadIdx.x] : 0.f;
+    }
+    // every matrix's fetch in flight before the first is waited for (160 registers of fetched weights; one wave per SIMD has 512)
+    {
+        float v[10][RBK_FETCH];
 #pragma unroll
         for (int st = 0; st < 10; ++st) {
-            WO[st] = off;
-            rbk_stage_w(W[st], wall + off, IN[st], OUT[st]);
-            off += OUT[st] * (IN[st] + 1);
+            if (st >= FIRST64 && st < FIRST64 + 7) rbk_fetch<64>(S.W[st], S.OUT[st], v[st]);
+            else rbk_fetch<32>(S.W[st], S.OUT[st], v[st]);
+        }
+#pragma unroll
+        for (int st = 0; st < 10; ++st) {
+            if (st >= FIRST64 && st < FIRST64 + 7) rbk_put<64>(wall + S.WO[st], S.OUT[st], v[st]);
+            else rbk_put<32>(wall + S.WO[st], S.OUT[st], v[st]);
         }
     }
-    __syncthreads();
-#ifndef LUSH_ABL_RBK_STAGES       // timing ablation only (wrong results): fewer stages
-#define LUSH_ABL_RBK_STAGES 10
-#endif
+    if (BIAS) {
 #pragma unroll
-    for (int st = 0; st < LUSH_ABL_RBK_STAGES; ++st) {
-        rbk_dense_lds(wall + WO[st], B[st], A + XO[st], A + YO[st], n, IN[st], OUT[st], st < 7);
-        __syncthreads();
+        for (int st = 0; st < 10; ++st) {
+            const int in = st >= FIRST64 && st < FIRST64 + 7 ? 64 : 32;
+            if ((int)threadIdx.x < S.OUT[st]) wall[S.WO[st] + threadIdx.x * (in + 1) + in] = bias[st];
+        }
     }
-    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
-        const int i = t / (3 * M), o = t % (3 * M);
+}
+
+// y[i][o] = act(b[o] + sum_k W[o][k] x[i][k]) from the staged W: bias first, k ascending (the order of every earlier version);
+// RBK_IPB x OUT <= RBK_NT outputs, one per thread, image index fastest across lanes
+template <int IN>
+__device__ __forceinline__ void rbk_dense_lds(const float* __restrict__ wb, const float* x, float* y, int OUT, int relu) {
+    const int i = threadIdx.x % RBK_IPB, o = threadIdx.x / RBK_IPB;
+    if (o >= OUT) return;
+    const float* w = wb + o * (IN + 1);
+    const float* xi = x + i * RBK_LS;
+    float s = w[IN];
+#pragma unroll
+    for (int k0 = 0; k0 < IN; k0 += 16) {       // (operands of 16 terms fetched before they are summed)
+        float wv[16], xv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { wv[j] = w[k0 + j]; xv[j] = xi[k0 + j]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += wv[j] * xv[j];
+    }
+    y[i * RBK_LS + o] = relu ? fmaxf(s, 0.f) : s;
+}
+
+__global__ __launch_bounds__(RBK_NT) void rbk_mlp_fwd_kernel(lush_rbk_params p, int n_all, int M, float window,
+                                                            float* __restrict__ acts) {
+    const int img0 = blockIdx.x * RBK_IPB;
+    const int n = n_all - img0 < RBK_IPB ? n_all - img0 : RBK_IPB;
+    p.embed += (long long)img0 * 64;
+    acts += (long long)img0 * LUSH_RBK_ACT_STRIDE;
+    extern __shared__ float rbk_lds[];
+    float* A = rbk_lds;                             // [RBK_IPB][RBK_LS] activations
+    float* wall = rbk_lds + RBK_IPB * RBK_LS;       // every stage's matrix
+    constexpr int ST = LUSH_RBK_ACT_STRIDE;
+    RbkStages S = {{p.w_trunk[0], p.w_trunk[1], p.w_trunk[2], p.w_trunk[3], p.w_rb, p.w_vb, p.w_wb, p.w_r, p.w_v, p.w_w},
+                   {p.b_trunk[0], p.b_trunk[1], p.b_trunk[2], p.b_trunk[3], p.b_rb, p.b_vb, p.b_wb, p.b_r, p.b_v, p.b_w},
+                   {64, 64, 64, 64, 32, 32, 32, 3 * M, 3 * M, M + 1}, {}};
+    const int XO[10] = {RA_E, RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_H0 + 192, RA_H0 + 192, RA_HR, RA_HV, RA_HW};
+    const int YO[10] = {RA_H0, RA_H0 + 64, RA_H0 + 128, RA_H0 + 192, RA_HR, RA_HV, RA_HW, RA_R, RA_V, RA_WS};
+    {   // (RBK_IPB x 64 = RBK_NT: one embedding float per thread; an absent image's row is zeros and is never written out)
+        const int i = threadIdx.x / 64;
+        A[i * RBK_LS + RA_E + threadIdx.x % 64] = i < n ? p.embed[threadIdx.x] : 0.f;
+    }
+    rbk_stage_all<true, 0>(S, wall);
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 10; ++st) {
+        if (st < 7) rbk_dense_lds<64>(wall + S.WO[st], A + XO[st], A + YO[st], S.OUT[st], 1);
+        else rbk_dense_lds<32>(wall + S.WO[st], A + XO[st], A + YO[st], S.OUT[st], 0);
+        // (the three branches and the three heads read one input and write disjoint outputs: one barrier per group)
+        if (st != 4 && st != 5 && st != 7 && st != 8) __syncthreads();
+    }
+    if ((int)threadIdx.x < RBK_IPB * 3 * M) {
+        const int i = threadIdx.x / (3 * M), o = threadIdx.x % (3 * M);
         A[i * RBK_LS + RA_R + o] *= window;
         A[i * RBK_LS + RA_V + o] *= window;
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if ((int)threadIdx.x < RBK_IPB) {
+        const int i = threadIdx.x;
         float sum = 0.f;
         for (int m = 0; m <= M; ++m) {
             const float s = 1.f / (1.f + expf(-A[i * RBK_LS + RA_WS + m]));
@@ -897,79 +947,120 @@ __global__ __launch_bounds__(1024) void rbk_mlp_fwd_kernel(lush_rbk_params p, in
         for (int m = 0; m <= M; ++m) A[i * RBK_LS + RA_WN + m] = A[i * RBK_LS + RA_WS + m] / (sum + 1e-10f);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < n * ST; t += blockDim.x) acts[t] = (t % ST) < RA_WN + 8 ? A[(t / ST) * RBK_LS + (t % ST)] : 0.f;
+#pragma unroll
+    for (int j = 0; j < RBK_IPB * ST / RBK_NT; ++j) {
+        const int t = j * RBK_NT + threadIdx.x;
+        if (t < n * ST) acts[t] = (t % ST) < RA_WN + 8 ? A[(t / ST) * RBK_LS + (t % ST)] : 0.f;
+    }
 }
 
 // dx[i][k] = [gate[i][k] > 0] * (sum_o W[o][k] dz[i][o] (+ dx[i][k])) from the staged W (row pitch IN + 1); o ascending, the
-// previous value added last, the gate applied to the total -- the arithmetic of round 3's separate passes
-__device__ __forceinline__ void rbk_dense_bwd_x_lds(const float* __restrict__ wb, const float* dz, float* dx, const float* gate, int n,
-                                                    int IN, int OUT, int accumulate) {
-    for (int t = threadIdx.x; t < n * IN; t += blockDim.x) {
-        const int i = t % n, k = t / n;
-        float s = 0.f;
-        const float* zi = dz + i * RBK_LS;
-        int o0 = 0;
-        for (; o0 + 8 <= OUT; o0 += 8) {          // (operands of 8 terms fetched before they are summed; same order of the sum)
-            float wv[8], zv[8];
+// previous value added last, the gate applied to the total -- the arithmetic of round 3's separate passes.
+// RBK_IPB x IN <= RBK_NT outputs, one per thread.
+template <int IN>
+__device__ __forceinline__ void rbk_dense_bwd_x_lds(const float* __restrict__ wb, const float* dz, float* dx, const float* gate,
+                                                    int OUT, int accumulate) {
+    const int i = threadIdx.x % RBK_IPB, k = threadIdx.x / RBK_IPB;
+    if (k >= IN) return;
+    float s = 0.f;
+    const float* zi = dz + i * RBK_LS;
+    int o0 = 0;
+    for (; o0 + 8 <= OUT; o0 += 8) {          // (operands of 8 terms fetched before they are summed; same order of the sum)
+        float wv[8], zv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { wv[j] = wb[(o0 + j) * (IN + 1) + k]; zv[j] = zi[o0 + j]; }
+        for (int j = 0; j < 8; ++j) { wv[j] = wb[(o0 + j) * (IN + 1) + k]; zv[j] = zi[o0 + j]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += wv[j] * zv[j];
+        for (int j = 0; j < 8; ++j) s += wv[j] * zv[j];
+    }
+    if (o0 < OUT) {                            // the heads' 3 M or M + 1 outputs: up to 7 more, fetched together as well
+        float wv[8], zv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in = o0 + j < OUT;
+            wv[j] = in ? wb[(o0 + j) * (IN + 1) + k] : 0.f;
+            zv[j] = in ? zi[o0 + j] : 0.f;
         }
-        for (; o0 < OUT; ++o0) s += wb[o0 * (IN + 1) + k] * zi[o0];
-        if (accumulate) s += dx[i * RBK_LS + k];
-        if (gate && !(gate[i * RBK_LS + k] > 0.f)) s = 0.f;
-        dx[i * RBK_LS + k] = s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (o0 + j < OUT) s += wv[j] * zv[j];
     }
+    if (accumulate) s += dx[i * RBK_LS + k];
+    if (gate && !(gate[i * RBK_LS + k] > 0.f)) s = 0.f;
+    dx[i * RBK_LS + k] = s;
 }
-// accumulate: 0 = overwrite, 1 = add (one workgroup), 2 = atomic add (several workgroups, each with its own images)
-__device__ void rbk_dense_bwd_w(const float* dz, const float* x, float* dW, float* db, int n, int IN, int OUT, int accumulate) {
-    for (int t = threadIdx.x; t < OUT * IN; t += blockDim.x) {
-        const int o = t / IN, k = t % IN;
-        float s = 0.f;
-        for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o] * x[i * RBK_LS + k];
-        if (accumulate == 2) atomicAdd(dW + t, s);
-        else dW[t] = accumulate ? dW[t] + s : s;
+// dW[o][k] += sum_i dz[i][o] x[i][k], db[o] += sum_i dz[i][o]: added into buffers that hold values (the trainer's flat gradient,
+// or zeros the launcher wrote), by atomics because several workgroups -- each with its own images -- add into the same matrix.
+// Thread t takes outputs t, t + RBK_NT, ...: k = t % IN is the same for all of them (RBK_NT is a multiple of IN), so a thread
+// reads its RBK_IPB activations once; rows of absent images hold zeros.
+template <int IN>
+__device__ __forceinline__ void rbk_dense_bwd_w(const float* dz, const float* x, float* __restrict__ dW, float* __restrict__ db, int OUT) {
+    const int k = threadIdx.x % IN, o_first = threadIdx.x / IN;
+    constexpr int OSTEP = RBK_NT / IN;
+    float xv[RBK_IPB];
+#pragma unroll
+    for (int i = 0; i < RBK_IPB; ++i) xv[i] = x[i * RBK_LS + k];
+#pragma unroll
+    for (int r = 0; r < 64 / OSTEP; ++r) {
+        const int o = o_first + r * OSTEP;
+        if (o < OUT) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < RBK_IPB; ++i) s += dz[i * RBK_LS + o] * xv[i];
+            atomicAdd(dW + o * IN + k, s);
+        }
     }
-    for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
+    if ((int)threadIdx.x < OUT) {
         float s = 0.f;
-        for (int i = 0; i < n; ++i) s += dz[i * RBK_LS + o];
-        if (accumulate == 2) atomicAdd(db + o, s);
-        else db[o] = accumulate ? db[o] + s : s;
+#pragma unroll
+        for (int i = 0; i < RBK_IPB; ++i) s += dz[i * RBK_LS + threadIdx.x];
+        atomicAdd(db + threadIdx.x, s);
     }
     // (no barrier: dW / db are outputs only; the adjoints a later stage overwrites are guarded by that stage's barrier)
 }
 
-// Workgroup b takes images [b ipb, b ipb + ipb): d(activation) is per image, the weight gradients are sums over the images and
-// leave by atomics when there are several workgroups (only when adding into buffers that hold values: accumulate != 0).
-__global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n_all, int M, float window,
-                                                          const float* __restrict__ acts,
-                                                          const float* __restrict__ d_rvw, lush_rbk_grads g,
-                                                          float* __restrict__ /*scratch: unused since the LDS version*/, int accumulate,
-                                                          int RS /* floats between two images' rows of d_rvw */, int ipb) {
-    const int img0 = blockIdx.x * ipb;
-    const int n = n_all - img0 < ipb ? n_all - img0 : ipb;
+// Workgroup b takes images [b RBK_IPB, (b + 1) RBK_IPB): d(activation) is per image, the weight gradients are sums over images.
+__global__ __launch_bounds__(RBK_NT) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n_all, int M, float window,
+                                                            const float* __restrict__ acts,
+                                                            const float* __restrict__ d_rvw, lush_rbk_grads g,
+                                                            int RS /* floats between two images' rows of d_rvw */) {
+    const int img0 = blockIdx.x * RBK_IPB;
+    const int n = n_all - img0 < RBK_IPB ? n_all - img0 : RBK_IPB;
     acts += (long long)img0 * LUSH_RBK_ACT_STRIDE;
     d_rvw += (long long)img0 * RS;
     g.embed += (long long)img0 * 64;
-    if (gridDim.x > 1) accumulate = 2;
-    // LDS: activations [n][RBK_LS] then adjoints of the pre-activations in the same per-image layout
+    // LDS: activations [RBK_IPB][RBK_LS], then the adjoints of the pre-activations in the same per-image layout, then the matrices
     extern __shared__ float rbk_lds[];
     float* A = rbk_lds;
-    float* sc = rbk_lds + ipb * RBK_LS;
-    float* wall = rbk_lds + 2 * ipb * RBK_LS;   // every stage's matrix, loaded once (see the forward)
-    const int ST = LUSH_RBK_ACT_STRIDE;
-    for (int t = threadIdx.x; t < n * ST; t += blockDim.x) {
-        A[(t / ST) * RBK_LS + (t % ST)] = acts[t];
-        sc[(t / ST) * RBK_LS + (t % ST)] = 0.f;
+    float* sc = rbk_lds + RBK_IPB * RBK_LS;
+    float* wall = rbk_lds + 2 * RBK_IPB * RBK_LS;
+    constexpr int ST = LUSH_RBK_ACT_STRIDE;
+    {
+        float v[RBK_IPB * ST / RBK_NT];
+#pragma unroll
+        for (int j = 0; j < RBK_IPB * ST / RBK_NT; ++j) {
+            const int t = j * RBK_NT + threadIdx.x;
+            v[j] = t < n * ST ? acts[t] : 0.f;            // (an absent image: zero activations, zero adjoints)
+        }
+#pragma unroll
+        for (int j = 0; j < RBK_IPB * ST / RBK_NT; ++j) {
+            const int t = j * RBK_NT + threadIdx.x;
+            A[(t / ST) * RBK_LS + (t % ST)] = v[j];
+            sc[(t / ST) * RBK_LS + (t % ST)] = 0.f;
+        }
     }
+    // ten dx stages: heads r, v, w; branches rb, vb, wb into one d h3; trunk 3..0
+    RbkStages S = {{p.w_r, p.w_v, p.w_w, p.w_rb, p.w_vb, p.w_wb, p.w_trunk[3], p.w_trunk[2], p.w_trunk[1], p.w_trunk[0]}, {},
+                   {3 * M, 3 * M, M + 1, 32, 32, 32, 64, 64, 64, 64}, {}};
+    rbk_stage_all<false, 3>(S, wall);
     __syncthreads();
-    for (int t = threadIdx.x; t < n * 3 * M; t += blockDim.x) {
-        const int i = t / (3 * M), o = t % (3 * M);
-        sc[i * RBK_LS + RA_R + o] = d_rvw[i * RS + o] * window;
-        sc[i * RBK_LS + RA_V + o] = d_rvw[i * RS + 12 + o] * window;
+    if ((int)threadIdx.x < RBK_IPB * 3 * M) {
+        const int i = threadIdx.x / (3 * M), o = threadIdx.x % (3 * M);
+        if (i < n) {
+            sc[i * RBK_LS + RA_R + o] = d_rvw[i * RS + o] * window;
+            sc[i * RBK_LS + RA_V + o] = d_rvw[i * RS + 12 + o] * window;
+        }
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if ((int)threadIdx.x < n) {
+        const int i = threadIdx.x;
         float sum = 1e-10f, dotp = 0.f;
         for (int m = 0; m <= M; ++m) { sum += A[i * RBK_LS + RA_WS + m]; dotp += d_rvw[i * RS + 24 + m] * A[i * RBK_LS + RA_WS + m]; }
         for (int m = 0; m <= M; ++m) {
@@ -979,38 +1070,29 @@ __global__ __launch_bounds__(1024) void rbk_mlp_bwd_kernel(lush_rbk_params p, in
         }
     }
     __syncthreads();
-    // ten dx stages (heads r, v, w; branches rb, vb, wb into one d h3; trunk 3..0), each from weights staged one stage ahead;
-    // the weight gradients of a stage read LDS only and need no barrier of their own
-    const float* W[10] = {p.w_r, p.w_v, p.w_w, p.w_rb, p.w_vb, p.w_wb, p.w_trunk[3], p.w_trunk[2], p.w_trunk[1], p.w_trunk[0]};
-    const int IN[10] = {32, 32, 32, 64, 64, 64, 64, 64, 64, 64};
-    const int OUT[10] = {3 * M, 3 * M, M + 1, 32, 32, 32, 64, 64, 64, 64};
     const int ZO[10] = {RA_R, RA_V, RA_WS, RA_HR, RA_HV, RA_HW, RA_H0 + 192, RA_H0 + 128, RA_H0 + 64, RA_H0};
     const int XO[10] = {RA_HR, RA_HV, RA_HW, RA_H0 + 192, RA_H0 + 192, RA_H0 + 192, RA_H0 + 128, RA_H0 + 64, RA_H0, RA_E};
     const int GATE[10] = {1, 1, 1, 0, 0, 1, 1, 1, 1, 0};       // ReLU gate of the stage's input activations (d h3: after the third addend)
     const int ACC[10] = {0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
     float* gw[10] = {g.w_r, g.w_v, g.w_w, g.w_rb, g.w_vb, g.w_wb, g.w_trunk[3], g.w_trunk[2], g.w_trunk[1], g.w_trunk[0]};
     float* gb[10] = {g.b_r, g.b_v, g.b_w, g.b_rb, g.b_vb, g.b_wb, g.b_trunk[3], g.b_trunk[2], g.b_trunk[1], g.b_trunk[0]};
-    int WO[10];
-    {
-        int off = 0;
-#pragma unroll
-        for (int st = 0; st < 10; ++st) {
-            WO[st] = off;
-            rbk_stage_w(W[st], wall + off, IN[st], OUT[st]);
-            off += OUT[st] * (IN[st] + 1);
-        }
-    }
-    __syncthreads();
 #pragma unroll
     for (int st = 0; st < 10; ++st) {
         // dW / db of this stage: dz (complete since the previous barrier) x the stage's input activations
-        rbk_dense_bwd_w(sc + ZO[st], A + XO[st], gw[st], gb[st], n, IN[st], OUT[st], accumulate);
-        rbk_dense_bwd_x_lds(wall + WO[st], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, n, IN[st], OUT[st], ACC[st]);
-        __syncthreads();
+        if (st < 3) {
+            rbk_dense_bwd_w<32>(sc + ZO[st], A + XO[st], gw[st], gb[st], S.OUT[st]);
+            rbk_dense_bwd_x_lds<32>(wall + S.WO[st], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, S.OUT[st], ACC[st]);
+        } else {
+            rbk_dense_bwd_w<64>(sc + ZO[st], A + XO[st], gw[st], gb[st], S.OUT[st]);
+            rbk_dense_bwd_x_lds<64>(wall + S.WO[st], sc + ZO[st], sc + XO[st], GATE[st] ? A + XO[st] : nullptr, S.OUT[st], ACC[st]);
+        }
+        // (the three heads write three different adjoints: one barrier behind them; the three branches accumulate into ONE d h3
+        // in order, a barrier each)
+        if (st != 0 && st != 1) __syncthreads();
     }
-    for (int t = threadIdx.x; t < n * 64; t += blockDim.x) {      // (an image's embedding row belongs to one workgroup)
-        const float v = sc[(t / 64) * RBK_LS + RA_E + (t % 64)];
-        g.embed[t] = accumulate ? g.embed[t] + v : v;
+    {   // (an image's embedding row belongs to one workgroup; RBK_IPB x 64 = RBK_NT)
+        const int i = threadIdx.x / 64;
+        if (i < n) g.embed[threadIdx.x] += sc[i * RBK_LS + RA_E + (threadIdx.x % 64)];
     }
 }
 
@@ -1438,14 +1520,12 @@ int lush_consist_loss_fwd_bwd(const float* rgb, const float* cert, int V, int ns
     return 0;
 }
 
-constexpr int RBK_IPB = 4;        // images per workgroup of the split launches
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_fwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_fwd: no images");
-    const int ipb = num_img < RBK_IPB ? num_img : RBK_IPB;
-    const size_t lds = ((size_t)ipb * RBK_LS + RBK_WALL) * sizeof(float);
+    const size_t lds = ((size_t)RBK_IPB * RBK_LS + RBK_WALL) * sizeof(float);
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(cdiv(num_img, ipb)), dim3(256), lds, S_(st), *p, num_img, M, window, acts, ipb);
+    hipLaunchKernelGGL(rbk_mlp_fwd_kernel, dim3(cdiv(num_img, RBK_IPB)), dim3(RBK_NT), lds, S_(st), *p, num_img, M, window, acts);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1454,8 +1534,8 @@ int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window,
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
     if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_mlp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");
-    // images split over workgroups, the weight gradients summed by atomics into buffers that hold values -- the trainer's flat
-    // gradient (accumulate != 0), or zeros written here first (accumulate == 0: 19 small memsets, not a path a training step takes)
+    // the weight gradients are summed by atomics into buffers that hold values -- the trainer's flat gradient (accumulate != 0),
+    // or zeros written here first (accumulate == 0: 19 small memsets, not a path a training step takes)
     if (!accumulate) {
         const size_t f = sizeof(float);
         LUSH_HIP(hipMemsetAsync(g->embed, 0, (size_t)num_img * 64 * f, S_(st)));
@@ -1473,11 +1553,11 @@ int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window,
         LUSH_HIP(hipMemsetAsync(g->w_v, 0, (size_t)3 * M * 32 * f, S_(st))); LUSH_HIP(hipMemsetAsync(g->b_v, 0, (size_t)3 * M * f, S_(st)));
         LUSH_HIP(hipMemsetAsync(g->w_w, 0, (size_t)(M + 1) * 32 * f, S_(st))); LUSH_HIP(hipMemsetAsync(g->b_w, 0, (size_t)(M + 1) * f, S_(st)));
     }
-    const int ipb = num_img < RBK_IPB ? num_img : RBK_IPB;
-    const size_t lds = ((size_t)2 * ipb * RBK_LS + RBK_WALL) * sizeof(float);
+    (void)scratch;      // (unused since the LDS version; kept in the signature)
+    const size_t lds = ((size_t)2 * RBK_IPB * RBK_LS + RBK_WALL) * sizeof(float);
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rbk_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(cdiv(num_img, ipb)), dim3(256), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g, scratch, 1,
-                       rvw_stride, ipb);
+    hipLaunchKernelGGL(rbk_mlp_bwd_kernel, dim3(cdiv(num_img, RBK_IPB)), dim3(RBK_NT), lds, S_(st), *p, num_img, M, window, acts, d_rvw, *g,
+                       rvw_stride);
     CHECK_LAUNCH();
     return 0;
 }
