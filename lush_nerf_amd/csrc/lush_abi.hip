@@ -580,7 +580,25 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
             j.n_out2 = n.HV;
         }
         if (fold) job(a.dzv + n.HV, ldzv, DZV_EXT, hv, n.HV, 0, n.HV, facH, n.HV, 0, facSH);   // rgb head: Z = the extra columns, X = views hidden
-        const int splits = dw_splits(L.Ppad);
+        // A workgroup ends a job with up to 64 K fp32 atomics on addresses every other slice of the job also adds to: ~50 us per
+        // job when 256 slices do it at once, whatever the point count (measured: 32 768 points, 11 jobs in turn, 0.55 ms).  Passes
+        // below LUSH_DW_PERJOB_MAX_PTS points therefore run ONE job per workgroup (grid: slices x jobs) with just enough slices to
+        // fill the chip once -- one round of atomics in all, 1 / slices of the contenders per address (the same pass: 0.15 ms;
+        // 4 096 points 0.107 -> 0.064 ms).  Above it a job's streaming time hides its atomics and every workgroup takes every job of
+        // its slice in turn, which balances the narrow jobs.
+#ifndef LUSH_DW_PERJOB_MAX_PTS
+#define LUSH_DW_PERJOB_MAX_PTS 262144
+#endif
+        int splits = dw_splits(L.Ppad);
+        G.per_job = 0;
+        if (L.Ppad <= LUSH_DW_PERJOB_MAX_PTS) {
+            int dev = 0, cus = 256;
+            if (current_device_cus(dev, cus) != 0) cus = 256;
+            long long sp = cus / G.n, most = L.Ppad / 256;
+            if (sp > most) sp = most;
+            splits = sp < 1 ? 1 : (int)sp;
+            G.per_job = 1;
+        }
         long long pps = (L.Ppad + splits - 1) / splits;
         pps = (pps + 31) / 32 * 32;
         G.Ppad = (int)L.Ppad;

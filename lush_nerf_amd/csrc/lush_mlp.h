@@ -248,6 +248,8 @@ struct DwGroup {
     int pts_per_split;             // multiple of 32
     const float* scale;            // {loss scale, 1/scale} when Z is loss-scaled fp16, else null
     const float* xd;               // [Ppad][8] points and view directions (MlpFwdArgs::xd), or null: every X2 is read from its rows
+    int per_job;                   // 1: grid (splits, n) -- a workgroup takes ONE job of its slice (launches whose slices alone leave
+                                   // CUs idle); 0: grid (splits) -- a workgroup takes every job of its slice in turn
 };
 
 }  // namespace lush

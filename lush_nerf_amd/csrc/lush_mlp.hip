@@ -1171,8 +1171,11 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
     for (int v = 0; v < 2; ++v) { b_off[v] = tr_off_sw(wi * 64 + v * 32, lane); x2_off[v] = tr_off_x2(v * 32, lane); }
     const unsigned sel_off = tr_off_sw(wo * 128 + wi * 32, lane);
 
-    for (int jj = 0; jj < G.n; ++jj) {
-        int jsel = (int)((blockIdx.x + (unsigned)jj) % (unsigned)G.n);
+    // (a small launch -- the 4 096-point noise net, configuration 1 -- has fewer slices than the chip has CUs and spent its time
+    // walking 7-19 jobs in series, each a ring refill + a few tiles + 64 K atomics: 69 us for 0.4 GFLOP; one job per workgroup then)
+    const int j_begin = G.per_job ? (int)blockIdx.y : 0, j_end = G.per_job ? (int)blockIdx.y + 1 : G.n;
+    for (int jj = j_begin; jj < j_end; ++jj) {
+        int jsel = G.per_job ? jj : (int)((blockIdx.x + (unsigned)jj) % (unsigned)G.n);
         jsel = __builtin_amdgcn_readfirstlane(jsel);
         const DwJob A = G.j[jsel];                      // one scalar load of the whole record per job
         const bool has_x2 = A.X2 != nullptr;
@@ -1439,16 +1442,18 @@ int launch_mlp_bwd(int net, int ns, const MlpBwdArgs& a, int grid, hipStream_t s
 // part 2: db_feat[i] += sum_v Wva[v][i] s[v];  db_views[v] += s[v]
 // part 3 (heads folded into the grouped launch): dW_rgb, db_rgb, dW_alpha, db_alpha = hi-plane row + lo-plane row
 // Each output has one owner and the launch is ordered after the grouped dW launch on the same stream: plain adds.
+constexpr int FF_VB = 8;        // rows v of dW_views per workgroup of part 1 (two per wave)
+constexpr int FF_KC = 128;      // columns k of W_feat staged per pass
 __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a) {
     const int HW = a.HW, HV = a.HV;
-    const int n0 = HW * HW, n1 = HV * HW, n2 = HW + HV, n3 = a.Hd ? 3 * HV + 3 + HW + 1 : 0;
-    int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n0) {
+    const int nb0 = HW * HW / 256, nb1 = (HW / 64) * (HV / FF_VB);
+    if ((int)blockIdx.x < nb0) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
         const int i = t / HW, k = t % HW;
-        // (four independent partial sums, eight products in flight: as one dependent chain of HV L2 loads the kernel was
-        // latency-bound, 38-46 us for 0.1 MFLOP)
+        // four independent partial sums, 32 products (64 loads) in flight: as one dependent chain of HV L2 loads the kernel was
+        // latency-bound, 38-46 us for 0.1 MFLOP; with 8 in flight 19 us
         float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 8
         for (int v = 0; v < HV; v += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc4[u] += a.w_views[(long long)(v + u) * a.ldv + i] * a.G[(v + u) * HW + k];
@@ -1456,29 +1461,59 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
         a.g_w_feat[t] += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         return;
     }
-    t -= n0;
-    if (t < n1) {
-        const int v = t / HW, i = t % HW;
-        const float4* g4 = reinterpret_cast<const float4*>(a.G + v * HW);      // scratch: 256-byte aligned
-        const float* wr = a.w_feat + (long long)i * HW;                        // a parameter: only 4-byte alignment is promised
-        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int k = 0; k < HW / 4; k += 4) {
+    if ((int)blockIdx.x < nb0 + nb1) {
+        // part 1, dW_views[v][i] += sum_k G[v][k] Wf[i][k] + s[v] b_f[i]: both operands are contiguous in k, so with a thread per
+        // (v, i) every lane walked its own 1-KiB row of Wf (64 cache lines per load instruction: 19 us per launch).  A workgroup
+        // now takes 64 rows i and FF_VB rows v: Wf[i0..i0+63][k] goes through LDS transposed (coalesced reads along k, pitch 65),
+        // lane = i reads T[k][lane] without conflicts, and G[v][k] is the same address for the whole wave.
+        __shared__ float T[FF_KC * 65];
+        const int b = blockIdx.x - nb0, n_it = HW / 64;
+        const int i0 = (b % n_it) * 64;
+        const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int v0 = __builtin_amdgcn_readfirstlane((b / n_it) * FF_VB + w * 2);
+        const float* __restrict__ g0 = a.G + (long long)v0 * HW;
+        const float* __restrict__ g1 = g0 + HW;
+        const float* __restrict__ wf = a.w_feat + (long long)i0 * HW;
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int kc = 0; kc < HW; kc += FF_KC) {
+            if (kc) __syncthreads();                       // the previous pass has been read
+            float tmp[64 * FF_KC / 256];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 g = g4[k + u];
-                acc4[u] += g.x * wr[4 * (k + u)] + g.y * wr[4 * (k + u) + 1] + g.z * wr[4 * (k + u) + 2] + g.w * wr[4 * (k + u) + 3];
+            for (int j = 0; j < 64 * FF_KC / 256; ++j) {
+                const int idx = j * 256 + threadIdx.x, r = idx / FF_KC, c = idx % FF_KC;
+                tmp[j] = wf[(long long)r * HW + kc + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 64 * FF_KC / 256; ++j) {
+                const int idx = j * 256 + threadIdx.x, r = idx / FF_KC, c = idx % FF_KC;
+                T[c * 65 + r] = tmp[j];
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int c0 = 0; c0 < FF_KC; c0 += 16) {
+                float tv[16], ga[16], gb[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { tv[j] = T[(c0 + j) * 65 + lane]; ga[j] = g0[kc + c0 + j]; gb[j] = g1[kc + c0 + j]; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { acc0 += ga[j] * tv[j]; acc1 += gb[j] * tv[j]; }
             }
         }
-        a.g_w_views[(long long)v * a.ldv + i] += ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + a.s[v] * a.b_feat[i];
+        const float bf = a.b_feat[i0 + lane];
+        a.g_w_views[(long long)v0 * a.ldv + i0 + lane] += acc0 + a.s[v0] * bf;
+        a.g_w_views[(long long)(v0 + 1) * a.ldv + i0 + lane] += acc1 + a.s[v0 + 1] * bf;
         return;
     }
-    t -= n1;
+    const int n2 = HW + HV, n3 = a.Hd ? 3 * HV + 3 + HW + 1 : 0;
+    int t = (blockIdx.x - nb0 - nb1) * 256 + threadIdx.x;
     if (t < n2) {
         if (t < HW) {
-            float acc = 0.f;
-            for (int v = 0; v < HV; ++v) acc += a.w_views[(long long)v * a.ldv + t] * a.s[v];
-            a.g_b_feat[t] += acc;
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int v = 0; v < HV; v += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc4[u] += a.w_views[(long long)(v + u) * a.ldv + t] * a.s[v + u];
+            }
+            a.g_b_feat[t] += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         } else {
             a.g_b_views[t - HW] += a.s[t - HW];
         }
@@ -1500,8 +1535,10 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
     }
 }
 int launch_feat_factor(const FeatFactorArgs& a, hipStream_t s) {
-    const int n = a.HW * a.HW + a.HV * a.HW + a.HW + a.HV + (a.Hd ? 3 * a.HV + 3 + a.HW + 1 : 0);
-    hipLaunchKernelGGL(feat_factor_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    if (a.HW % FF_KC != 0 || a.HV % FF_VB != 0 || (a.HW * a.HW) % 256 != 0) return set_error("launch_feat_factor: widths must be multiples of 128 (W) and 8 (W/2)");
+    const int tail = a.HW + a.HV + (a.Hd ? 3 * a.HV + 3 + a.HW + 1 : 0);
+    const int blocks = a.HW * a.HW / 256 + (a.HW / 64) * (a.HV / FF_VB) + (tail + 255) / 256;
+    hipLaunchKernelGGL(feat_factor_kernel, dim3(blocks), dim3(256), 0, s, a);
     LUSH_HIP(hipGetLastError());
     return 0;
 }
@@ -1554,7 +1591,7 @@ static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
     const size_t lds = (size_t)DMA_STAGES * GRP_STAGE + (g.xd ? 2 * GRP_PE_BYTES : 0);
     auto k = dw_group_kernel<XF16, ZF16, NS>;
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(splits), dim3(DW_THREADS2), lds, s, g);
+    hipLaunchKernelGGL(k, dim3(splits, g.per_job ? g.n : 1), dim3(DW_THREADS2), lds, s, g);
     LUSH_HIP(hipGetLastError());
     return 0;
 }

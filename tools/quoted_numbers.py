@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One source of truth for the numbers quoted in DESIGN.md and README.md.
 
-  python tools/numbers.py            # rewrites the blocks between <!-- numbers:NAME --> ... <!-- /numbers:NAME -->
-  python tools/numbers.py --check    # exit 1 if a block is out of date (tests/test_cpu_host.py runs this)
+  python tools/quoted_numbers.py            # rewrites the blocks between <!-- numbers:NAME --> ... <!-- /numbers:NAME -->
+  python tools/quoted_numbers.py --check    # exit 1 if a block is out of date (tests/test_cpu_host.py runs this)
 
 Sources, nothing else: the driver's latest BENCH_rNN.json at the repo root (the HEADLINE: what the driver measured on its
 own box at the end of the previous round), and this round's committed profile artefacts under profiles/ (rNN_bench_line.json =
@@ -129,6 +129,6 @@ if __name__ == "__main__":
     blk = blocks()
     stale = [f for f in ("DESIGN.md", "README.md") if rewrite(os.path.join(ROOT, f), blk, check)]
     if check and stale:
-        print("out of date (run tools/numbers.py):", stale)
+        print("out of date (run tools/quoted_numbers.py):", stale)
         sys.exit(1)
     print("up to date" if not stale else f"rewrote {stale}")
