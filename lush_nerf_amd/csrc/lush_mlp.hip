@@ -1012,6 +1012,15 @@ __device__ __forceinline__ void dw_pe_write(char* dst, const f32x4 c, int gch, i
 
 // The streaming loop of one job, specialised on the number of 32-column X2 blocks (0: none, the side accumulator is the
 // bias alone).  Nothing in it depends on the job except through `st` (registers) and three wave-uniform flags.
+#ifdef LUSH_PROF_DW   // developer build: s_memtime counts of workgroup 0 / thread 0 per phase of a job, read back through lush_debug_prof_dw
+__device__ unsigned long long lush_prof_dw[16];
+__device__ unsigned long long lush_prof_dw_span[2 * 1024];      // [b] start, [1024 + b] end of workgroup b (s_memtime: one clock for the chip)
+#define DPROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DPROF_ADD(slot, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) lush_prof_dw[slot] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#else
+#define DPROF_T(var)
+#define DPROF_ADD(slot, t0)
+#endif
 template <bool XF16, bool ZF16, int NV2, int NS>
 __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tiles, unsigned lds0, int n_tiles, int w, int lane,
                                            bool wave_live, bool row_live, bool x2_wave, const unsigned (&a_off)[4],
@@ -1038,6 +1047,7 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
         dma16s(st.xd, (unsigned)(pt * 32), __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(DMA_STAGES * GRP_STAGE + (k & 1) * GRP_PE_BYTES + w * 1024)));
     };
     constexpr bool PE = XF16 && NS == 1;                          // the only stash format the encoding is recomputed for
+    DPROF_T(t_pe0);
     if constexpr (NV2 > 0 && PE) {
         if (st.xd != nullptr) {       // chunk 0 before the first tile is issued (once per job: the only drain of the scheme)
             pe_chunk(0);
@@ -1045,6 +1055,7 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
+    DPROF_ADD(2, t_pe0);
     auto issue = [&](int slot) {
         const unsigned base = lds0 + (unsigned)slot * GRP_STAGE;
 #pragma unroll
@@ -1128,22 +1139,33 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
         else if (younger == 1) { if (five) grp_wait<5>(); else grp_wait<4>(); }
         else grp_wait<0>();
     };
+    DPROF_T(t_pro);
     for (int t = 0; t < DMA_STAGES - 1 && t < n_tiles; ++t) issue(t);
     int slot = 0;
     const int n_steady = n_tiles - (DMA_STAGES - 1);
+#ifdef LUSH_PROF_DW
+    bool first = true;
+#endif
+    DPROF_T(t_steady0);
     for (int t = 0; t < n_steady; ++t) {            // DMA_STAGES - 2 younger stages in flight behind the one awaited
         if (five) grp_wait<5 * (DMA_STAGES - 2)>(); else grp_wait<4 * (DMA_STAGES - 2)>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef LUSH_PROF_DW
+        if (first) { DPROF_ADD(3, t_pro); first = false; }
+#endif
         issue(slot == 0 ? DMA_STAGES - 1 : slot - 1);
         compute(slot);
         slot = slot + 1 == DMA_STAGES ? 0 : slot + 1;
     }
+    DPROF_ADD(4, t_steady0);
+    DPROF_T(t_drain);
     for (int t = n_steady < 0 ? 0 : n_steady; t < n_tiles; ++t) {     // drain: nothing left to issue
         wait_younger(n_tiles - 1 - t);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         compute(slot);
         slot = slot + 1 == DMA_STAGES ? 0 : slot + 1;
     }
+    DPROF_ADD(5, t_drain);
 }
 
 template <bool XF16, bool ZF16, int NS>
@@ -1155,6 +1177,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = w >> 2, wi = w & 3;
+    DPROF_T(t_kernel);
     const long long p_begin = (long long)blockIdx.x * G.pts_per_split;
     long long p_end = p_begin + G.pts_per_split;
     if (p_end > G.Ppad) p_end = G.Ppad;
@@ -1182,6 +1205,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
         const bool wave_live = (wo * 128 < A.n_out) && (wi * 64 < A.k_in);
         const bool row_live = wo * 128 + wi * 32 < A.n_out;           // this wave's 32 rows of the bias / X2 blocks
         const int nv2 = has_x2 ? (A.k2_in > 32 ? 2 : 1) : 0;
+        DPROF_T(t_zero);
         // columns beyond a job's widths are never written by its DMAs: start every job from a zeroed ring
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone has left the previous job's tiles
         for (int i = tid; i < DMA_STAGES * GRP_STAGE / 16; i += DW_THREADS2)
@@ -1196,6 +1220,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
             for (int a = 0; a < 4; ++a) { acc[a][0][q] = 0.f; acc[a][1][q] = 0.f; }
             accs[0][q] = 0.f; accs[1][q] = 0.f;
         }
+        DPROF_ADD(1, t_zero);
         const int bias_blk = nv2 ? nv2 - 1 : 0;                    // block that carries the bias column (its column 31)
         const bool x2_wave = has_x2 && w < 4;          // waves 0..3 move the four 1-KiB pieces of the X2 tile
         GrpStream st;
@@ -1240,6 +1265,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
         if (nv2 == 0) grp_stream<XF16, ZF16, 0, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
         else if (nv2 == 1) grp_stream<XF16, ZF16, 1, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
         else grp_stream<XF16, ZF16, 2, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
+        DPROF_T(t_flush);
         if (row_live) {
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
@@ -1268,7 +1294,15 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                         if (o < A.n_out && i < A.k_in) atomicAdd(A.dW + (long long)o * A.ldw + A.wcol0 + i, acc[u][v][q] * unscale);
                     }
         }
+        DPROF_ADD(6, t_flush);
+#ifdef LUSH_PROF_DW
+        if (blockIdx.x == 0 && threadIdx.x == 0) lush_prof_dw[8] += 1;
+#endif
     }
+    DPROF_ADD(0, t_kernel);
+#ifdef LUSH_PROF_DW
+    if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) { lush_prof_dw_span[blockIdx.x] = t_kernel; lush_prof_dw_span[1024 + blockIdx.x] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
 
 // Loss scale of the fp16 gradient chain: scale = 2^k with max|d_raw| * scale in [8, 16) (gradients grow by at most
@@ -1595,6 +1629,21 @@ static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
     LUSH_HIP(hipGetLastError());
     return 0;
 }
+#ifdef LUSH_PROF_DW
+}  // namespace lush
+extern "C" int lush_debug_prof_dw(unsigned long long* out, int reset) {
+    LUSH_HIP(hipDeviceSynchronize());
+    LUSH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lush::lush_prof_dw), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {}; LUSH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(lush::lush_prof_dw), z, sizeof(z))); }
+    return 0;
+}
+extern "C" int lush_debug_prof_dw_span(unsigned long long* out) {
+    LUSH_HIP(hipDeviceSynchronize());
+    LUSH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(lush::lush_prof_dw_span), sizeof(unsigned long long) * 2048));
+    return 0;
+}
+namespace lush {
+#endif
 // one launch for all the weight-gradient GEMMs of a network pass (ns = 1: one 16-bit plane per operand; 2: two bf16 planes)
 int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16, hipStream_t s) {
     for (int i = 0; i < g.n; ++i) {

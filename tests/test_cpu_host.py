@@ -425,5 +425,5 @@ def test_bench_self_launch_builds_the_documented_command(monkeypatch):
 def test_quoted_numbers_match_their_sources():
     """Every number in the marked blocks of DESIGN.md / README.md is what tools/quoted_numbers.py derives from the driver's BENCH_rNN.json
     (the file the status block names) and the committed profiles/ artefacts: no hand-edited figures."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "numbers.py"), "--check"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quoted_numbers.py"), "--check"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
