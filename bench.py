@@ -367,8 +367,7 @@ def main():
 
         def one(i, graph_body=False):
             b = static if graph_body else batches[i % n_batches]
-            tr.flat.grad.zero_()
-            tr._pack_weights()                   # one launch for every network (ops.PackPlan), as Trainer.step does
+            tr._pack_weights(zero_grad=True)     # one launch for every network (ops.PackPlan) that also clears the gradients, as Trainer.step does
             rays = ops.gen_rays(b["c2w"], b["view"], b["px"], b["py"], K)
             if graph_body:      # rate, Adam step count and draw counter from the device step state (include/lush_march.h)
                 net.hooks.state, net.hooks.draw_delta = state, 0

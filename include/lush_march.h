@@ -28,10 +28,11 @@ extern "C" {
 typedef void* lush_stream_t;
 
 const char* lush_last_error(void);
-int lush_abi_version(void);   /* 7 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
+int lush_abi_version(void);   /* 8 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
                              * backward entry points write their outputs instead of accumulating; 7, round 4: the fused ray-level
                              * entry points lush_rbk_warp_ndc_* and lush_blur_mix_*, an explicit d_rvw row stride, and no second
-                             * stream inside lush_march_bwd) */
+                             * stream inside lush_march_bwd; 8: lush_pack_plan_run takes a buffer to clear, lush_adam_multi /
+                             * lush_adam_state_multi update several segments in one launch) */
 
 /* ------------------------------------------------------------------ sampling
  * z grid + stratified jitter: models/lushnerf.py:389-412 / 501-523.
@@ -283,7 +284,9 @@ typedef struct {
 } lush_pack_job;
 size_t lush_pack_plan_bytes(int n_jobs);
 int lush_pack_plan_build(const lush_pack_job* jobs, int n_jobs, void* plan, size_t plan_bytes, int* launch_blocks);
-int lush_pack_plan_run(const void* plan, int launch_blocks, lush_stream_t stream);
+/* zero_n > 0 (ABI 8): the same launch clears zero_buf[0 .. zero_n) -- the trainer's flat gradient buffer, i.e. the step's zero_grad
+ * (run_lushnerf.py:652 optimizer.zero_grad()) without a fill launch of its own. */
+int lush_pack_plan_run(const void* plan, int launch_blocks, float* zero_buf, long long zero_n, lush_stream_t stream);
 /* Re-pack the fp32 parameters into MFMA fragment order (forward and transposed). */
 int lush_mlp_pack(int net, int planes, const lush_mlp_params* prm, void* packed, lush_stream_t stream);
 /* ... only the copies the kernels selected by `variant` read (variant < 0: all of them, as lush_mlp_pack). */
@@ -385,6 +388,11 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
  * torch.optim.Adam step on a flat segment (run_lushnerf.py:368-371, 675-685). */
 int lush_adam(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1,
               float beta2, float eps, int step, float grad_scale, lush_stream_t stream);
+/* One launch for up to three CONSECUTIVE segments of one flat buffer: segment s = elements [end(s-1), end(s)), end(-1) = 0, at its
+ * own step count steps[s] (torch.optim.Adam keeps one per parameter; parameters without a gradient do not count the step); bit s
+ * of `mask` clear = segment s is skipped. */
+int lush_adam_multi(float* param, const float* grad, float* m, float* v, long long end0, long long end1, long long end2, int mask,
+                    float lr, float beta1, float beta2, float eps, const int* steps, float grad_scale, lush_stream_t stream);
 
 /* ------------------------------------------------------------- step state on the device
  * What a training step otherwise takes from the host as kernel arguments -- the learning rate (run_lushnerf.py:675-685), Adam's
@@ -403,6 +411,10 @@ int lush_draws_state(unsigned long long seed, unsigned long long offset, const v
                      float* noise_c, long long n_c, float* u, long long n_u, float* noise_f, long long n_f, lush_stream_t stream);
 int lush_adam_state(float* param, const float* grad, float* m, float* v, long long n, const void* state, int segment,
                     float beta1, float beta2, float eps, float grad_scale, lush_stream_t stream);
+/* The same step for up to three CONSECUTIVE segments of one flat buffer in one launch: segment s covers the elements
+ * [end(s-1), end(s)) with end(-1) = 0; bit s of `mask` clear = the segment is skipped (no gradient this step). */
+int lush_adam_state_multi(float* param, const float* grad, float* m, float* v, long long end0, long long end1, long long end2,
+                          const void* state, int mask, float beta1, float beta2, float eps, float grad_scale, lush_stream_t stream);
 
 /* Test hooks (tests/ only): raw access to a stash array for layer-wise parity. */
 int lush_debug_stash_layout(int net, int planes, long long P, long long* offsets /* host, 16 entries */);

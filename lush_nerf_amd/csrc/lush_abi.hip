@@ -382,9 +382,10 @@ int lush_pack_plan_build(const lush_pack_job* jobs, int n_jobs, void* plan, size
     return 0;
 }
 
-int lush_pack_plan_run(const void* plan, int launch_blocks, lush_stream_t stream) {
+int lush_pack_plan_run(const void* plan, int launch_blocks, float* zero_buf, long long zero_n, lush_stream_t stream) {
     if (!plan || launch_blocks < 1) return set_error("lush_pack_plan_run: no plan");
-    return launch_pack_plan(plan, launch_blocks, (hipStream_t)stream);
+    if (zero_n < 0 || (zero_n > 0 && !zero_buf)) return set_error("lush_pack_plan_run: bad zero buffer");
+    return launch_pack_plan(plan, launch_blocks, (hipStream_t)stream, zero_n > 0 ? zero_buf : nullptr, zero_n);
 }
 
 size_t lush_mlp_stash_bytes(int net, int planes_fwd, int stash_planes, long long P) {
@@ -495,10 +496,14 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.dpts = dpts;
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
+    bool fac_zeroed = false;       // the feature-factor scratch of the grouped weight gradients was zeroed by the loss-scale launch
     if (do_chain && z_f16 && !prepared) {
         if (!draw) return set_error("lush_mlp_bwd: draw is required");
-        LUSH_HIP(hipMemsetAsync(gscale, 0, 16, st));
-        rc = launch_grad_scale(draw, P * 4, gscale, st);
+        // (chain and weight gradients in ONE call -- the noise net's backward: the loss-scale launch also zeroes the scratch the
+        // grouped launch accumulates into, instead of a fill launch of its own)
+        fac_zeroed = do_weights && planes_b <= 2;
+        rc = launch_grad_scale(draw, P * 4, gscale, fac_zeroed ? (float*)(db + D.fac) : nullptr,
+                               fac_zeroed ? (long long)((n.HV + DZV_EXT) * (n.HW + 1) + DZV_EXT * (n.HV + 1)) : 0, st);
         if (rc) return rc;
     }
     if (do_chain) rc = chain ? launch_mlp_chain_bwd(net, code_b, a, variant, st) : launch_mlp_bwd(net, planes_b, a, grid, st);
@@ -573,7 +578,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         float* facS = facG + (size_t)grow * n.HW;            // [grow]
         float* facH = facS + grow;                           // [DZV_EXT][HV]
         float* facSH = facH + (size_t)DZV_EXT * n.HV;        // [DZV_EXT]
-        if (!prepared) LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(grow * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4, st));
+        if (!prepared && !fac_zeroed) LUSH_HIP(hipMemsetAsync(facG, 0, (size_t)(grow * (n.HW + 1) + DZV_EXT * (n.HV + 1)) * 4, st));
         {
             DwJob& j = job(a.dzv, ldzv, fold && alpha ? grow : n.HV, H(n.NL - 1), n.HW, 0, n.HW, facG, n.HW, 0, facS);
             with_pe(j, PE_X, DV, g->w_views, n.HW + DV, n.HW);

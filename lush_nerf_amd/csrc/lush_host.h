@@ -70,12 +70,12 @@ int launch_mlp_wide_fwd(const MlpFwdArgs& a, hipStream_t s);
 // lush_mlp_wide_bwd.hip
 int launch_mlp_wide_bwd(const MlpBwdArgs& a, hipStream_t s);
 int launch_pack(int ns, const PackTable& t, int total_blocks, void* dst, hipStream_t s);
-int launch_pack_plan(const void* plan, int blocks, hipStream_t s);
+int launch_pack_plan(const void* plan, int blocks, hipStream_t s, float* zero_buf, long long zero_n);
 int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStream_t s);
 int launch_dw(int ns, const DwArgs& a, int splits, hipStream_t s);
 int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16, hipStream_t s);
 int launch_feat_factor(const FeatFactorArgs& a, hipStream_t s);
-int launch_grad_scale(const float* draw, long long n, float* scale, hipStream_t s);
+int launch_grad_scale(const float* draw, long long n, float* scale, float* zero_buf, long long zero_n, hipStream_t s);
 int launch_head_dw(int ns, bool x_f16, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
                    float* db_alpha, hipStream_t s);

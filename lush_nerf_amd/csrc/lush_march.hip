@@ -1367,6 +1367,39 @@ __global__ void adam_state_kernel(float* __restrict__ p, const float* __restrict
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= (lr / bc1) * (mi / denom);
 }
+// the same update over SEVERAL segments of one flat buffer in one launch: element i belongs to segment (i >= end0) + (i >= end1);
+// segments whose bit is clear in `mask` are left alone (the reference's grad=None parameters: Adam skips them, counts included)
+__global__ void adam_state_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                        float* __restrict__ v, long long end0, long long end1, long long end2,
+                                        const StepState* __restrict__ st, int mask, float b1, float b2, float eps, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end2) return;
+    const int seg = (i >= end0) + (i >= end1);
+    if (!((mask >> seg) & 1)) return;
+    const float lr = st->lr, bc1 = st->bc1[seg], bc2_sqrt = st->bc2s[seg];
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+struct AdamMulti { long long end[3]; float bc1[3], bc2s[3]; int mask; };
+__global__ void adam_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                  const AdamMulti A, float lr, float b1, float b2, float eps, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.end[2]) return;
+    const int seg = (i >= A.end[0]) + (i >= A.end[1]);
+    if (!((A.mask >> seg) & 1)) return;
+    const float bc1 = seg == 0 ? A.bc1[0] : seg == 1 ? A.bc1[1] : A.bc1[2];
+    const float bc2_sqrt = seg == 0 ? A.bc2s[0] : seg == 1 ? A.bc2s[1] : A.bc2s[2];
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
 __device__ void step_state_derive(StepState* st, double lrate, double decay_steps, double b1, double b2) {
     const int g = st->global_step - 1 > 0 ? st->global_step - 1 : 0;
     st->lr = (float)(lrate * pow(0.1, (double)g / decay_steps));
@@ -1406,7 +1439,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 7; }
+int lush_abi_version(void) { return 8; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
@@ -1699,6 +1732,24 @@ int lush_adam(float* param, const float* grad, float* m, float* v, long long n, 
     return 0;
 }
 
+int lush_adam_multi(float* param, const float* grad, float* m, float* v, long long end0, long long end1, long long end2, int mask,
+                    float lr, float beta1, float beta2, float eps, const int* steps, float grad_scale, lush_stream_t st) {
+    if (!steps || end0 < 0 || end1 < end0 || end2 < end1 || mask < 0 || mask > 7) return set_error("lush_adam_multi: bad segment ends / mask / steps");
+    AdamMulti A;
+    A.end[0] = end0; A.end[1] = end1;
+    A.end[2] = (mask & 4) ? end2 : (mask & 2) ? end1 : (mask & 1) ? end0 : 0;      // (only up to the end of the last active segment)
+    A.mask = mask;
+    for (int s = 0; s < 3; ++s) {
+        const int t = steps[s] > 0 ? steps[s] : 1;
+        A.bc1[s] = (float)(1.0 - pow((double)beta1, (double)t));
+        A.bc2s[s] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    }
+    if (A.end[2] <= 0) return 0;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(cdiv(A.end[2], 256)), dim3(256), 0, S_(st), param, grad, m, v, A, lr, beta1, beta2, eps, grad_scale);
+    CHECK_LAUNCH();
+    return 0;
+}
+
 size_t lush_step_state_bytes(void) { return sizeof(StepState); }
 int lush_step_state_init(void* state, unsigned long long draw_base, int global_step, const int* adam_steps, double lrate,
                          double decay_steps, double beta1, double beta2, lush_stream_t st) {
@@ -1722,6 +1773,18 @@ int lush_adam_state(float* param, const float* grad, float* m, float* v, long lo
     if (!state || segment < 0 || segment > 2) return set_error("lush_adam_state: bad state / segment");
     hipLaunchKernelGGL(adam_state_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), param, grad, m, v, n,
                        static_cast<const StepState*>(state), segment, beta1, beta2, eps, grad_scale);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_adam_state_multi(float* param, const float* grad, float* m, float* v, long long end0, long long end1, long long end2,
+                          const void* state, int mask, float beta1, float beta2, float eps, float grad_scale, lush_stream_t st) {
+    if (!state || end0 < 0 || end1 < end0 || end2 < end1 || mask < 0 || mask > 7) return set_error("lush_adam_state_multi: bad state / segment ends / mask");
+    // (only up to the end of the last active segment)
+    const long long n = (mask & 4) ? end2 : (mask & 2) ? end1 : (mask & 1) ? end0 : 0;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_state_multi_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(st), param, grad, m, v, end0, end1, n,
+                       static_cast<const StepState*>(state), mask, beta1, beta2, eps, grad_scale);
     CHECK_LAUNCH();
     return 0;
 }

@@ -90,7 +90,18 @@ __global__ void pack_f32_kernel(const MlpParams P, float* __restrict__ dst) {
 }
 
 // The whole plan in one launch: block b -> its job by binary search over the prefix sums.
-__global__ __launch_bounds__(64) void pack_plan_kernel(const PlanHeader* __restrict__ H) {
+__global__ __launch_bounds__(64) void pack_plan_kernel(const PlanHeader* __restrict__ H, float* __restrict__ zero_buf, long long zero_n) {
+    // (the step's first launch also clears the flat gradient buffer: the trainer's zero_grad without a fill launch of its own)
+    if (zero_buf != nullptr) {
+        const long long t = (long long)blockIdx.x * 64 + threadIdx.x, nt = (long long)gridDim.x * 64;
+        if ((reinterpret_cast<size_t>(zero_buf) & 15) == 0) {
+            float4* z4 = reinterpret_cast<float4*>(zero_buf);
+            for (long long i = t; i < zero_n / 4; i += nt) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long i = zero_n / 4 * 4 + t; i < zero_n; i += nt) zero_buf[i] = 0.f;
+        } else {
+            for (long long i = t; i < zero_n; i += nt) zero_buf[i] = 0.f;
+        }
+    }
     const MlpParams* prm = reinterpret_cast<const MlpParams*>(H + 1);
     const PlanJob* jobs = reinterpret_cast<const PlanJob*>(prm + PLAN_MAX_NETS);
     const int b = blockIdx.x;
@@ -1310,11 +1321,15 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
 // finite.  One launch: per-block maxima by atomicMax on the bit pattern (non-negative floats order as integers),
 // the last block to finish writes {scale, 1/scale} and re-arms the two words it used.
 __global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ draw, long long n, float* __restrict__ out,
-                                                        unsigned* __restrict__ work /* [2]: running max bits, finished blocks */) {
+                                                        unsigned* __restrict__ work /* [2]: running max bits, finished blocks */,
+                                                        float* __restrict__ zero_buf, long long zero_n) {
+    // (the weight-gradient pass's small scratch accumulators, zeroed here instead of by a fill launch of their own)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (long long)gridDim.x * blockDim.x) zero_buf[i] = 0.f;
     float m = 0.f;
     // 16 bytes per lane and trip (d_raw is [P][4]: n is a multiple of 4 and the rows are 16-byte aligned); with 4-byte loads the
     // fine pass's 42 MB took 34 us
     const float4* d4 = reinterpret_cast<const float4*>(draw);
+#pragma unroll 8
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
         const float4 v = d4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -1327,10 +1342,14 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-        atomicMax(work, __float_as_uint(m));
-        __threadfence();
-        if (atomicAdd(work + 1, 1u) == gridDim.x - 1) {
-            const float mx = __uint_as_float(atomicMax(work, 0u));
+        bool last = gridDim.x == 1;          // (a single workgroup -- the noise net's 4 096 rays -- needs no work words and no zero-fill)
+        if (!last) {
+            atomicMax(work, __float_as_uint(m));
+            __threadfence();
+            last = atomicAdd(work + 1, 1u) == gridDim.x - 1;
+        }
+        if (last) {
+            const float mx = gridDim.x == 1 ? m : __uint_as_float(atomicMax(work, 0u));
             float sc = 1.f;
             if (mx > 0.f && mx < 3.0e38f) {
                 int e;
@@ -1589,8 +1608,8 @@ int launch_pack_f32(int net, int ns, const MlpParams& prm, void* packed, hipStre
     return 0;
 }
 
-int launch_pack_plan(const void* plan, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL(pack_plan_kernel, dim3(blocks), dim3(64), 0, s, reinterpret_cast<const PlanHeader*>(plan));
+int launch_pack_plan(const void* plan, int blocks, hipStream_t s, float* zero_buf, long long zero_n) {
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(blocks), dim3(64), 0, s, reinterpret_cast<const PlanHeader*>(plan), zero_buf, zero_n);
     LUSH_HIP(hipGetLastError());
     return 0;
 }
@@ -1665,10 +1684,13 @@ int launch_dw_group(const DwGroup& g, int splits, int ns, bool x_f16, bool z_f16
     return x_f16 ? launch_dw_group_t<true, false, 1>(g, splits, s) : launch_dw_group_t<false, false, 1>(g, splits, s);
 }
 
-int launch_grad_scale(const float* draw, long long n, float* scale /* {scale, 1/scale, 2 work words} */, hipStream_t s) {
+int launch_grad_scale(const float* draw, long long n, float* scale /* {scale, 1/scale, 2 work words} */, float* zero_buf, long long zero_n,
+                      hipStream_t s) {
     int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-    hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, s, draw, n, scale, reinterpret_cast<unsigned*>(scale + 2));
+    if (n <= 65536) blocks = 1;       // 16 K float4 for 256 threads: ~5 us either way, and one launch instead of fill + launch
+    if (blocks > 1) LUSH_HIP(hipMemsetAsync(scale, 0, 16, s));      // the work words (the scratch is the caller's fresh memory)
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, s, draw, n, scale, reinterpret_cast<unsigned*>(scale + 2), zero_buf, zero_n);
     LUSH_HIP(hipGetLastError());
     return 0;
 }

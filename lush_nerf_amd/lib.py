@@ -183,7 +183,7 @@ _SIGS = {
     "lush_mlp_packed_bytes": ([_i, _i], _sz),
     "lush_pack_plan_bytes": ([_i], _sz),
     "lush_pack_plan_build": ([_p, _i, _p, _sz, _p], _i),
-    "lush_pack_plan_run": ([_p, _i, _p], _i),
+    "lush_pack_plan_run": ([_p, _i, _p, _ll, _p], _i),
     "lush_mlp_pack": ([_i, _i, C.POINTER(MlpParams), _p, _p], _i),
     "lush_mlp_pack_for": ([_i, _i, C.POINTER(MlpParams), _p, _i, _p], _i),
     "lush_mlp_stash_bytes": ([_i, _i, _i, _ll], _sz),
@@ -206,10 +206,12 @@ _SIGS = {
     "lush_step_state_advance": ([_p, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, _p], _i),
     "lush_draws_state": ([C.c_ulonglong, C.c_ulonglong, _p, _p, _ll, _p, _ll, _p, _ll, _p, _ll, _p], _i),
     "lush_adam_state": ([_p, _p, _p, _p, _ll, _p, _i, _f, _f, _f, _f, _p], _i),
+    "lush_adam_multi": ([_p, _p, _p, _p, _ll, _ll, _ll, _i, _f, _f, _f, _f, _p, _f, _p], _i),
+    "lush_adam_state_multi": ([_p, _p, _p, _p, _ll, _ll, _ll, _p, _i, _f, _f, _f, _f, _p], _i),
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 7
+ABI_VERSION = 8
 PLANES_F16 = 17          # include/lush_march.h: plane code of ONE fp16 plane (1..3 = bf16 planes)
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
 VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 64

@@ -151,8 +151,12 @@ class PackPlan:
         self.blocks = int(blocks.value)
         self.signature = tuple((int(net), int(planes), int(variant), tuple(t.data_ptr() for t in tensors)) for net, planes, tensors, variant in entries)
 
-    def run(self):
-        lib.call("lush_pack_plan_run", lib.ptr(self.plan), self.blocks, _stream())
+    def run(self, zero: Optional[torch.Tensor] = None):
+        """Enqueue the one launch; `zero` (a contiguous fp32 tensor, e.g. the trainer's flat gradient) is cleared by the same kernel."""
+        if zero is not None and (zero.dtype != torch.float32 or not zero.is_contiguous()):
+            raise ValueError("PackPlan.run: the buffer to clear must be contiguous fp32")
+        lib.call("lush_pack_plan_run", lib.ptr(self.plan), self.blocks, lib.ptr(zero) if zero is not None else None,
+                 zero.numel() if zero is not None else 0, _stream())
 
 
 def _packed_for(hooks, tensors, planes):
@@ -861,6 +865,21 @@ def adam_step_state(param, grad, m, v, state, segment, beta1=0.9, beta2=0.999, e
     """The same step with rate and bias corrections read from the device step state (Trainer.step_graph)."""
     lib.call("lush_adam_state", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), param.numel(), lib.ptr(state), int(segment),
              float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
+
+
+def adam_step_multi(param, grad, m, v, ends, mask, lr, steps, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """adam_step over the consecutive segments [0, ends[0]), [ends[0], ends[1]), [ends[1], ends[2]) of one flat buffer in one launch,
+    segment s at its own step count steps[s]; bit s of `mask` clear = segment s is skipped."""
+    st = (C.c_int * 3)(*[int(x) for x in steps])
+    lib.call("lush_adam_multi", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), int(ends[0]), int(ends[1]), int(ends[2]), int(mask),
+             float(lr), float(beta1), float(beta2), float(eps), st, float(grad_scale), _stream())
+
+
+def adam_step_state_multi(param, grad, m, v, ends, state, mask, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """adam_step_state over the consecutive segments [0, ends[0]), [ends[0], ends[1]), [ends[1], ends[2]) of one flat buffer in one
+    launch; bit s of `mask` clear = segment s is skipped."""
+    lib.call("lush_adam_state_multi", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), int(ends[0]), int(ends[1]), int(ends[2]),
+             lib.ptr(state), int(mask), float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
 
 
 def gen_rays(c2w, view, px, py, K):

@@ -138,6 +138,8 @@ class Trainer:
         # test seam: the CPU (gloo) tests replace the HIP forward+backward of one slice by injected gradients
         self._fwd_bwd = step_fn or self._hip_forward_backward
         self._adam = ops.adam_step
+        sg = self.flat.segments      # (three groups laid out one after the other: one Adam launch covers the active ones)
+        self._segments_consecutive = len(sg) == 3 and sg[0][0] == 0 and sg[1][0] == sg[0][1] and sg[2][0] == sg[1][1]
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
         # scratch of the loss kernel's reduction (zero once, left zero by every launch: no zero-fill per step)
         self._loss_work = torch.zeros(2, dtype=torch.float32, device=self.flat.param.device) if self.flat.param.is_cuda else None
@@ -194,16 +196,19 @@ class Trainer:
             ent.append((ops.NET_NOISE, pn.bwd, self.model.mlp_noise_coarse.tensors(), -1))
         return ent
 
-    def _pack_weights(self):
+    def _pack_weights(self, zero_grad=False):
         """ONE launch re-packs every network's MFMA fragments for this step (ops.PackPlan; the plan is rebuilt when the precision
-        mode or a parameter's address changes) and hands them to the step's ops through the model's hooks."""
+        mode or a parameter's address changes) and hands them to the step's ops through the model's hooks.  With zero_grad the
+        same launch clears the flat gradient buffer (the step's zero_grad); without the HIP path it is cleared here."""
         if not self.flat.param.is_cuda or self._fwd_bwd != self._hip_forward_backward:
+            if zero_grad:
+                self.flat.grad.zero_()
             return
         ent = self._pack_entries()
         sig = tuple((int(n), int(p), int(v), tuple(t.data_ptr() for t in ts)) for n, p, ts, v in ent)
         if self._pack_plan is None or self._pack_plan.signature != sig:
             self._pack_plan = ops.PackPlan(ent)
-        self._pack_plan.run()
+        self._pack_plan.run(self.flat.grad if zero_grad else None)
         self.model.hooks.packed = self._pack_plan.buffers
 
     # ------------------------------------------------------------------ one slice on the GPU
@@ -236,7 +241,6 @@ class Trainer:
         """One optimisation step on a batch {rays [N,3,2] (or c2w/view/px/py for device-side ray generation),
         images_idx [N,1], target [N,3], fq_mask [N]}."""
         self.model.train()
-        self.flat.grad.zero_()
         force_naive = i < self.kernel_start_iter
         N = batch["target"].shape[0]
         mb = self.micro_batch if 0 < self.micro_batch < N else N
@@ -244,7 +248,7 @@ class Trainer:
         hooks = self.model.hooks
         sink_before, hooks.sink = hooks.sink, True
         try:      # dW kernels add straight into the flat gradient (p.grad are views of it)
-            self._pack_weights()
+            self._pack_weights(zero_grad=True)
             for a in range(0, N, mb):
                 b = min(a + mb, N)
                 part = self._fwd_bwd(batch, a, b, i, draws, (b - a) / N, force_naive)
@@ -263,8 +267,15 @@ class Trainer:
         for s, (a, b) in enumerate(self.flat.segments):
             if active[s] and b > a:
                 self.steps[s] += 1
-                self._adam(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
-                           grad_scale=1.0 / self.world)
+        if self._segments_consecutive and self._adam is ops.adam_step:
+            mask = sum(1 << s for s, (a, b) in enumerate(self.flat.segments) if active[s] and b > a)
+            ops.adam_step_multi(self.flat.param, self.flat.grad, self.m, self.v, [b for _, b in self.flat.segments], mask, lr, self.steps,
+                                grad_scale=1.0 / self.world)
+        else:
+            for s, (a, b) in enumerate(self.flat.segments):
+                if active[s] and b > a:
+                    self._adam(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], lr, self.steps[s],
+                               grad_scale=1.0 / self.world)
         self.global_step += 1
         return loss
 
@@ -283,7 +294,6 @@ class Trainer:
     def _body_grads(self, batch, i, force_naive, state):
         """First half of what step() enqueues -- zero the flat gradient, forward + backward of every micro-batch -- with the
         Philox draw counter taken from the device step state."""
-        self.flat.grad.zero_()
         N = batch["target"].shape[0]
         mb = self.micro_batch if 0 < self.micro_batch < N else N
         loss = None
@@ -291,7 +301,7 @@ class Trainer:
         sink_before, hooks.sink = hooks.sink, True
         hooks.state, hooks.draw_delta = state, 0
         try:
-            self._pack_weights()
+            self._pack_weights(zero_grad=True)
             for a in range(0, N, mb):
                 b = min(a + mb, N)
                 part = self._fwd_bwd(batch, a, b, i, None, (b - a) / N, force_naive)
@@ -303,11 +313,15 @@ class Trainer:
     def _body_update(self, force_naive, state, calls):
         """Second half: Adam on the active segments with rate / step counts from the device step state, then advance it."""
         active = [True, not force_naive, False]
-        for s, (a, b) in enumerate(self.flat.segments):
-            if active[s] and b > a:
-                ops.adam_step_state(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], state, s,
-                                    grad_scale=1.0 / self.world)
         mask = sum(1 << s for s, (a, b) in enumerate(self.flat.segments) if active[s] and b > a)
+        ends = [b for _, b in self.flat.segments]
+        if self._segments_consecutive:
+            ops.adam_step_state_multi(self.flat.param, self.flat.grad, self.m, self.v, ends, state, mask, grad_scale=1.0 / self.world)
+        else:
+            for s, (a, b) in enumerate(self.flat.segments):
+                if active[s] and b > a:
+                    ops.adam_step_state(self.flat.param[a:b], self.flat.grad[a:b], self.m[a:b], self.v[a:b], state, s,
+                                        grad_scale=1.0 / self.world)
         ops.lib.call("lush_step_state_advance", ops.lib.ptr(state), int(calls), int(mask), float(self.lrate),
                      float(self.lrate_decay * 1000), 0.9, 0.999, ops._stream())
         return mask

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     assert set(lib.EXPORTS) <= declared | {"lush_last_error"}
     l = lib.load()
-    assert l.lush_abi_version() == lib.ABI_VERSION == 7
+    assert l.lush_abi_version() == lib.ABI_VERSION == 8
     # pure host queries (no device work)
     p1, p3 = l.lush_mlp_packed_bytes(0, 1), l.lush_mlp_packed_bytes(0, 3)
     assert p1 > 2 * 593408 * 2 and 2.9 * p1 < p3 < 3 * p1      # fragments scale with planes, the fp32 bias block does not

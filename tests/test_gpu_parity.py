@@ -699,6 +699,44 @@ def test_step_graph_resynchronises_with_the_host(diag, mode, tmp_path):
     print(f"step_graph after a checkpoint load: losses within {worst:.1e} of the eager steps, parameters within {dp:.1e}")
 
 
+def test_adam_multi_equals_per_segment(diag):
+    """lush_adam_multi / lush_adam_state_multi (ABI 8: the active segments of the flat parameter buffer in ONE launch) give, bit
+    for bit, what one lush_adam / lush_adam_state launch per segment gives -- own step count per segment, skipped segments untouched."""
+    import ctypes as C
+    from lush_nerf_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ends = [70001, 70001 + 3333, 70001 + 3333 + 129]
+    n = ends[2]
+    p0, gr, m0 = (torch.randn(n, generator=g).to(dev) for _ in range(3))
+    v0 = torch.rand(n, generator=g).to(dev)
+    steps = [3, 7, 1]
+    for mask in (1, 3, 5, 7, 2):
+        a = [t.clone() for t in (p0, m0, v0)]
+        b = [t.clone() for t in (p0, m0, v0)]
+        ops.adam_step_multi(a[0], gr, a[1], a[2], ends, mask, 5e-4, steps, grad_scale=0.5)
+        lo = 0
+        for s_, hi in enumerate(ends):
+            if (mask >> s_) & 1:
+                ops.adam_step(b[0][lo:hi], gr[lo:hi], b[1][lo:hi], b[2][lo:hi], 5e-4, steps[s_], grad_scale=0.5)
+            lo = hi
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), mask
+        # the device-state form: rate and bias corrections from lush_step_state (steps taken so far = steps - 1)
+        state = torch.zeros(diag.lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
+        st = (C.c_int * 3)(*[x - 1 for x in steps])
+        diag.lib.call("lush_step_state_init", diag.lib.ptr(state), C.c_ulonglong(0), 10, st, 5e-4, 250000.0, 0.9, 0.999, ops._stream())
+        a = [t.clone() for t in (p0, m0, v0)]
+        b = [t.clone() for t in (p0, m0, v0)]
+        ops.adam_step_state_multi(a[0], gr, a[1], a[2], ends, state, mask, grad_scale=0.5)
+        lo = 0
+        for s_, hi in enumerate(ends):
+            if (mask >> s_) & 1:
+                ops.adam_step_state(b[0][lo:hi], gr[lo:hi], b[1][lo:hi], b[2][lo:hi], state, s_, grad_scale=0.5)
+            lo = hi
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), ("state", mask)
+        assert not torch.equal(a[0], p0)
+
+
 @pytest.mark.parametrize("planes", ["h,h", "2,h", "2,2"])
 def test_pack_plan_equals_per_network_packing(diag, planes):
     """ops.PackPlan (lush_pack_plan_*: every network of a step re-packed by ONE launch) writes, byte for byte, what
@@ -715,7 +753,13 @@ def test_pack_plan_equals_per_network_packing(diag, planes):
     plan = ops.PackPlan(ent)
     for t in plan.buffers.values():
         t.zero_()
-    plan.run()
+    # (ABI 8) the same launch clears a buffer -- the trainer's flat gradient: 16-byte aligned with a ragged end, and not aligned
+    junk = torch.ones(100003, device=dev)
+    plan.run(junk[:100002])
+    assert float(junk[:100002].abs().max()) == 0.0 and float(junk[100002]) == 1.0
+    junk.fill_(1.0)
+    plan.run(junk[1:99999])
+    assert float(junk[1:99999].abs().max()) == 0.0 and float(junk[0]) == 1.0 and float(junk[99999:].min()) == 1.0
     for n_, p_, tensors, variant in ent:
         nbytes = diag.lib.load().lush_mlp_packed_bytes(n_, p_)
         ref = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
@@ -731,7 +775,7 @@ def test_pack_plan_equals_per_network_packing(diag, planes):
     g1 = tr.flat.grad.clone()
     net2 = _model(precision=prec, seed=2)
     tr2 = Trainer(net2, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, 64, 64)
-    tr2._pack_weights = lambda: None           # every march packs for itself
+    tr2._pack_weights = lambda zero_grad=False: tr2.flat.grad.zero_() if zero_grad else None      # every march packs for itself
     l2 = float(tr2.step(b, 0, draws=d))
     assert abs(l1 - l2) <= 1e-6 * abs(l2), (l1, l2)
     assert diag.util.relerr(g1, tr2.flat.grad) < 2e-4
