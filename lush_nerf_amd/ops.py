@@ -214,6 +214,10 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
     dpts = torch.empty(R * S, 8, dtype=torch.float32, device=dev)
     st, gs = lib.mlp_struct(tensors, _NL[net]), lib.mlp_struct(grads, _NL[net])
     timed = timer is not None and net == NET_NERF
+    if not timed:      # chain + weight gradients as ONE call (the loss-scale launch then also zeroes the weight gradients' scratch)
+        lib.call("lush_mlp_bwd", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b), C.byref(st), lib.ptr(draw),
+                 lib.ptr(stash), lib.ptr(dstash), C.byref(gs), lib.ptr(dpts), int(variant), _stream())
+        return ([None] * len(tensors) if sink is not None else grads), dpts
     ev = timer.span("mlp_bwd_chain", R * S) if timed else None
     if ev:
         ev[0].record()

@@ -343,6 +343,29 @@ def t_rbk():
     worst = max(util.relerr(t.grad, r.grad) for t, r in zip(tens2, rbk_tensors(pw)))
     RESULTS.append((f"rbk ({n_img} images, global tables) worst parameter grad", worst, 3e-4, worst <= 3e-4))
     print(f"{'ok  ' if worst <= 3e-4 else 'FAIL'} rbk ({n_img} images, global tables) worst parameter grad {worst:.2e}")
+    # other shapes of the same kernels: fewer motions (narrower heads) and image counts that leave the last workgroup ragged
+    for n_img, M in ((5, 2), (1, 1), (7, 3)):
+        pw = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in synth.rbk_weights(n_img, 90 + M, num_motion=M).items()}
+        with torch.no_grad():
+            for k in ("mlp_rbk.r_linear.weight", "mlp_rbk.v_linear.weight"):
+                pw[k] *= 3.0e5
+        bb = synth.ray_batch(nr, 90 + M, n_img)
+        rays3 = torch.from_numpy(bb["rays"]).requires_grad_(True)
+        idx3 = torch.from_numpy(bb["images_idx"])
+        rr, cc = O.rbk_forward(pw, rays3, idx3, num_motion=M)
+        tens3 = [gpu(t.detach()).requires_grad_(True) for t in rbk_tensors(pw)]
+        rg3 = gpu(bb["rays"]).requires_grad_(True)
+        gr3, gc3 = ops.RbkWarp.apply(rg3, gpu(idx3), M, 0.1, None, None, *tens3)
+        rep(f"rbk ({n_img} images, {M} motions) new_rays", gr3, rr, 2e-5)
+        rep(f"rbk ({n_img} images, {M} motions) ccw", gc3, cc, 2e-5)
+        g1 = torch.from_numpy(synth.normal(tuple(rr.shape), 65))
+        g2 = torch.from_numpy(synth.normal(tuple(cc.shape), 66))
+        ((rr * g1).sum() + (cc * g2).sum()).backward()
+        ((gr3 * gpu(g1)).sum() + (gc3 * gpu(g2)).sum()).backward()
+        rep(f"rbk ({n_img} images, {M} motions) d rays", rg3.grad, rays3.grad, 2e-4)
+        worst = max(util.relerr(t.grad, r.grad) for t, r in zip(tens3, rbk_tensors(pw)))
+        RESULTS.append((f"rbk ({n_img} images, {M} motions) worst parameter grad", worst, 3e-4, worst <= 3e-4))
+        print(f"{'ok  ' if worst <= 3e-4 else 'FAIL'} rbk ({n_img} images, {M} motions) worst parameter grad {worst:.2e}")
 
 
 def t_mix():
