@@ -376,8 +376,8 @@ def main():
                 use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., retraw=True)
             tm = net.tonemapping(rgb)
             # the loss and its gradient in one kernel, fed to autograd directly (run_lushnerf.py:652-661 with rgb0 = rgb: N_importance = 0)
-            _, ga, gb = ops.train_loss_grads(tm, tm, b["target"], 1.0, work=tr._loss_work)
-            tm.backward(ga + gb)
+            _, g, _ = ops.train_loss_grads(tm, tm, b["target"], 1.0, work=tr._loss_work)      # (a is b: one summed gradient)
+            tm.backward(g)
             net.hooks.packed = None
             a0, a1 = tr.flat.segments[0]
             if graph_body:

@@ -227,7 +227,8 @@ int lush_blur_mix_bwd(const float* rgb, const float* rgb0, const float* ccw, con
  * 0.5*MSE + 0.5*L1 against target [n][3], times `scale` (the share of a micro-batch in the step's
  * mean; 1 for the plain loss).  ga / gb = d loss / d a, d loss / d b (overwritten).
  * work == NULL: loss[0] accumulates (zero it first).  work != NULL: 2 floats of caller-owned scratch, ZERO before the first
- * call and left zero by every call; loss[0] is then WRITTEN (no zero-fill launch per call). */
+ * call and left zero by every call; loss[0] is then WRITTEN (no zero-fill launch per call).
+ * gb == NULL (allowed only with a == b: no fine pass, the reference's rgb0 = rgb): ga receives the sum of the two gradients. */
 int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float scale, float* loss,
                       float* ga, float* gb, float* work, lush_stream_t stream);
 

@@ -1226,8 +1226,10 @@ __global__ void loss_kernel(const float* __restrict__ a, const float* __restrict
         const float inv = scale / (float)n3;
         const float da = a[t] - tg[t], db = b[t] - tg[t];
         l = 0.5f * (da * da + fabsf(da) + db * db + fabsf(db)) * inv;
-        ga[t] = (da + 0.5f * (da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f))) * inv;
-        gb[t] = (db + 0.5f * (db > 0.f ? 1.f : (db < 0.f ? -1.f : 0.f))) * inv;
+        const float va = (da + 0.5f * (da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f))) * inv;
+        const float vb = (db + 0.5f * (db > 0.f ? 1.f : (db < 0.f ? -1.f : 0.f))) * inv;
+        if (gb != nullptr) { ga[t] = va; gb[t] = vb; }
+        else ga[t] = va + vb;           // a and b are the same tensor (no fine pass: rgb0 = rgb): its gradient is the sum
     }
     l = wave_sum(l);
     if (work == nullptr) {
@@ -1686,6 +1688,7 @@ int lush_noise_act_bwd(const float* x, int n, const float* dy, float* dx, lush_s
 }
 int lush_loss_fwd_bwd(const float* a, const float* b, const float* target, int n, float scale, float* loss, float* ga,
                       float* gb, float* work, lush_stream_t st) {
+    if (!gb && a != b) return set_error("lush_loss_fwd_bwd: one gradient buffer serves only a == b");
     hipLaunchKernelGGL(loss_kernel, dim3(cdiv(3LL * n, 256)), dim3(256), 0, S_(st), a, b, target, 3 * n, scale, loss, ga, gb, work);
     CHECK_LAUNCH();
     return 0;

@@ -272,7 +272,7 @@ class NeRFAll(nn.Module):
         batch, sh = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
         res = self._chunks(lambda b, d: self.render_rays(b, draws=d, **kwargs), batch, chunk, draws)
         all_ret = self._merge([r[0] for r in res], sh)
-        noise = torch.cat([r[1]['rgb_map'] for r in res], 0)
+        noise = torch.cat([r[1]['rgb_map'] for r in res], 0) if len(res) > 1 else res[0][1]['rgb_map']      # (one chunk: no copy launch)
         k_extract = ['rgb_map', 'depth_map', 'acc_map']
         return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}], noise
 

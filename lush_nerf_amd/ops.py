@@ -829,11 +829,17 @@ class NoiseAct(torch.autograd.Function):
 
 def train_loss_grads(a, b, target, scale: float = 1.0, work: Optional[torch.Tensor] = None):
     """run_lushnerf.py:652-661 without an autograd node: (scale * loss, scale * d loss/d a, scale * d loss/d b) from one
-    kernel.  The trainer feeds the two gradients to torch.autograd.backward itself (no ones-fill, no grad * g kernels).
+    kernel; with `a is b` (no fine pass: rgb0 = rgb) the second gradient is None and the first is the sum of both terms'.  The trainer feeds the two gradients to torch.autograd.backward itself (no ones-fill, no grad * g kernels).
     work: 2 floats of scratch owned by the caller, zero before the first call (the kernel leaves them zero): the loss word is
     then written by the kernel instead of zero-filled here and accumulated."""
+    same = a is b
     a, b, target = _f32(a.detach()), _f32(b.detach()), _f32(target)
     loss = torch.empty(1, dtype=torch.float32, device=a.device) if work is not None else torch.zeros(1, dtype=torch.float32, device=a.device)
+    if same and a.data_ptr() == b.data_ptr():      # one tensor in both roles (no fine pass): ONE gradient, the sum of the two terms'
+        ga = torch.empty_like(a)
+        lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(a), lib.ptr(target), a.shape[0], float(scale), lib.ptr(loss),
+                 lib.ptr(ga), None, lib.ptr(work), _stream())
+        return loss[0], ga, None
     ga, gb = torch.empty_like(a), torch.empty_like(b)
     lib.call("lush_loss_fwd_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(target), a.shape[0], float(scale), lib.ptr(loss),
              lib.ptr(ga), lib.ptr(gb), lib.ptr(work), _stream())

@@ -222,7 +222,10 @@ class Trainer:
                          retraw=True, force_naive=force_naive, allkernel=i < self.allkernel_start_iter,
                          kernel_pixel=batch["fq_mask"][a:b], draws=d, **self.kw)
         part, ga, gb = ops.train_loss_grads(out[0], out[1], batch["target"][a:b], frac, work=self._loss_work)
-        torch.autograd.backward([out[0], out[1]], [ga, gb])
+        if gb is None:      # (one tensor in both roles)
+            torch.autograd.backward([out[0]], [ga])
+        else:
+            torch.autograd.backward([out[0], out[1]], [ga, gb])
         return part
 
     def _consistency(self, consist, weight):

@@ -699,6 +699,22 @@ def test_step_graph_resynchronises_with_the_host(diag, mode, tmp_path):
     print(f"step_graph after a checkpoint load: losses within {worst:.1e} of the eager steps, parameters within {dp:.1e}")
 
 
+def test_loss_with_one_tensor_in_both_roles(diag):
+    """lush_loss_fwd_bwd with gb == NULL (a == b: no fine pass, the reference's rgb0 = rgb): the one gradient is the sum of the two
+    the two-buffer form gives, the loss the same; a != b without a second buffer is refused."""
+    from lush_nerf_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    a = torch.rand(1000, 3, generator=g).to(dev)
+    tg = torch.rand(1000, 3, generator=g).to(dev)
+    l2, ga, gb = ops.train_loss_grads(a, a.clone(), tg, 0.75)
+    l1, gs, none = ops.train_loss_grads(a, a, tg, 0.75)
+    assert none is None and float(l1) == float(l2) and torch.equal(gs, ga + gb)
+    with pytest.raises(RuntimeError, match="one gradient buffer"):
+        diag.lib.call("lush_loss_fwd_bwd", diag.lib.ptr(a), diag.lib.ptr(tg), diag.lib.ptr(tg), 1000, 1.0, diag.lib.ptr(torch.zeros(1, device=dev)),
+                      diag.lib.ptr(gs), None, None, ops._stream())
+
+
 def test_adam_multi_equals_per_segment(diag):
     """lush_adam_multi / lush_adam_state_multi (ABI 8: the active segments of the flat parameter buffer in ONE launch) give, bit
     for bit, what one lush_adam / lush_adam_state launch per segment gives -- own step count per segment, skipped segments untouched."""
