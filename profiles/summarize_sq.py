@@ -15,7 +15,12 @@ KEEP = {"mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 1>": "mlp_wide_fwd_kernel (o
         "mlp_wide_bwd_kernel<lush::NetT<256": "mlp_wide_bwd_kernel (one loss-scaled fp16 plane, 64 points per wave, 1 workgroup per CU)",
         "dw_group_kernel": "dw_group_kernel (the weight-gradient GEMMs of the fine pass in one launch)"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "p*", "*", "*_counter_collection.csv")):
+newest = {}
+for f in glob.glob(os.path.join(src, "p*", "*", "*_counter_collection.csv")):      # (a merged scratch directory may hold earlier collections)
+    d = os.path.relpath(f, src).split(os.sep)[0]
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         for k, name in KEEP.items():
             if k in r["Kernel_Name"]:
