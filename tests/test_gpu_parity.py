@@ -709,7 +709,7 @@ def test_loss_with_one_tensor_in_both_roles(diag):
     tg = torch.rand(1000, 3, generator=g).to(dev)
     l2, ga, gb = ops.train_loss_grads(a, a.clone(), tg, 0.75)
     l1, gs, none = ops.train_loss_grads(a, a, tg, 0.75)
-    assert none is None and float(l1) == float(l2) and torch.equal(gs, ga + gb)
+    assert none is None and abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l2)) and torch.equal(gs, ga + gb)      # (the loss is a sum of atomics: order)
     with pytest.raises(RuntimeError, match="one gradient buffer"):
         diag.lib.call("lush_loss_fwd_bwd", diag.lib.ptr(a), diag.lib.ptr(tg), diag.lib.ptr(tg), 1000, 1.0, diag.lib.ptr(torch.zeros(1, device=dev)),
                       diag.lib.ptr(gs), None, None, ops._stream())
