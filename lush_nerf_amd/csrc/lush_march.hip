@@ -3,6 +3,7 @@
 // scans/reductions along the ray are wave-level shuffles.
 #include "lush_common.h"
 #include "lush_host.h"
+#include <type_traits>
 #include "../../include/lush_march.h"
 
 #include <cmath>
@@ -285,6 +286,40 @@ __global__ __launch_bounds__(256) void loss_scale_kernel(const float* __restrict
 
 // ------------------------------------------------------ hierarchical sampling
 constexpr int SM_MAXN = 512;   // S + Ni rounded up to a power of two
+
+// Bitonic sort of 64 * EPL values held EPL per lane, element e * 64 + lane in v[e], ascending: the same network as the LDS
+// form below (so the same result: a sorting network's output is the sorted sequence), but a compare-exchange across lanes is one
+// cross-lane read and a min / max instead of two LDS reads, two conditional LDS writes and a wait, partners 64 or more apart are
+// registers of the same lane, and everything is unrolled (the LDS form's 28-64 steps ran ~40 instructions each for two elements).
+template <int EPL>
+__device__ __forceinline__ void wave_bitonic_sort(float (&v)[EPL], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * EPL; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if ((e & (j >> 6)) == 0) {
+                        const int pe = e | (j >> 6);
+                        const bool up = ((e * 64) & k) == 0;          // (k >= 128 here: the direction depends on e only)
+                        const float lo = fminf(v[e], v[pe]), hi = fmaxf(v[e], v[pe]);
+                        v[e] = up ? lo : hi;
+                        v[pe] = up ? hi : lo;
+                    }
+                }
+            } else {
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const float o = __shfl_xor(v[e], j, 64);
+                    const bool up = ((e * 64 + lane) & k) == 0;
+                    v[e] = (lower == up) ? fminf(v[e], o) : fmaxf(v[e], o);
+                }
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const float* __restrict__ z,
         const float* __restrict__ weights, int R, int S, int Ni, const float* __restrict__ u,
         float* __restrict__ z_out, float* __restrict__ z_samples, float* __restrict__ z_std, int* __restrict__ flags) {
@@ -319,7 +354,11 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const
     // inverse CDF
     float sum = 0.f;
     const int N = S + Ni;
-    for (int i = lane; i < Ni; i += 64) {
+    // whole 64-value rows of coarse depths and of new samples: the union is sorted in registers (wave_bitonic_sort)
+    const bool in_regs = (S & 63) == 0 && (Ni & 63) == 0;
+    float smp_r[4] = {0.f, 0.f, 0.f, 0.f};            // sample lane + 64 t (Ni <= 256 when in_regs)
+    int t_idx = 0;
+    for (int i = lane; i < Ni; i += 64, ++t_idx) {
         const float uu = u ? u[(long long)ray * Ni + i] : linspace01(i, Ni);
         int lo = 0, hi = nb;                // first index with cdf > uu  (searchsorted right=True)
         while (lo < hi) {
@@ -336,6 +375,7 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const
         const float smp = bb + t * (bins[above] - bb);
         if (z_samples) z_samples[(long long)ray * Ni + i] = smp;
         srt[S + i] = smp;
+        if (t_idx == 0) smp_r[0] = smp; else if (t_idx == 1) smp_r[1] = smp; else if (t_idx == 2) smp_r[2] = smp; else if (t_idx == 3) smp_r[3] = smp;
         sum += smp;
     }
     sum = wave_sum(sum);
@@ -351,6 +391,28 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const
     // sort(cat(z, samples)): bitonic network over N2 >= N values padded with +inf
     int N2 = 64;
     while (N2 < N) N2 <<= 1;
+    if (in_regs && N2 >= 128) {
+        const int sr = S >> 6, nr = Ni >> 6;           // rows of depths, rows of samples
+        auto sorted_rows = [&](auto epl_c) {
+            constexpr int EPL = decltype(epl_c)::value;
+            float v[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float x = __builtin_inff();
+                if (e < sr) x = zr[e * 64 + lane];
+                else if (e - sr < nr) x = (e - sr) == 0 ? smp_r[0] : (e - sr) == 1 ? smp_r[1] : (e - sr) == 2 ? smp_r[2] : smp_r[3];
+                v[e] = x;
+            }
+            wave_bitonic_sort<EPL>(v, lane);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (e * 64 < N) z_out[(long long)ray * N + e * 64 + lane] = v[e];      // (N is a multiple of 64 here)
+        };
+        if (N2 == 128) sorted_rows(std::integral_constant<int, 2>{});
+        else if (N2 == 256) sorted_rows(std::integral_constant<int, 4>{});
+        else sorted_rows(std::integral_constant<int, 8>{});
+        return;
+    }
     for (int i = lane; i < S; i += 64) srt[i] = zr[i];
     for (int i = N + lane; i < N2; i += 64) srt[i] = __builtin_inff();
     __builtin_amdgcn_wave_barrier();
