@@ -116,26 +116,36 @@ __device__ __forceinline__ f32x16 mfma_planes(const bf16x8 (&a)[NS], const bf16x
 __host__ __device__ constexpr int mfma_per_product(int ns) { return ns == 1 ? 1 : (ns == 2 ? 3 : 6); }
 
 // wave64 reductions / scans -------------------------------------------------
+// By DPP (data-parallel primitives on the VALU: the other lane's value is an operand modifier), the sequence the compiler's own
+// wave scans use on gfx9: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals carried
+// across (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes without a source take the identity.
+// As __shfl_xor / __shfl_up (ds_bpermute through the LDS crossbar, a wait and an add per step) the nine sums of
+// ray_grad_reduce_kernel were 54 LDS round trips per ray -- most of its 20 us; a DPP step is one VALU instruction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float wave_dpp(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int /*lane*/ = 0) {
+    v += wave_dpp<0x111, 0xf>(0.f, v);        // row_shr:1
+    v += wave_dpp<0x112, 0xf>(0.f, v);        // row_shr:2
+    v += wave_dpp<0x114, 0xf>(0.f, v);        // row_shr:4
+    v += wave_dpp<0x118, 0xf>(0.f, v);        // row_shr:8
+    v += wave_dpp<0x142, 0xa>(0.f, v);        // row_bcast:15 -> rows 1, 3
+    v += wave_dpp<0x143, 0xc>(0.f, v);        // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ float wave_incl_prod(float v, int /*lane*/ = 0) {
+    v *= wave_dpp<0x111, 0xf>(1.f, v);
+    v *= wave_dpp<0x112, 0xf>(1.f, v);
+    v *= wave_dpp<0x114, 0xf>(1.f, v);
+    v *= wave_dpp<0x118, 0xf>(1.f, v);
+    v *= wave_dpp<0x142, 0xa>(1.f, v);
+    v *= wave_dpp<0x143, 0xc>(1.f, v);
+    return v;
+}
+// the sum over the wave, in every lane (lane 63 of the inclusive scan, read into a scalar)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(v, o, 64);
-        if (lane >= o) v *= t;
-    }
-    return v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_sum(v)), 63));
 }
 
 }  // namespace lush

@@ -1376,22 +1376,38 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void ray_grad_reduce_kernel(co
     const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= R) return;
     float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = lane; s < S; s += 64) {
-        const long long p = (long long)ray * S + s;
-        const float4 gx = *reinterpret_cast<const float4*>(dpts + p * 8);
-        const float4 gv = *reinterpret_cast<const float4*>(dpts + p * 8 + 4);
-        const float zz = z[p];
-        a[0] += gx.x; a[1] += gx.y; a[2] += gx.z;
-        a[3] += gx.x * zz; a[4] += gx.y * zz; a[5] += gx.z * zz;
-        a[6] += gv.x; a[7] += gv.y; a[8] += gv.z;
+    // (up to 256 samples with every load in flight before the first is used: as a loop with a run-time trip count each 64
+    // samples waited for their own three loads; more samples take the loop)
+    for (int s0 = 0; s0 < S; s0 += 256) {
+        float4 gx[4], gv[4];
+        float zz[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int s = s0 + c * 64 + lane;
+            const bool in = s < S;
+            const long long p = (long long)ray * S + (in ? s : 0);
+            gx[c] = *reinterpret_cast<const float4*>(dpts + p * 8);
+            gv[c] = *reinterpret_cast<const float4*>(dpts + p * 8 + 4);
+            zz[c] = z[p];
+            if (!in) { gx[c] = make_float4(0.f, 0.f, 0.f, 0.f); gv[c] = gx[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {          // (chunks in order: the order of the sums is the loop's)
+            if (s0 + c * 64 < S) {
+                a[0] += gx[c].x; a[1] += gx[c].y; a[2] += gx[c].z;
+                a[3] += gx[c].x * zz[c]; a[4] += gx[c].y * zz[c]; a[5] += gx[c].z * zz[c];
+                a[6] += gv[c].x; a[7] += gv[c].y; a[8] += gv[c].z;
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) a[i] = wave_sum(a[i]);
-    if (lane == 0) {
-        float* o = drays + (long long)ray * 11;
-        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3]; o[4] += a[4]; o[5] += a[5];
-        o[8] += a[6]; o[9] += a[7]; o[10] += a[8];
-    }
+    // one addition per word by lanes 0..8 (a read-modify-write by lane 0 waited for its own nine loads; this ray's words are
+    // touched by no other wave of the launch, and the launches of a step run one after the other)
+    float mine = a[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) mine = lane == i ? a[i] : mine;
+    if (lane < 9) atomicAdd(drays + (long long)ray * 11 + (lane < 6 ? lane : lane + 2), mine);
 }
 
 // ------------------------------------------------------------------------ Adam
