@@ -1528,7 +1528,13 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
         const float* __restrict__ g1 = g0 + HW;
         const float* __restrict__ wf = a.w_feat + (long long)i0 * HW;
         float acc0 = 0.f, acc1 = 0.f;
+        // this wave's two rows of G, column c in lane c % 64 of register c / 64 (FF_KC / 64 registers per pass): read coalesced
+        // once per pass and handed out by v_readlane -- as wave-uniform global loads inside the k loop every batch of 16 columns
+        // waited for L2 (16 round trips per workgroup: most of the kernel's 14 us)
         for (int kc = 0; kc < HW; kc += FF_KC) {
+            float gr0[FF_KC / 64], gr1[FF_KC / 64];
+#pragma unroll
+            for (int q = 0; q < FF_KC / 64; ++q) { gr0[q] = g0[kc + q * 64 + lane]; gr1[q] = g1[kc + q * 64 + lane]; }
             if (kc) __syncthreads();                       // the previous pass has been read
             float tmp[64 * FF_KC / 256];
 #pragma unroll
@@ -1542,13 +1548,19 @@ __global__ __launch_bounds__(256) void feat_factor_kernel(const FeatFactorArgs a
                 T[c * 65 + r] = tmp[j];
             }
             __syncthreads();
-#pragma unroll 2
+#pragma unroll
             for (int c0 = 0; c0 < FF_KC; c0 += 16) {
-                float tv[16], ga[16], gb[16];
+                float tv[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { tv[j] = T[(c0 + j) * 65 + lane]; ga[j] = g0[kc + c0 + j]; gb[j] = g1[kc + c0 + j]; }
+                for (int j = 0; j < 16; ++j) tv[j] = T[(c0 + j) * 65 + lane];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { acc0 += ga[j] * tv[j]; acc1 += gb[j] * tv[j]; }
+                for (int j = 0; j < 16; ++j) {
+                    const int c = c0 + j;
+                    const float ga = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr0[c / 64]), c % 64));
+                    const float gb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr1[c / 64]), c % 64));
+                    acc0 += ga * tv[j];
+                    acc1 += gb * tv[j];
+                }
             }
         }
         const float bf = a.b_feat[i0 + lane];
