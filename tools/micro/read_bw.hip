@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void read_regs(const uint4* __restrict__ p, si
 
 // LDS-DMA ring: STAGES slots of SLOT bytes; each of the 8 waves moves 1/8 of a slot with 16-byte pieces (64 lanes x 16 B = 1 KiB per
 // instruction); one barrier per slot, like the kernels' rings.  Nothing reads the LDS: this is the transport alone.
-template <int STAGES, int SLOT>
+template <int STAGES, int SLOT, bool BARRIER = true>
 __global__ __launch_bounds__(512) void read_dma(const char* __restrict__ p, size_t bytes_per_wg, unsigned* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const char* q = p + (size_t)blockIdx.x * bytes_per_wg;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512) void read_dma(const char* __restrict__ p, size
         // all but the STAGES - 2 younger slots' pieces of this wave have landed
         if (s + STAGES - 1 <= n_slots) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * INSTR < 63 ? (STAGES - 2) * INSTR : 63) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (BARRIER) __syncthreads();
         if (s + STAGES - 1 < n_slots) issue(s + STAGES - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -84,10 +84,10 @@ int main() {
     {
         const int wgs = 256;
         const size_t per = bytes / wgs;
-        auto run = [&](auto k, int stages, int slot) {
+        auto run = [&](auto k, int stages, int slot, const char* note = "") {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, stages * slot);
             float t = time([&] { hipLaunchKernelGGL(k, dim3(wgs), dim3(512), stages * slot, 0, (const char*)buf, per, out); });
-            printf("LDS-DMA, 256 workgroups of 512, %d slots of %d KB (%d KB in flight): %.2f TB/s\n", stages, slot >> 10, (stages - 1) * slot >> 10, bytes / t / 1e9);
+            printf("LDS-DMA, 256 workgroups of 512, %d slots of %d KB (%d KB in flight)%s: %.2f TB/s\n", stages, slot >> 10, (stages - 1) * slot >> 10, note, bytes / t / 1e9);
         };
         run(read_dma<3, 32768>, 3, 32768);
         run(read_dma<4, 32768>, 4, 32768);
@@ -96,6 +96,8 @@ int main() {
         run(read_dma<8, 16384>, 8, 16384);
         run(read_dma<9, 16384>, 9, 16384);
         run(read_dma<16, 8192>, 16, 8192);
+        run(read_dma<4, 32768, false>, 4, 32768, ", no barrier per slot");
+        run(read_dma<8, 16384, false>, 8, 16384, ", no barrier per slot");
     }
     return 0;
 }
