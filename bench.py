@@ -197,6 +197,14 @@ def measure_traffic(argv_tail, kernel_key, progress=None, timeout=240):
                       "(FETCH_SIZE x2: gfx950 correction), average over the kernel's launches"}
 
 
+def traffic_child_args(a):
+    """Arguments of the child runs measure_traffic profiles: the SAME workload as this run (sizes, micro-batch, mode, variant,
+    library), two steps, nothing else timed."""
+    return ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--also=", "--extra=", "--no-kernel-pass", "--no-traffic", "--sustained", "0",
+            "--planes", a.planes, "--config", a.config, "--variant", str(a.variant), "--n-rand", str(a.n_rand), "--n-samples", str(a.n_samples),
+            "--n-importance", str(a.n_importance), "--micro-batch", str(a.micro_batch)] + (["--so", a.so] if a.so else [])
+
+
 CONFIGS = {   # BASELINE.json configs (SURVEY 8d): input rays per GPU, N_samples, N_importance, blur kernel on, micro-batch
     "C1": dict(n_rand=256, ns=32, ni=0, kernel=False, micro=0),
     "C2": dict(n_rand=4096, ns=64, ni=64, kernel=True, micro=0),
@@ -246,6 +254,8 @@ def main():
                     "command, rank 0, N = 1 only); quote profiles/pmc_traffic.json instead")
     ap.add_argument("--so", type=str, default=None, help="developer A/B: another build of the library (tools/build_variant.py); the line "
                     "then carries its path under `library` -- a reported line has none")
+    ap.add_argument("--sustained", type=float, default=3.0, help="seconds of back-to-back headline steps behind the timed region, reported "
+                    "under `sustained` (0 to skip)")
     ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
     ap.add_argument("--config", type=str, default="C2", choices=["C2", "C3", "C5"],
                     help="BASELINE config timed as the headline workload (C2 = the one the metric is quoted on)")
@@ -312,8 +322,10 @@ def main():
     def evals_per_step(n_rand, ns, ni, kernel=True):
         return n_rand * (M if kernel else 1) * (ns + (ns + ni if ni else 0))
 
-    def run_mode(pf, pb, steps, warmup, cfg=None):
-        """Time `steps` optimisation steps of one BASELINE config in one precision mode (max over ranks)."""
+    def run_mode(pf, pb, steps, warmup, cfg=None, sustained_s=0.0):
+        """Time `steps` optimisation steps of one BASELINE config in one precision mode (max over ranks).  sustained_s > 0: after
+        the timed region, the same steps back to back for at least that many seconds (the timed region of the driver's
+        `--steps 20` is a third of a second on a chip that runs at its power cap: this is its steady-state neighbour)."""
         cfg = cfg or dict(n_rand=a.n_rand, ns=a.n_samples, ni=a.n_importance, kernel=True, micro=a.micro_batch)
         batches = make_batches(cfg["n_rand"])
         net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb, a.variant))
@@ -330,6 +342,19 @@ def main():
         dt = time.perf_counter() - t0
         ar_ms = sum(a_.elapsed_time(b_) for a_, b_ in tr.allreduce_events) / max(len(tr.allreduce_events), 1)
         tr.allreduce_events = None
+        sustained = None
+        if sustained_s > 0:
+            n_sus = max(steps, int(sustained_s / max(dt / steps, 1e-6)) + 1)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(n_sus):
+                tr.step(batches[(warmup + steps + i) % n_batches], warmup + steps + i)
+            sync()
+            sdt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+            sustained = {"steps": n_sus, "seconds": round(float(sdt.item()), 3), "ms_per_step": round(float(sdt.item()) / n_sus * 1e3, 3),
+                         "value": round(cfg["n_rand"] * world * n_sus / float(sdt.item()), 1), "unit": "rays/s",
+                         "note": "the headline configuration for >= %g s back to back, right behind the timed region" % sustained_s}
         # kernel groups: the SAME steps once more with HIP events around each MLP kernel group on the launch stream.  The
         # timed region above runs the march as one C-ABI call per direction (lush_march_fwd / lush_march_bwd); with the
         # timer set the same kernels are launched group by group through the piecewise entry points.
@@ -350,6 +375,7 @@ def main():
         torch.cuda.empty_cache()
         summ = timer.summary()
         summ["_allreduce_ms"] = ar_ms
+        summ["_sustained"] = sustained
         return dt, summ
 
     def run_c1(pf, pb, steps, warmup):
@@ -360,69 +386,32 @@ def main():
         batches = [BlobBatch(b) for b in make_batches(c["n_rand"])]      # per-step inputs in one buffer: one copy per replay
         net = make_model(model_args(0), dev, ops.Precision(pf, pb)).train()
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, c["ns"], 0, kernel_start_iter=1 << 30, distributed=True)
-        K = tr.K
 
-        state = torch.zeros(lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
-        static = batches[0].clone_static()
+        # the step itself is Trainer.step_coarse_only (render_infer at 32 + 0, one summed loss gradient, Adam): the same function
+        # tests/test_gpu_parity.py::test_c1_step_against_the_oracle checks against the oracle, eagerly and as the graph replayed here
+        for i in range(warmup):
+            tr.step_coarse_only(batches[i % n_batches])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step_coarse_only(batches[(warmup + i) % n_batches])
+        sync()
+        dt_eager = time.perf_counter() - t0
+        # the same step captured in a HIP graph: one launch per step, the batch copied into the graph's tensors first
+        replay, static = tr.capture_coarse_only(batches[0])
 
-        def one(i, graph_body=False):
-            b = static if graph_body else batches[i % n_batches]
-            tr._pack_weights(zero_grad=True)     # one launch for every network (ops.PackPlan) that also clears the gradients, as Trainer.step does
-            rays = ops.gen_rays(b["c2w"], b["view"], b["px"], b["py"], K)
-            if graph_body:      # rate, Adam step count and draw counter from the device step state (include/lush_march.h)
-                net.hooks.state, net.hooks.draw_delta = state, 0
-            (rgb, depth, acc, extras), noise = net.render_infer(
-                synth.H_DEF, synth.W_DEF, K, 1 << 15, rays=rays, perturb=1., N_importance=0, N_samples=c["ns"],
-                use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., retraw=True)
-            tm = net.tonemapping(rgb)
-            # the loss and its gradient in one kernel, fed to autograd directly (run_lushnerf.py:652-661 with rgb0 = rgb: N_importance = 0)
-            _, g, _ = ops.train_loss_grads(tm, tm, b["target"], 1.0, work=tr._loss_work)      # (a is b: one summed gradient)
-            tm.backward(g)
-            net.hooks.packed = None
-            a0, a1 = tr.flat.segments[0]
-            if graph_body:
-                calls, net.hooks.state = net.hooks.draw_delta, None
-                ops.adam_step_state(tr.flat.param[a0:a1], tr.flat.grad[a0:a1], tr.m[a0:a1], tr.v[a0:a1], state, 0)
-                lib.call("lush_step_state_advance", lib.ptr(state), int(calls), 1, float(tr.lrate), float(tr.lrate_decay * 1000), 0.9, 0.999,
-                         ops._stream())
-            else:
-                tr.steps[0] += 1
-                ops.adam_step(tr.flat.param[a0:a1], tr.flat.grad[a0:a1], tr.m[a0:a1], tr.v[a0:a1], tr.lr(), tr.steps[0])
-
-        net.hooks.sink = True
-        try:
-            for i in range(warmup):
-                one(i)
-            sync()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                one(warmup + i)
-            sync()
-            dt_eager = time.perf_counter() - t0
-            # the same step captured in a HIP graph: one launch per step, the batch copied into the graph's tensors first
-            import ctypes as C
-            adam_steps = (C.c_int * 3)(*tr.steps)
-            lib.call("lush_step_state_init", lib.ptr(state), C.c_ulonglong(net.hooks.draw_offset), int(tr.global_step), adam_steps,
-                     float(tr.lrate), float(tr.lrate_decay * 1000), 0.9, 0.999, ops._stream())
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                one(0, graph_body=True)
-
-            def replay(i):
-                static.load(batches[i % n_batches])
-                graph.replay()
-            for i in range(warmup):
-                replay(i)
-            sync()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                replay(warmup + i)
-            sync()
-        finally:
-            net.hooks.sink = False
-            net.hooks.packed = None
+        def run(i):
+            static.load(batches[i % n_batches])
+            replay()
+        for i in range(warmup):
+            run(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run(warmup + i)
+        sync()
         dt = time.perf_counter() - t0
-        del tr, net, graph
+        del tr, net, replay
         return dt, dt_eager
 
     def run_eval(pf, steps):
@@ -454,7 +443,7 @@ def main():
         mfma_mult = {"mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
         kern = {}
         for g, d in groups.items():
-            if g not in bytes_eval:
+            if g not in bytes_eval or not isinstance(d, dict):
                 continue
             avg_ms = d["ms"] / d["launches"]
             pts = d["points"] / d["launches"]
@@ -471,8 +460,9 @@ def main():
     pf, pb = ops.parse_planes(a.planes)
     evals_step = evals_per_step(a.n_rand, a.n_samples, a.n_importance)
     progress(f"headline mode {a.planes}: {a.warmup} warm-up + {a.steps} timed steps on {world} rank(s)")
-    dt, groups = run_mode(pf, pb, a.steps, a.warmup)
-    progress(f"headline: {dt / a.steps * 1e3:.2f} ms/step")
+    dt, groups = run_mode(pf, pb, a.steps, a.warmup, sustained_s=a.sustained)
+    progress(f"headline: {dt / a.steps * 1e3:.2f} ms/step" + (f"; sustained {groups['_sustained']['ms_per_step']:.2f} ms/step over "
+                                                               f"{groups['_sustained']['seconds']:.1f} s" if groups.get("_sustained") else ""))
     others = []
     for m in [x for x in a.also.split(";") if x and x != a.planes]:
         qf, qb = ops.parse_planes(m)
@@ -520,8 +510,7 @@ def main():
             traffic, traffic_source = None, None
             dom_kernel = {"mlp_bwd_weights": "dw_group_kernel<true", "mlp_fwd": "mlp_wide_fwd_kernel", "mlp_bwd_chain": "mlp_wide_bwd_kernel"}.get(dom)
             if world == 1 and not a.no_traffic and dom_kernel and a.planes == "h,h":
-                tail = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--also=", "--extra=", "--no-kernel-pass", "--no-traffic",
-                        "--planes", a.planes, "--config", a.config, "--variant", str(a.variant)] + (["--so", a.so] if a.so else [])
+                tail = traffic_child_args(a)
                 torch.cuda.empty_cache()
                 traffic = measure_traffic(tail, dom_kernel, progress)
                 if traffic:
@@ -532,12 +521,25 @@ def main():
                 if os.path.exists(tpath):     # per-launch HBM bytes from the separate rocprofv3 --pmc passes of profiles/collect.sh
                     traffic = json.load(open(tpath)).get(f"{dom}:{a.planes}")
                 traffic_source = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; not re-measured in this run)"
+            # the same kernel against BOTH roofs and BOTH byte models: `design_bytes` = what this design moves per evaluation in
+            # that kernel (it stashes dZ as well as X), `survey_stash_bytes` = SURVEY 8d's 4.35 KB per
+            # evaluation (the X stash alone, read once by this pass)
+            pts_launch = groups[dom]["points"] / groups[dom]["launches"]
+            design_b = k["hbm_gbs_algorithmic"] * 1e9 * k["avg_ms"] * 1e-3 / pts_launch
+            survey_b = 4352.0
+            survey_gbs = survey_b * pts_launch / (k["avg_ms"] * 1e-3) / 1e9
+            both = {"frac_mfma": k["frac_mfma"], "frac_hbm": k["frac_hbm"],
+                    "design_bytes_per_eval": round(design_b), "frac_hbm_design_bytes": k["frac_hbm"],
+                    "survey_stash_bytes_per_eval": int(survey_b), "frac_hbm_survey_stash_bytes": round(survey_gbs / PEAK_HBM_GBS, 4)}
+            if traffic and traffic.get("hbm_bytes_per_launch"):
+                both["traffic_over_design"] = round(traffic["hbm_bytes_per_launch"] / (design_b * pts_launch), 3)
+                both["traffic_over_survey"] = round(traffic["hbm_bytes_per_launch"] / (survey_b * pts_launch), 3)
             roof = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": k["hbm_gbs_algorithmic"] if hbm_bound else k["tflops_algorithmic"],
                     "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": k["frac_hbm"] if hbm_bound else k["frac_mfma"], "traffic": traffic,
                     "traffic_source": traffic_source,
-                    "executed_mfma_frac": k["frac_mfma_executed"],
+                    "executed_mfma_frac": k["frac_mfma_executed"], **both,
                     "note": "dominant kernel group by time; achieved = algorithmic bytes (or 2*593408 FLOP) per MLP "
                             "evaluation x evaluations per launch / average launch time from HIP events on the launch stream; "
                             "the bound is the roof the kernel hits first counting the MFMAs it executes per product "
@@ -567,6 +569,7 @@ def main():
             # the one collective of a step (HIP events around dist.all_reduce of the 5.2 MB flat gradient on the launch
             # stream, mean over the timed steps): what an N > 1 run adds to the N = 1 step
             "allreduce_ms": round(groups.get("_allreduce_ms", 0.0), 4),
+            "sustained": groups.get("_sustained"),
             "kernel_timing": "HIP events around each MLP kernel group on the launch stream, over the same steps run once more "
                              "group by group (the timed region makes one lush_march_fwd / lush_march_bwd call per march and has no "
                              "events inside; every kernel runs alone on the one stream in both passes)",
@@ -590,6 +593,9 @@ def main():
                 out["ms_per_step_strict_2_2"] = out["modes"]["2,2"]["ms_per_step"]
         if extras:
             out["extra_configs"] = extras
+        if world > 1:      # a SCALE line explains what it leaves out
+            out["n1_only"] = ("cpu_baseline, roofline.traffic (live rocprofv3 --pmc passes) and extra_configs are N = 1 quantities: see the "
+                              "N = 1 line of the same round (BENCH_rNN.json); roofline.traffic here quotes profiles/pmc_traffic.json")
         if not a.no_cpu_baseline and world == 1:
             progress(f"CPU baseline (oracle on the host cores, N_rand {a.cpu_n_rand} kernel-on + config 1)")
             out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, 64, 64, progress=progress)

@@ -164,12 +164,14 @@ typedef struct {
 /* acts [num_img][512] (hidden activations + r, v, w; every element written, [464..511] as zeros). */
 int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window, float* acts,
                      lush_stream_t stream);
-/* d_rvw [num_img][rvw_stride >= 32] = gradients w.r.t. r(12), v(12), normalised w(5) in the first 29 floats of a row.
+/* d_rvw [num_img][rvw_stride >= 32] = gradients w.r.t. r(12), v(12), normalised w(5) in the first 29 floats of a row; they are
+ * CONSUMED: the kernel leaves those 29 floats zero (ABI 9), so rows kept in the zero tail of `acts` are zero again for the next
+ * lush_rbk_warp_bwd / _ndc_bwd over the same activations (a second backward of a retained graph).
  * `g` is added to when accumulate != 0 (gradient buffers that already hold a slice's contribution), else overwritten (the
  * entry point zeroes it first: the images are split over workgroups and the sums leave by atomics either way).  `scratch` is
  * unused since ABI 7 and may be NULL. */
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
-                     const float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate,
+                     float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate,
                      lush_stream_t stream);
 /* rbk_warp (models/lushnerf.py:75-98) + SE3Field.warp (utils/rigid_warping.py:20-140):
  * rays [N][3][2], idx [N] int64 -> new_rays [N*(M+1)][3][2] (slot 0 = input ray),

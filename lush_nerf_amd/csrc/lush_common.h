@@ -12,6 +12,31 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator block
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Diagnostic build -DLUSH_CLOCK (tools/clock_probe.py; never the product): the clock a kernel actually runs at, per workgroup, as
+// d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, "DVFS give-back" item 6).  Thread 0 of a workgroup stamps both
+// counters at the kernel's head and at its end into an array of its own that no other code reads; no output value depends on them.
+#ifdef LUSH_CLOCK
+#define LUSH_CLOCK_DECL(name) __device__ unsigned long long name[1024][4];
+#define LUSH_CLOCK_STAMP(name, k)                                                                      \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {                                \
+            name[blockIdx.x][2 * (k)] = __builtin_amdgcn_s_memtime();                                  \
+            name[blockIdx.x][2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();                          \
+        }                                                                                              \
+    } while (0)
+#define LUSH_CLOCK_EXPORT(fn, name)                                                                    \
+    extern "C" int fn(unsigned long long* out /* host, 1024 x 4; zeroed on the device afterwards */) { \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                           \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(name), sizeof(unsigned long long) * 4096) != hipSuccess) return -1; \
+        static unsigned long long zeros[4096];                                                         \
+        return hipMemcpyToSymbol(HIP_SYMBOL(name), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;       \
+    }
+#else
+#define LUSH_CLOCK_DECL(name)
+#define LUSH_CLOCK_STAMP(name, k)
+#define LUSH_CLOCK_EXPORT(fn, name)
+#endif
+
 enum { DT_BF16 = 0, DT_F16 = 1 };   // 16-bit operand element type (see mfma_f16 below)
 constexpr int WAVE = 64;
 constexpr int MAX_PLANES = 3;

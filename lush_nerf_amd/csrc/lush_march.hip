@@ -355,8 +355,9 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void sample_merge_kernel(const
     float sum = 0.f;
     const int N = S + Ni;
     // whole 64-value rows of coarse depths and of new samples: the union is sorted in registers (wave_bitonic_sort)
-    const bool in_regs = (S & 63) == 0 && (Ni & 63) == 0;
-    float smp_r[4] = {0.f, 0.f, 0.f, 0.f};            // sample lane + 64 t (Ni <= 256 when in_regs)
+    // (a lane keeps four rows of new samples: more than 256 of them take the LDS network below)
+    const bool in_regs = (S & 63) == 0 && (Ni & 63) == 0 && Ni <= 256;
+    float smp_r[4] = {0.f, 0.f, 0.f, 0.f};            // sample lane + 64 t
     int t_idx = 0;
     for (int i = lane; i < Ni; i += 64, ++t_idx) {
         const float uu = u ? u[(long long)ray * Ni + i] : linspace01(i, Ni);
@@ -1082,7 +1083,7 @@ __device__ __forceinline__ void rbk_dense_bwd_w(const float* dz, const float* x,
 // Workgroup b takes images [b RBK_IPB, (b + 1) RBK_IPB): d(activation) is per image, the weight gradients are sums over images.
 __global__ __launch_bounds__(RBK_NT) void rbk_mlp_bwd_kernel(lush_rbk_params p, int n_all, int M, float window,
                                                             const float* __restrict__ acts,
-                                                            const float* __restrict__ d_rvw, lush_rbk_grads g,
+                                                            float* __restrict__ d_rvw, lush_rbk_grads g,
                                                             int RS /* floats between two images' rows of d_rvw */) {
     const int img0 = blockIdx.x * RBK_IPB;
     const int n = n_all - img0 < RBK_IPB ? n_all - img0 : RBK_IPB;
@@ -1119,6 +1120,10 @@ __global__ __launch_bounds__(RBK_NT) void rbk_mlp_bwd_kernel(lush_rbk_params p, 
         if (i < n) {
             sc[i * RBK_LS + RA_R + o] = d_rvw[i * RS + o] * window;
             sc[i * RBK_LS + RA_V + o] = d_rvw[i * RS + 12 + o] * window;
+            // consumed: every element of d_rvw is read by exactly one thread, which leaves it ZERO -- the rows live in the zero
+            // tail of `acts` (LUSH_RBK_RVW_OFFSET), so a second backward over the same saved activations starts from zero again
+            d_rvw[i * RS + o] = 0.f;
+            d_rvw[i * RS + 12 + o] = 0.f;
         }
     }
     if ((int)threadIdx.x < n) {
@@ -1129,6 +1134,7 @@ __global__ __launch_bounds__(RBK_NT) void rbk_mlp_bwd_kernel(lush_rbk_params p, 
             const float ws = A[i * RBK_LS + RA_WS + m];
             const float dws = d_rvw[i * RS + 24 + m] / sum - dotp / (sum * sum);
             sc[i * RBK_LS + RA_WS + m] = dws * ws * (1.f - ws);
+            d_rvw[i * RS + 24 + m] = 0.f;
         }
     }
     __syncthreads();
@@ -1519,7 +1525,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 8; }
+int lush_abi_version(void) { return 9; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
@@ -1643,7 +1649,7 @@ int lush_rbk_mlp_fwd(const lush_rbk_params* p, int num_img, int M, float window,
     return 0;
 }
 int lush_rbk_mlp_bwd(const lush_rbk_params* p, int num_img, int M, float window, const float* acts,
-                     const float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate, lush_stream_t st) {
+                     float* d_rvw, int rvw_stride, const lush_rbk_grads* g, float* scratch, int accumulate, lush_stream_t st) {
     if (M < 1 || M > 4) return set_error("lush_rbk_mlp_bwd: 1 <= num_motion <= 4");
     if (num_img < 1) return set_error("lush_rbk_mlp_bwd: no images");
     if (rvw_stride < LUSH_RBK_RVW_STRIDE) return set_error("lush_rbk_mlp_bwd: rvw_stride must be at least LUSH_RBK_RVW_STRIDE");

@@ -1023,6 +1023,7 @@ __device__ __forceinline__ void dw_pe_write(char* dst, const f32x4 c, int gch, i
 
 // The streaming loop of one job, specialised on the number of 32-column X2 blocks (0: none, the side accumulator is the
 // bias alone).  Nothing in it depends on the job except through `st` (registers) and three wave-uniform flags.
+LUSH_CLOCK_DECL(lush_clock_dw)
 #ifdef LUSH_PROF_DW   // developer build: s_memtime counts of workgroup 0 / thread 0 per phase of a job, read back through lush_debug_prof_dw
 __device__ unsigned long long lush_prof_dw[16];
 __device__ unsigned long long lush_prof_dw_span[2 * 1024];      // [b] start, [1024 + b] end of workgroup b (s_memtime: one clock for the chip)
@@ -1189,6 +1190,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = w >> 2, wi = w & 3;
     DPROF_T(t_kernel);
+    LUSH_CLOCK_STAMP(lush_clock_dw, 0);
     const long long p_begin = (long long)blockIdx.x * G.pts_per_split;
     long long p_end = p_begin + G.pts_per_split;
     if (p_end > G.Ppad) p_end = G.Ppad;
@@ -1311,6 +1313,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
 #endif
     }
     DPROF_ADD(0, t_kernel);
+    LUSH_CLOCK_STAMP(lush_clock_dw, 1);
 #ifdef LUSH_PROF_DW
     if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) { lush_prof_dw_span[blockIdx.x] = t_kernel; lush_prof_dw_span[1024 + blockIdx.x] = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -1660,6 +1663,7 @@ static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
     LUSH_HIP(hipGetLastError());
     return 0;
 }
+LUSH_CLOCK_EXPORT(lush_debug_clock_dw, lush_clock_dw)
 #ifdef LUSH_PROF_DW
 }  // namespace lush
 extern "C" int lush_debug_prof_dw(unsigned long long* out, int reset) {

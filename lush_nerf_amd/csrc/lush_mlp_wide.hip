@@ -40,6 +40,7 @@ enum { WC_NONE = 0, WC_ACT = 1, WC_ALPHA = 2 };               // what happens to
 constexpr int WD_WRAP = NetNerf::fwd4_len / 8;      // stream positions per tile
 static_assert(NetNerf::fwd4_len % 8 == 0, "the quarter-row stream is whole positions");
 
+LUSH_CLOCK_DECL(lush_clock_wide_fwd)
 #ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back through lush_debug_prof_wide
 __device__ unsigned long long lush_prof_wide[16];
 #define WPROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
     constexpr bool MASK = SPK > 0;
     constexpr int ML_BYTES = NRB * 128;                        // decision words of one (column block, layer)
     constexpr int CB_BYTES = N::n_mask_layers * ML_BYTES;      // ... of one column block
+    LUSH_CLOCK_STAMP(lush_clock_wide_fwd, 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The bias block comes first: its reads then are one per-lane register + an immediate (DS offsets reach 64 KiB; placed
     // behind the images every distinct bias address became a register of its own, hoisted out of the tile loop and spilled).
@@ -705,11 +707,13 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
     }
 #endif
     wd_wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
+    LUSH_CLOCK_STAMP(lush_clock_wide_fwd, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+LUSH_CLOCK_EXPORT(lush_debug_clock_fwd, lush_clock_wide_fwd)
 static_assert((NetNerf::f32_w_rgb * 4) % 16 == 0, "the ring behind the bias block stays 16-byte aligned");
 size_t mlp_wide_fwd_lds_bytes() { return (size_t)WD_S * WD_SLOT + (size_t)WD_PE_PLANE + (size_t)NetNerf::f32_w_rgb * 4 + 8 * 4096; }
 

@@ -23,6 +23,7 @@
 namespace lush {
 
 constexpr int WB_WRAP = NetNerf::bwd4_len / 8;      // stream positions per tile
+LUSH_CLOCK_DECL(lush_clock_wide_bwd)
 #ifdef LUSH_PROF   // developer build: cycle counts (s_memtime) of block 0 / wave 0, read back through lush_debug_prof_wbwd
 __device__ unsigned long long lush_prof_wbwd[16];
 #define BPROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     constexpr int HW = N::HW, HV = N::HV, NL = N::NL;
     constexpr int LDV = HV + DZV_EXT;                          // dZv rows carry the head gradients in 8 more columns
     constexpr int CB_BYTES = N::n_mask_layers * 1024;          // decision words of one column block: 1 KiB per mask layer
+    LUSH_CLOCK_STAMP(lush_clock_wide_bwd, 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wtab = reinterpret_cast<float*>(smem);              // w_rgb [3][HV] | w_alpha [HW]   (first: DS immediates reach it)
     constexpr int WTAB_BYTES = (3 * HV + HW) * 4;
@@ -750,11 +752,13 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     }
 #endif
     wd_wait_vm<0>();          // the look-ahead DMAs of the non-existent next tile must land before the LDS is released
+    LUSH_CLOCK_STAMP(lush_clock_wide_bwd, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+LUSH_CLOCK_EXPORT(lush_debug_clock_chain, lush_clock_wide_bwd)
 #ifdef LUSH_PROF
 extern "C" int lush_debug_prof_wbwd(unsigned long long* out) {
     LUSH_HIP(hipDeviceSynchronize());

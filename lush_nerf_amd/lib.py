@@ -211,7 +211,7 @@ _SIGS = {
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 8
+ABI_VERSION = 9
 PLANES_F16 = 17          # include/lush_march.h: plane code of ONE fp16 plane (1..3 = bf16 planes)
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
 VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS = 1, 2, 4, 8, 16, 64

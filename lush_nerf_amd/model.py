@@ -30,6 +30,8 @@ class NeRF(nn.Module):
         super().__init__()
         if not use_viewdirs:
             raise NotImplementedError("the MI355X path implements the use_viewdirs=True topology only")
+        if use_awp:
+            raise NotImplementedError("use_awp=True is not built (utils/run_lushnerf_helpers.py:366-377; no shipped config sets it)")
         if tuple(skips) != (4,) or (D, W) not in ((8, 256), (4, 128)) or input_ch != 63 or input_ch_views != 27:
             raise NotImplementedError("kernels are built for D=8/W=256 (NeRF) and D=4/W=128 (NeRF_Noise), "
                                       "multires=10, multires_views=4, skips=[4]")
@@ -118,6 +120,8 @@ class RBK(nn.Module):
                  output_ch_rbk_r, output_ch_rbk_v, skips_rbk, rbk_use_origin, rbk_se_rv_window, num_motion_rbk,
                  use_dpnerf=True, use_awp=False, near=0.0, far=1.0, ndc=False):
         super().__init__()
+        if use_awp or not use_dpnerf:
+            raise NotImplementedError("RBK: use_dpnerf=True, use_awp=False only (models/lushnerf.py:156-175; configs/*_lushnerf)")
         self.use_dpnerf, self.view_embed_ch, self.use_awp = use_dpnerf, view_embed_ch, use_awp
         self.view_embed_layer = View_Embedding(num_embed=num_img, embed_dim=view_embed_ch)
         self.RBK = Rigid_Blurring_Kernel(
@@ -239,6 +243,17 @@ class NeRFAll(nn.Module):
         return {'rgb_map': self._noise(ray_batch, N_samples, lindisp)}
 
     # ------------------------------------------------------------------ the "render()" trio
+    @staticmethod
+    def _refuse_unbuilt(c2w_staticcam, use_awp):
+        """Branches of the render trio that are not built raise instead of being silently skipped: `c2w_staticcam` (rays of a
+        second camera with the first one's view directions, models/lushnerf.py:709-713, 775-779, 830-834) and `use_awp` (the
+        adaptive-weight branch, :222-260, 760, 817).  No shipped config sets either.  `kernelpixel` and `allkernel` are accepted and
+        unused exactly as in the reference, whose three bodies (:679-866) never read them."""
+        if c2w_staticcam is not None:
+            raise NotImplementedError("c2w_staticcam is not built (models/lushnerf.py:709-713: a visualisation aid no config uses)")
+        if use_awp:
+            raise NotImplementedError("use_awp=True is not built (models/lushnerf.py:222-260; no shipped config sets it)")
+
     def _pack(self, H, W, K, rays, ndc, near, far, use_viewdirs):
         if not use_viewdirs:
             raise NotImplementedError("use_viewdirs=False is not built (every config sets it)")
@@ -269,6 +284,7 @@ class NeRFAll(nn.Module):
                      c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None, render_noise=True,
                      draws=None, **kwargs):
         """models/lushnerf.py:679-763 -> ([rgb, depth, acc, extras], noise_rgb)."""
+        self._refuse_unbuilt(c2w_staticcam, use_awp)
         batch, sh = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
         res = self._chunks(lambda b, d: self.render_rays(b, draws=d, **kwargs), batch, chunk, draws)
         all_ret = self._merge([r[0] for r in res], sh)
@@ -280,6 +296,7 @@ class NeRFAll(nn.Module):
                            use_viewdirs=False, c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None,
                            render_noise=True, draws=None, **kwargs):
         """models/lushnerf.py:766-819 -> [rgb, depth, acc, extras]."""
+        self._refuse_unbuilt(c2w_staticcam, use_awp)
         batch, sh = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
         res = self._chunks(lambda b, d: self.render_rays_nonoise(b, draws=d, **kwargs), batch, chunk, draws)
         all_ret = self._merge(res, sh)
@@ -288,6 +305,7 @@ class NeRFAll(nn.Module):
 
     def _render_train_scene_packed(self, batch, chunk, draws=None, **kwargs):
         """render_train_scene on an already packed ray batch [R,11] (the fused warp + NDC kernel made it)."""
+        self._refuse_unbuilt(kwargs.get("c2w_staticcam"), kwargs.get("use_awp", False))
         for k in ("c2w", "ndc", "near", "far", "use_viewdirs", "c2w_staticcam", "use_awp", "allkernel", "kernelpixel", "render_noise"):
             kwargs.pop(k, None)
         res = self._chunks(lambda b, d: self.render_rays_nonoise(b, draws=d, **kwargs), batch, chunk, draws)
@@ -304,6 +322,7 @@ class NeRFAll(nn.Module):
                            use_viewdirs=False, c2w_staticcam=None, use_awp=False, allkernel=0, kernelpixel=None,
                            render_noise=True, draws=None, **kwargs):
         """models/lushnerf.py:821-866 -> noise rgb [N,3]."""
+        self._refuse_unbuilt(c2w_staticcam, use_awp)
         batch, _ = self._pack(H, W, K, rays, ndc, near, far, use_viewdirs)
         res = self._chunks(lambda b, d: self.render_rays_noise(b, **kwargs)['rgb_map'], batch, chunk, None)
         return torch.cat(res, 0) if len(res) > 1 else res[0]

@@ -386,22 +386,30 @@ class March(torch.autograd.Function):
 
     # ------------------------------------------------------------------ one call per direction
     @staticmethod
-    def _c_cfg(cfg: MarchCfg, R: int, same: bool, need_grad: bool, coarse=None, fine=None):
+    def _packed_of(cfg: MarchCfg, same: bool, need_grad: bool, coarse, fine):
+        """The step's packed fragments (ops.Hooks.packed, set by the trainer for the duration of a step) this march reads: looked
+        up ONCE, at the forward, and kept by the autograd node -- the backward passes the same buffers whatever hooks.packed holds
+        by then (a backward outside Trainer.step's try block, a retained graph): lush_march_fwd skips the workspace copy of
+        fragments it is handed, so a backward that looked again and found nothing would chain over a never-written copy."""
+        if cfg.hooks is None or cfg.hooks.packed is None:
+            return None
+        pf, pb = cfg.precision.fwd, cfg.precision.bwd
+        pk = {"coarse": _packed_for(cfg.hooks, coarse, pf), "fine": None if same else _packed_for(cfg.hooks, fine, pf)}
+        if need_grad and pb != pf:
+            pk["bwd_coarse"] = _packed_for(cfg.hooks, coarse, pb)
+            pk["bwd_fine"] = None if same else _packed_for(cfg.hooks, fine, pb)
+        return pk
+
+    @staticmethod
+    def _c_cfg(cfg: MarchCfg, R: int, same: bool, need_grad: bool, packed=None):
         pf, pb = cfg.precision.fwd, cfg.precision.bwd
         c = lib.MarchCfgC(R, cfg.N_samples, cfg.N_importance, float(cfg.perturb), float(cfg.raw_noise_std), int(cfg.white_bkgd),
                           int(cfg.lindisp), float(cfg.near_mask), pf, pb if need_grad else 0, int(cfg.precision.variant), int(same))
-        keep = []
-        if coarse is not None and cfg.hooks is not None and cfg.hooks.packed is not None:      # packed once per step by the trainer
-            def p(tensors, planes):
-                t = _packed_for(cfg.hooks, tensors, planes)
-                if t is not None:
-                    keep.append(t)
-                return None if t is None else t.data_ptr()
-            c.packed_coarse = p(coarse, pf)
-            c.packed_fine = None if same else p(fine, pf)
+        if packed is not None:      # packed once per step by the trainer (the tensors stay alive in `packed`, held by the caller)
+            p = lambda k: None if packed.get(k) is None else packed[k].data_ptr()
+            c.packed_coarse, c.packed_fine = p("coarse"), p("fine")
             if need_grad and pb != pf:
-                c.packed_bwd_coarse = p(coarse, pb)
-                c.packed_bwd_fine = None if same else p(fine, pb)
+                c.packed_bwd_coarse, c.packed_bwd_fine = p("bwd_coarse"), p("bwd_fine")
         return c
 
     @staticmethod
@@ -414,7 +422,8 @@ class March(torch.autograd.Function):
     def _forward_fused(ctx, batch, cfg, d, coarse, fine, same, need_grad):
         R, S, Ni, dev = batch.shape[0], cfg.N_samples, cfg.N_importance, batch.device
         Sl = S + Ni
-        c = March._c_cfg(cfg, R, same, need_grad, coarse, fine)
+        ctx.packed = March._packed_of(cfg, same, need_grad, coarse, fine)
+        c = March._c_cfg(cfg, R, same, need_grad, ctx.packed)
         nbytes = lib.load().lush_march_workspace_bytes(C.byref(c))
         if nbytes == 0:
             raise RuntimeError("lush_march_workspace_bytes: bad configuration")
@@ -448,7 +457,7 @@ class March(torch.autograd.Function):
         cfg = ctx.cfg
         (ws,) = saved
         R, fine_on = batch.shape[0], cfg.N_importance > 0
-        c = March._c_cfg(cfg, R, ctx.same, True, coarse, fine)
+        c = March._c_cfg(cfg, R, ctx.same, True, ctx.packed)      # (the forward's packed buffers, not a second look at the hooks)
         gp = [_opt(g[0]), _opt(g[1]), _opt(g[2])] + ([_opt(g[7]), _opt(g[8]), _opt(g[9])] if fine_on else [None, None, None])
         go = lib.MarchGout(*(None if t is None else t.data_ptr() for t in gp))
         any_main = any(t is not None for t in gp[:3])
@@ -585,9 +594,11 @@ class NoiseMlp(torch.autograd.Function):
         stash = t[2] if ctx.has_stash else None
         tensors = list(t[3 if ctx.has_stash else 2:])
         base = g._base if g._is_view() else None
-        if base is not None and base.dtype == torch.float32 and tuple(base.shape) == (g.shape[0], 4) and base.is_contiguous() \
-                and g.data_ptr() == base.data_ptr() and tuple(g.stride()) == (4, 1):
-            draw = base             # ops.BlurMix.backward hands over columns 0..2 of a [R,4] buffer whose column 3 it zeroed
+        if base is not None and getattr(base, "_lush_col3_zero", False) and base.dtype == torch.float32 \
+                and tuple(base.shape) == (g.shape[0], 4) and base.is_contiguous() and g.data_ptr() == base.data_ptr() \
+                and tuple(g.stride()) == (4, 1):
+            draw = base             # ops.BlurMix.backward hands over columns 0..2 of a [R,4] buffer whose column 3 it zeroed -- and
+                                    # says so on the buffer: any other [:, :3] view of a [R,4] tensor gets the zero-padded copy
         else:
             draw = torch.zeros(g.shape[0], 4, dtype=torch.float32, device=g.device)
             draw[:, :3] = g
@@ -753,6 +764,7 @@ class BlurMix(torch.autograd.Function):
         d_nraw4 = torch.empty(N, 4, dtype=torch.float32, device=rgb.device)      # column 3 = 0: the noise MLP's d_raw as it stands
         lib.call("lush_blur_mix_bwd", lib.ptr(rgb), lib.ptr(rgb0), lib.ptr(ccw), lib.ptr(nraw), int(nraw.stride(0)), N, M1, ctx.gamma,
                  *(lib.ptr(_opt(x)) for x in g), lib.ptr(d_rgb), lib.ptr(d_rgb0), lib.ptr(d_ccw), lib.ptr(d_nraw4), _stream())
+        d_nraw4._lush_col3_zero = True      # (read by NoiseMlp.backward: the kernel wrote column 3 = 0)
         return d_rgb, d_rgb0, d_ccw, d_nraw4[:, :3], None
 
 

@@ -282,6 +282,71 @@ class Trainer:
         self.global_step += 1
         return loss
 
+    # ------------------------------------------------------------------ BASELINE config 1: the coarse-only step
+    def step_coarse_only(self, batch: Dict[str, torch.Tensor], draws=None, state: Optional[torch.Tensor] = None):
+        """One optimisation step at N_importance = 0 (BASELINE config 1: N_rand 256, 32 + 0, naive).  NeRFAll.forward cannot take
+        N_importance = 0 -- the reference indexes extras['rgb0'] there (models/lushnerf.py:660) -- so the entry is render_infer
+        (:679-763 -> render_rays :354-479), as in the reference's own CPU-runnable case; the loss is run_lushnerf.py:652-661
+        with rgb0 = rgb (ONE summed gradient), Adam on the first segment (coarse network).  What bench.py's C1 figure times and
+        what tests/test_gpu_parity.py checks against the oracle, eagerly and as a HIP graph.
+        `state` (the device step state, include/lush_march.h lush_step_state_*): the graph-body form -- draw counter, rate and
+        Adam step count come from the state and the last node advances it; the host's counters are the caller's to advance
+        after a replay.  Returns (loss, tone-mapped colours)."""
+        model, hooks = self.model, self.model.hooks
+        model.train()
+        sink_before, hooks.sink = hooks.sink, True
+        if state is not None:
+            hooks.state, hooks.draw_delta = state, 0
+        try:
+            self._pack_weights(zero_grad=True)        # one launch: every network re-packed, the flat gradient cleared
+            rays = batch["rays"] if "rays" in batch else ops.gen_rays(batch["c2w"], batch["view"], batch["px"], batch["py"], self.K)
+            (rgb, depth, acc, extras), noise = model.render_infer(
+                self.H, self.W, self.K, self.chunk, rays=rays, retraw=True, draws=draws, **dict(self.kw, N_importance=0))
+            tm = model.tonemapping(rgb)
+            loss, g, _ = ops.train_loss_grads(tm, tm, batch["target"], 1.0, work=self._loss_work)      # (a is b: rgb0 = rgb)
+            tm.backward(g)
+            calls = self._coarse_only_calls = hooks.draw_delta      # lush_draws calls of this step (graph-body form)
+        finally:
+            hooks.sink, hooks.packed, hooks.state = sink_before, None, None
+        a0, a1 = self.flat.segments[0]
+        if state is not None:
+            ops.adam_step_state(self.flat.param[a0:a1], self.flat.grad[a0:a1], self.m[a0:a1], self.v[a0:a1], state, 0,
+                                grad_scale=1.0 / self.world)
+            ops.lib.call("lush_step_state_advance", ops.lib.ptr(state), int(calls), 1, float(self.lrate), float(self.lrate_decay * 1000),
+                         0.9, 0.999, ops._stream())
+        else:
+            if self.distributed:
+                self._all_reduce()
+            lr = self.lr() if self._lr_next is None else self._lr_next
+            self._lr_next = None
+            self.steps[0] += 1
+            ops.adam_step(self.flat.param[a0:a1], self.flat.grad[a0:a1], self.m[a0:a1], self.v[a0:a1], lr, self.steps[0],
+                          grad_scale=1.0 / self.world)
+            self.global_step += 1
+        return loss, tm.detach()
+
+    def capture_coarse_only(self, batch):
+        """step_coarse_only captured as ONE HIP graph (call after at least one eager step of the same shapes).  Returns
+        (replay, static): static is the graph's own copy of the batch (load the step's inputs into it), replay() launches the
+        graph and advances the host's mirror of the counters; replay.loss / replay.tm are the graph's output tensors."""
+        if self.world > 1:
+            raise NotImplementedError("capture_coarse_only: one rank (the collective is not captured; use step_coarse_only)")
+        state = torch.zeros(ops.lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=self.flat.param.device)
+        self._state_init(state)
+        static = batch.clone_static() if isinstance(batch, BlobBatch) else {k: v.clone() for k, v in batch.items()}
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss, tm = self.step_coarse_only(static, state=state)
+        hooks, calls = self.model.hooks, self._coarse_only_calls
+
+        def replay():
+            graph.replay()
+            self.steps[0] += 1
+            self.global_step += 1
+            hooks.draw_offset += calls      # (one lush_draws call per step: the march's; the noise branch draws nothing)
+        replay.loss, replay.tm, replay.graph, replay.state = loss, tm, graph, state
+        return replay, static
+
     # ------------------------------------------------------------------ the step as one HIP graph
     def _all_reduce(self):
         """The step's ONE collective: sum of the flat gradient over the ranks (RCCL over xGMI; 1/world is folded into Adam)."""
@@ -342,7 +407,7 @@ class Trainer:
         self._graph = None
         self._graph_eager_left = max(self._graph_eager_left, 1)
 
-    def step_graph(self, batch: Dict[str, torch.Tensor], i: int, split: Optional[bool] = None):
+    def step_graph(self, batch: Dict[str, torch.Tensor], i: int, split: Optional[bool] = None, consist: Optional[dict] = None):
         """step() with the whole step -- ray generation, both marches, loss, backward, Adam -- captured once in a HIP graph
         and replayed: one graph launch instead of ~50 kernel launches from Python (the launch-bound configurations: BASELINE
         config 1 spends its step in the host's launch path).  What the host passes per step as kernel arguments -- the
@@ -366,9 +431,10 @@ class Trainer:
                tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in batch.items())))
         if self._graph is not None and self._graph["key"] != key:
             self.invalidate_graph()         # (e.g. force_naive flips at kernel_start_iter: the RBK / noise kernels' first call must be eager)
-        if self._lr_next is not None or i >= self.noisenerf_start_iter or self._graph_eager_left > 0 or not self.flat.param.is_cuda:
+        if self._lr_next is not None or i >= self.noisenerf_start_iter or consist is not None or self._graph_eager_left > 0 \
+                or not self.flat.param.is_cuda:
             self._graph_eager_left = max(self._graph_eager_left - 1, 0)
-            return self.step(batch, i)
+            return self.step(batch, i, consist=consist)      # (the consistency branch draws its anchor / pixels on the host: eager)
         hooks = self.model.hooks
         if self._graph is None:
             self.model.train()

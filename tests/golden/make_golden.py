@@ -455,8 +455,111 @@ def case_trajectory_long(seed=43, n_rand=32, steps=300):
          final_rgb_b=sd["mlp_fine.rgb_linear.bias"].numpy().copy())
 
 
+def _consist_tables(seed, V=5, ns=32, anchor=3):
+    """Align_Matrix / Align_Mask of the consistency branch from the build-owned generator (as case_consistency)."""
+    HW = H * W
+    samples = (synth.uniform01(ns, seed, 11) * HW).astype(np.int64)
+    ax = synth.uniform((V, ns), -40, W + 40, seed, 12)
+    ay = synth.uniform((V, ns), -30, H + 30, seed, 13)
+    cert_f = synth.uniform((V, ns), 0, 1, seed, 14)
+    cert_f[cert_f < 0.35] = 0.0
+    cert_f[:, 5] = 0.0
+    Align_Matrix = torch.zeros(V, V, HW, 4)
+    Align_Mask = torch.zeros(V, V, HW, dtype=torch.bool)
+    st = torch.from_numpy(samples)
+    Align_Matrix[anchor][:, st, 2] = torch.from_numpy(ax)
+    Align_Matrix[anchor][:, st, 3] = torch.from_numpy(ay)
+    Align_Mask[anchor][:, st] = torch.from_numpy(cert_f) != 0
+    return samples, ax, ay, cert_f, Align_Matrix, Align_Mask
+
+
+def _named_grads(net):
+    grads, seen = {}, set()
+    for k, p in net.named_parameters():
+        ck = canon_name(k)
+        if ck in seen:
+            continue
+        seen.add(ck)
+        if p.grad is not None:
+            grads[ck] = p.grad
+    return grads
+
+
+def case_train_c1(seed=51, n_rand=256, Ns=32):
+    """BASELINE config 1 as a TRAINING step (round 5): N_rand 256, 32 + 0 samples, naive.  NeRFAll.forward cannot take
+    N_importance = 0 (it indexes extras['rgb0'], models/lushnerf.py:660), so the entry is render_infer (:679-763 -> render_rays
+    :354-479) as in the reference's own CPU-runnable case; the loss is run_lushnerf.py:652-661 with rgb0 = rgb (no fine pass: both
+    terms see the one colour), backward through the coarse network alone."""
+    wts = {k: v for k, v in synth.all_weights(NUM_IMG, seed, sharp=True).items()}
+    net = build_ref(0, wts)
+    net.train()
+    b = synth.ray_batch(n_rand, seed, NUM_IMG)
+    d = synth.draws(n_rand, Ns, 0, seed)
+    kw = dict(perturb=1., N_importance=0, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False,
+              near=0., far=1., retraw=True)
+    with ServeDraws([d["t_rand"], d["noise_c"]]):
+        (rgb, depth, acc, extras), noise = net.render_infer(H, W, K, 1 << 15, rays=torch.from_numpy(b["rays"]), **kw)
+    tm = net.tonemapping(rgb)
+    target = torch.from_numpy(b["target"])
+    loss = 2.0 * (ref_helpers.img2mse(tm, target) * 0.5 + ref_helpers.img2l1(tm, target) * 0.5)
+    loss.backward()
+    arrs = dict(meta=np.array([n_rand, Ns, 0, seed]), rgb_map=rgb.detach().numpy(), depth_map=depth.detach().numpy(),
+                acc_map=acc.detach().numpy(), rgb_tm=tm.detach().numpy(), noise_rgb=noise.detach().numpy(), loss=np.array(loss.item()))
+    arrs.update(pack_grads(_named_grads(net)))
+    arrs["grad_none"] = np.array(sorted(set(canon_name(k) for k, p in net.named_parameters() if p.grad is None)))
+    save("train_c1", **arrs)
+
+
+def case_train_consist(seed=52, n_rand=12, Ns=64, Ni=64):
+    """The COMBINED step after noisenerf_start_iter (run_lushnerf.py:625-661, round 5): the kernel-on training forward AND the
+    aligned-pixel renders of the consistency branch, loss = image terms + 1e-2 * loss_rgb, ONE backward through both."""
+    import random as pyrandom
+    import contextlib, io
+    V, ns, anchor = 5, 32, 3
+    wts = synth.all_weights(NUM_IMG, seed, sharp=True, rbk_scale=2.0e4)
+    net = build_ref(Ni, wts)
+    net.train()
+    b = synth.ray_batch(n_rand, seed, NUM_IMG)
+    d = synth.draws(n_rand * 5, Ns, Ni, seed)
+    rays = torch.from_numpy(b["rays"])
+    kw = dict(perturb=1., N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False,
+              near=0., far=1.)
+    with ServeDraws([d["t_rand"], d["noise_c"], d["u"], d["noise_f"]]):
+        out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": torch.from_numpy(b["images_idx"])}, retraw=True,
+                  force_naive=False, allkernel=False, kernel_pixel=torch.from_numpy(b["fq_mask"]).bool(), **kw)
+    rgb_blur, rgb0_blur = out[0], out[1]
+    poses = torch.from_numpy(synth.poses(V, seed))
+    samples, ax, ay, cert_f, Align_Matrix, Align_Mask = _consist_tables(seed, V, ns, anchor)
+    rk = dict(kw, perturb=False, raw_noise_std=0., inference=True, save_warped_ray_img=False)      # render_kwargs_test (:406-410)
+    keep = (torch.Tensor.cuda, pyrandom.randint, np.random.randint)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    pyrandom.randint = lambda a, b: anchor
+    np.random.randint = lambda lo, hi=None, size=None: samples.copy()
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            rgb_align, cert = net(H, W, K, 1 << 20, poses=poses, render_kwargs=rk, render_factor=0, rays_info=torch.arange(V),
+                                  consist_loss=True, Align_matrix=Align_Matrix, Align_mask=Align_Mask)
+    finally:
+        torch.Tensor.cuda, pyrandom.randint, np.random.randint = keep
+    mask = cert >= 0.8
+    mean = ref_helpers.compute_mean_with_confidence(rgb_align, cert, 0.8)
+    loss_rgb = torch.sum(torch.abs(rgb_align - mean.unsqueeze(0)) * mask.unsqueeze(2)) / len(mask[mask == 1])
+    target = torch.from_numpy(b["target"])
+    img = ref_helpers.img2mse(rgb_blur, target) * 0.5 + ref_helpers.img2l1(rgb_blur, target) * 0.5 \
+        + ref_helpers.img2mse(rgb0_blur, target) * 0.5 + ref_helpers.img2l1(rgb0_blur, target) * 0.5
+    loss = img + 1e-2 * loss_rgb               # run_lushnerf.py:658-659 (i > noisenerf_start_iter)
+    loss.backward()
+    arrs = dict(meta=np.array([n_rand, Ns, Ni, seed, V, ns, anchor]), samples=samples, ax=ax, ay=ay, cert_in=cert_f,
+                rgb_blur=rgb_blur.detach().numpy(), rgb0_blur=rgb0_blur.detach().numpy(), rgb_align=rgb_align.detach().numpy(),
+                certainty=cert.numpy(), loss=np.array(loss.item()), loss_img=np.array(img.item()), loss_rgb=np.array(loss_rgb.item()))
+    arrs.update(pack_grads(_named_grads(net)))
+    arrs["grad_none"] = np.array(sorted(set(canon_name(k) for k, p in net.named_parameters() if p.grad is None)))
+    save("train_consist", **arrs)
+
+
 NEW_CASES = {"sample_pdf_z": case_sample_pdf_z, "lindisp_white": case_lindisp_white, "eval_forward": case_eval_forward,
-             "consistency": case_consistency, "trajectory": case_trajectory, "trajectory_long": case_trajectory_long}
+             "consistency": case_consistency, "trajectory": case_trajectory, "trajectory_long": case_trajectory_long,
+             "train_c1": case_train_c1, "train_consist": case_train_consist}
 
 
 if __name__ == "__main__":
@@ -465,7 +568,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
         case_checkpoint_layout()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in NEW_CASES:      # regenerate one of the round-2 fixtures only
+    if len(sys.argv) > 1 and sys.argv[1] in NEW_CASES:      # regenerate some of the later rounds' fixtures only
         for name in sys.argv[1:]:
             NEW_CASES[name]()
         for sub in ("", "models", "utils"):

@@ -182,6 +182,17 @@ def t_sample():
     srt_ok = bool((zo[:, 1:] >= zo[:, :-1]).all())
     RESULTS.append(("merged output sorted", 0.0 if srt_ok else 1.0, 0, srt_ok))
     print("ok  " if srt_ok else "FAIL", "merged output sorted")
+    # (c) every shape class of the sort: whole 64-value rows (sorted in registers up to 256 new samples), more than four
+    # rows of new samples (Ni = 320 / 384 / 448: the LDS network -- a lane keeps only four rows), ragged counts
+    for S2, Ni2 in ((64, 64), (128, 128), (64, 256), (192, 256), (64, 320), (128, 384), (64, 448), (48, 40), (200, 56), (100, 300)):
+        z2 = torch.sort(torch.from_numpy(synth.uniform((24, S2), 0, 1, 31 + S2)), -1)[0]
+        w2 = torch.from_numpy(synth.uniform((24, S2), 0, 1, 32 + Ni2)) ** 4
+        u2 = torch.from_numpy(np.minimum(synth.uniform((24, Ni2), 0, 1, 33 + S2 + Ni2), np.float32(1 - 2 ** -24)))
+        ref2 = O.sample_pdf(.5 * (z2[:, 1:] + z2[:, :-1]), w2[:, 1:-1], Ni2, False, u2)
+        zo2, zs2, zstd2 = ops.sample_merge(gpu(z2), gpu(w2), Ni2, gpu(u2))
+        rep(f"sample_pdf {S2}+{Ni2}", zs2, ref2, 2e-5)
+        rep(f"merged sort {S2}+{Ni2}", zo2, torch.sort(torch.cat([z2, ref2], -1), -1)[0], 2e-5)
+        rep(f"z_std {S2}+{Ni2}", zstd2, torch.std(ref2, -1, unbiased=False), 2e-5)
 
 
 def _mlp_case(net, prefix, D, Wd, seed, R, S, sharp=False):
@@ -994,12 +1005,236 @@ def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
     masked_grad_check(tagname, run_oracle, _canon_grads(net), {"grad_rays": rays.grad}, keep, prec)
 
 
+def t_train_c1():
+    """BASELINE config 1 as bench.py times it (Trainer.step_coarse_only: render_infer at N_rand 256, 32 + 0, naive, ONE summed
+    loss gradient, Adam), eagerly AND as the replayed HIP graph, against the reference fixture `train_c1` and the oracle
+    (models/lushnerf.py:679-763 -> :354-479; run_lushnerf.py:652-661 with rgb0 = rgb)."""
+    from lush_nerf_amd.trainer import Trainer
+    from tests.test_oracle_golden import oracle_c1_step
+    g = util.golden("train_c1")
+    n, Ns, Ni, seed = (int(x) for x in g["meta"])
+    prec = ops.Precision(*E2E_PLANES)
+
+    def fresh():
+        net = _nerf_all(0, seed, sharp=True, precision=prec)
+        return net, Trainer(net, H, W, F, Ns, 0, kernel_start_iter=1 << 30)
+    b = batch_of(n, seed)
+    gb = {"rays": gpu(b["rays"]), "target": gpu(b["target"])}
+    cpu_draws = util.tdraws(n, Ns, 0, seed)
+    w0 = {k: torch.from_numpy(v) for k, v in synth.all_weights(util.NUM_IMG, seed, sharp=True).items() if not k.startswith("mlp_fine.")}
+    # (1) eager, explicit draws: outputs, loss, gradient-None set, gradients (masked float64 / fp32 pair + the fixture), Adam
+    net, tr = fresh()
+    keep = net.hooks.keep = {}
+    try:
+        loss, tm = tr.step_coarse_only(gb, draws={k: v.to(dev) for k, v in cpu_draws.items()})
+    finally:
+        net.hooks.keep = None
+    rep("c1 step rgb (tone-mapped)", tm, g["rgb_tm"], 1e-4)
+    rep("c1 step loss", loss.reshape(1), g["loss"].reshape(1), 1e-4)
+    fw = net.read_faults()
+    RESULTS.append(("c1 step fault word", float(fw), 0, fw == 0))
+    grads = {k: (None if v is None else v.clone()) for k, v in _canon_grads(net).items()}
+    coarse = {k: v for k, v in grads.items() if k.startswith("mlp_coarse.")}
+    # the trainer's flat gradient gives every parameter a .grad view; what this step must leave untouched (zero) is every
+    # tensor the reference leaves with grad = None (RBK, noise MLP: the noise branch is detached from the loss here)
+    none_ref = set(str(x) for x in g["grad_none"])
+    touched = set(k for k, v in grads.items() if v is not None and float(v.abs().max()) > 0)
+    ok = touched == set(grads) - none_ref
+    RESULTS.append(("c1 step: exactly the reference's grad-None tensors stay zero", 0. if ok else 1., 0, ok))
+    print("ok  " if ok else "FAIL", "c1 step grad-None set", sorted(touched ^ (set(grads) - none_ref))[:6])
+
+    def run_oracle(dt):
+        p = {k: v.to(dt).requires_grad_(True) for k, v in util.params(seed, sharp=True).items() if not k.startswith("mlp_fine.")}
+        _, _, _, lo = oracle_c1_step(p, b["rays"].to(dt), b["target"].to(dt), Ns, {k: v.to(dt) for k, v in cpu_draws.items()})
+        lo.backward()
+        return p, {}
+    masked_grad_check("c1 step", run_oracle, coarse, {}, keep, prec)
+    worst = util.check_grads(coarse, g, 1e9)
+    wk = max(worst, key=worst.get)
+    sec = 3e-2 if E2E_PLANES[0] in (2, 3) else 1e-1
+    RESULTS.append((f"c1 step worst grad vs fixture [{wk}]", worst[wk], sec, bool(worst[wk] <= sec)))
+    print(f"{'ok  ' if worst[wk] <= sec else 'FAIL'} c1 step worst grad vs reference fixture {wk}: {worst[wk]:.3e}")
+    # Adam's first step on these gradients: p - lr * g / (|g| + eps) (torch.optim.Adam, bias corrections cancel at step 1)
+    a0, a1 = tr.flat.segments[0]
+    flat0 = torch.cat([gpu(w0[k]).reshape(-1) for k in _flat_order(net)[0]])
+    gflat = tr.flat.grad[a0:a1]
+    want = flat0 - 5e-4 * gflat / (gflat.abs() + 1e-8)
+    rep("c1 step Adam update of the coarse network", tr.flat.param[a0:a1], want, 1e-6)
+    rest_same = torch.equal(tr.flat.param[a1:], torch.cat([gpu(w0[k]).reshape(-1) for k in _flat_order(net)[1]]))
+    RESULTS.append(("c1 step leaves RBK / noise parameters alone", 0. if rest_same else 1., 0, rest_same))
+    # (2) the same step as a replayed HIP graph (device step state: draw counter, rate, Adam count) against an eager trainer fed
+    # the draws the graph's Philox call makes (same seed / offset): losses, colours, gradients, parameters after 3 steps
+    torch.manual_seed(1234)
+    net_g, tr_g = fresh()
+    net_e, tr_e = fresh()
+    batches = [{"rays": gpu(batch_of(n, seed + 1 + s)["rays"]), "target": gpu(batch_of(n, seed + 1 + s)["target"])} for s in range(4)]
+    tr_g.step_coarse_only(batches[0])              # one eager step first (lazy initialisation outside the capture)
+    d0 = ops.march_draws(n, Ns, 0, 1., 1., dev, offset=1)
+    tr_e.step_coarse_only(batches[0], draws=d0)
+    net_e.hooks.draw_offset = net_g.hooks.draw_offset
+    replay, static = tr_g.capture_coarse_only(batches[1])
+    for s in (1, 2, 3):
+        for k in static:
+            static[k].copy_(batches[s][k])
+        off = net_g.hooks.draw_offset + 1
+        replay()
+        ds = ops.march_draws(n, Ns, 0, 1., 1., dev, offset=off)
+        le, tme = tr_e.step_coarse_only(batches[s], draws=ds)
+        rep(f"c1 graph replay {s}: loss vs eager", replay.loss.reshape(1), le.reshape(1), 2e-6)
+        rep(f"c1 graph replay {s}: colours vs eager", replay.tm, tme, 2e-6)
+        rep(f"c1 graph replay {s}: gradient vs eager", tr_g.flat.grad, tr_e.flat.grad, 2e-5)
+    rep("c1 graph: parameters after 1 eager + 3 replayed steps vs 4 eager steps", tr_g.flat.param, tr_e.flat.param, 2e-6)
+    cnt_ok = tr_g.steps == tr_e.steps and tr_g.global_step == tr_e.global_step == 4
+    RESULTS.append(("c1 graph: host counters advance like the eager step's", 0. if cnt_ok else 1., 0, cnt_ok))
+
+
+class KeepAll(dict):
+    """ops.Hooks.keep that remembers EVERY march of a step (the plain dict keeps the last one's stashes): the combined step of
+    the consistency branch marches twice through the same two networks."""
+
+    def __init__(self):
+        super().__init__()
+        self.marches = []
+
+    def update(self, *a, **kw):
+        if "stash_c" in kw:
+            self.marches.append(dict(kw))
+        super().update(*a, **kw)
+
+
+def _masks_of_all_marches(keep, precision):
+    """ReLU decisions of every coarse / fine / noise evaluation of a step, rows in call order (util.masked_oracle consumes them
+    with a per-prefix cursor)."""
+    pf, pb = precision.fwd, precision.bwd
+    f16 = pf == ops.PLANES_F16
+    sp = ops.nplanes(ops.stash_code(pf, pb))
+    per = {"mlp_coarse": [], "mlp_fine": []}
+    for m in keep.marches:
+        per["mlp_coarse"].append(util.stash_masks(ops.NET_NERF, sp, m["P_c"], m["stash_c"], f16=f16))
+        if m.get("stash_f") is not None:
+            per["mlp_fine"].append(util.stash_masks(ops.NET_NERF, sp, m["P_f"], m["stash_f"], f16=f16))
+    out = {k: [torch.cat([c[l] for c in v], 0) for l in range(len(v[0]))] for k, v in per.items() if v}
+    if keep.get("stash_noise") is not None:
+        pn = precision.noise()
+        out["mlp_noise_coarse"] = util.stash_masks(ops.NET_NOISE, ops.nplanes(ops.stash_code(pn.fwd, pn.bwd)), keep["P_noise"],
+                                                   keep["stash_noise"], f16=False)
+    return out
+
+
+def t_consist_step():
+    """Trainer.step(batch, i, consist=...) -- the combined step after noisenerf_start_iter (run_lushnerf.py:625-661): the ray
+    batch's march AND the aligned-pixel march accumulate into ONE flat gradient, loss = image terms + 1e-2 * loss_rgb for
+    i > noisenerf_start_iter, + 0 at i == noisenerf_start_iter (computed, not added).  Against the reference fixture
+    `train_consist` and the masked float64 / fp32 oracle; the `>` / `>=` edge; step_graph's fall-back."""
+    from lush_nerf_amd.trainer import Trainer
+    from tests.test_oracle_golden import consist_step_inputs, oracle_consist_step
+    g = util.golden("train_consist")
+    n, Ns, Ni, seed, V, ns, anchor, st, am, cm = consist_step_inputs(g)
+    prec = ops.Precision(*E2E_PLANES)
+    rbk_scale, START = 2.0e4, 5
+    b = batch_of(n, seed)
+    gb = {k: gpu(v) for k, v in b.items()}
+    poses = torch.from_numpy(synth.poses(V, seed))
+    consist = {"poses": gpu(poses), "images_idx": torch.arange(V), "Align_matrix": {anchor: gpu(am)}, "Align_mask": {anchor: gpu(cm)},
+               "anchor_pose": anchor, "samples": st}
+    cpu_draws = util.tdraws(n * 5, Ns, Ni, seed)
+    draws = {k: v.to(dev) for k, v in cpu_draws.items()}
+
+    def fresh():
+        net = _nerf_all(Ni, seed, sharp=True, precision=prec, rbk_scale=rbk_scale)
+        return net, Trainer(net, H, W, F, Ns, Ni, kernel_start_iter=0, allkernel_start_iter=0, noisenerf_start_iter=START)
+    # (1) i > noisenerf_start_iter: weight 1e-2
+    net, tr = fresh()
+    keep = net.hooks.keep = KeepAll()
+    try:
+        loss = tr.step(gb, START + 1, draws=draws, consist=consist)
+    finally:
+        net.hooks.keep = None
+    rep("consist step loss (image terms + 1e-2 loss_rgb)", loss.reshape(1), g["loss"].reshape(1), 1e-4)
+    fw = net.read_faults()
+    RESULTS.append(("consist step fault word", float(fw), 0, fw == 0))
+    two = len(keep.marches) == 2
+    RESULTS.append(("consist step marched twice (ray batch, aligned pixels)", float(len(keep.marches)), 2, two))
+    grads = {k: v.clone() for k, v in _canon_grads(net).items()}
+    none_ref = set(str(x) for x in g["grad_none"])
+    live = {k: v for k, v in grads.items() if k not in none_ref}
+    dead_zero = all(float(grads[k].abs().max()) == 0.0 for k in none_ref if k in grads)
+    RESULTS.append(("consist step: the reference's grad-None tensors stay zero", 0. if dead_zero else 1., 0, dead_zero))
+
+    def run_oracle(dt):
+        p = {k: v.to(dt).requires_grad_(True) for k, v in util.params(seed, sharp=True, rbk_scale=rbk_scale).items()}
+        out = oracle_consist_step(p, b, Ns, Ni, {k: v.to(dt) for k, v in cpu_draws.items()}, poses, am, cm, st, 1e-2, dt)
+        out[-1].backward()
+        return p, {}
+    # (masked_grad_check reads the masks through _gpu_masks(keep, prec): hand it every march's rows)
+    global _gpu_masks
+    saved = _gpu_masks
+    _gpu_masks = _masks_of_all_marches
+    try:
+        masked_grad_check("consist step", run_oracle, live, {}, keep, prec)
+    finally:
+        _gpu_masks = saved
+    worst = util.check_grads(live, g, 1e9)
+    wk = max(worst, key=worst.get)
+    sec = 3e-2 if E2E_PLANES[0] in (2, 3) else 1e-1
+    RESULTS.append((f"consist step worst grad vs fixture [{wk}]", worst[wk], sec, bool(worst[wk] <= sec)))
+    print(f"{'ok  ' if worst[wk] <= sec else 'FAIL'} consist step worst grad vs reference fixture {wk}: {worst[wk]:.3e}")
+    # the consistency term must actually reach the gradient: against the same step without it
+    net0, tr0 = fresh()
+    loss0 = tr0.step(gb, START + 1, draws=draws)
+    rep("plain step loss (image terms)", loss0.reshape(1), g["loss_img"].reshape(1), 1e-4)
+    moved = util.relerr(tr.flat.grad, tr0.flat.grad)
+    RESULTS.append(("consist step: the 1e-2 loss_rgb term changes the gradient", moved, 1e-4, moved > 1e-4))
+    print(f"{'ok  ' if moved > 1e-4 else 'FAIL'} consist step gradient differs from the plain step's by {moved:.2e}")
+    # (2) i == noisenerf_start_iter: computed, weight 0 (run_lushnerf.py:629 `>=`, :658 `>`): the plain step's loss and gradient
+    net1, tr1 = fresh()
+    loss1 = tr1.step(gb, START, draws=draws, consist=consist)
+    rep("consist step at i == noisenerf_start_iter: loss = image terms", loss1.reshape(1), loss0.reshape(1), 1e-6)
+    rep("consist step at i == noisenerf_start_iter: gradient = plain step's", tr1.flat.grad, tr0.flat.grad, 2e-5)
+    rep("consist step at i == noisenerf_start_iter: parameters = plain step's", tr1.flat.param, tr0.flat.param, 1e-6)
+    # (3) step_graph with the consistency branch falls back to step() and keeps the term (device draws, same seed and offsets)
+    torch.manual_seed(4321)
+    net2, tr2 = fresh()
+    net3, tr3 = fresh()
+    for i in range(2):       # the two plain steps after which step_graph would capture
+        tr2.step_graph(gb, i)
+        tr3.step(gb, i)
+    l2 = tr2.step_graph(gb, START + 1, consist=consist)
+    l3 = tr3.step(gb, START + 1, consist=consist)
+    rep("step_graph(consist=...) falls back: loss", l2.reshape(1), l3.reshape(1), 2e-6)
+    rep("step_graph(consist=...) falls back: gradient", tr2.flat.grad, tr3.flat.grad, 2e-5)
+    nograph = tr2._graph is None
+    RESULTS.append(("step_graph(consist=...) captured nothing", 0. if nograph else 1., 0, nograph))
+
+
+def _flat_order(net):
+    """Canonical names of the trainer's three Adam segments (trainer.adam_segments), in flat-buffer order."""
+    from lush_nerf_amd.trainer import adam_segments
+    name_of = {}
+    for k, v in net.named_parameters():
+        ck = k
+        if k.startswith("blur_kernel_net.RBK."):
+            ck = "mlp_rbk." + k[len("blur_kernel_net.RBK."):]
+        elif k.startswith("blur_kernel_net.view_embed_layer."):
+            ck = "mlp_rbk.view_embedding_layer.view_embed_layer.weight"
+        name_of.setdefault(id(v), ck)
+    segs = adam_segments(net)
+    seen, first, rest = set(), [], []
+    for si, seg in enumerate(segs):
+        for p_ in seg:
+            if id(p_) in seen:
+                continue
+            seen.add(id(p_))
+            (first if si == 0 else rest).append(name_of[id(p_)])
+    return first, rest
+
+
 if __name__ == "__main__":
     lib.load()
     print("device:", torch.cuda.get_device_name(0))
     only = sys.argv[1:]
     for fn in (t_zgrid_pack, t_gen_rays, t_composite, t_sample, t_mlp_fwd, t_mlp_ragged, t_mlp_bwd, t_rbk, t_warp_ndc, t_mix, t_blur_mix, t_march_e2e, t_train_e2e,
-               t_lindisp_white, t_eval_forward, t_consistency, t_faults, t_draws, t_train_bench_regime):
+               t_lindisp_white, t_eval_forward, t_consistency, t_faults, t_draws, t_train_bench_regime, t_train_c1, t_consist_step):
         if not only or fn.__name__ in only:
             section(fn)
     bad = [r for r in RESULTS if not r[3]]

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     assert set(lib.EXPORTS) <= declared | {"lush_last_error"}
     l = lib.load()
-    assert l.lush_abi_version() == lib.ABI_VERSION == 8
+    assert l.lush_abi_version() == lib.ABI_VERSION == 9
     # pure host queries (no device work)
     p1, p3 = l.lush_mlp_packed_bytes(0, 1), l.lush_mlp_packed_bytes(0, 3)
     assert p1 > 2 * 593408 * 2 and 2.9 * p1 < p3 < 3 * p1      # fragments scale with planes, the fp32 bias block does not
@@ -84,6 +84,34 @@ def test_model_mirror_has_reference_state_dict_keys():
     with pytest.raises(NotImplementedError):
         args2 = argparse.Namespace(**{**vars(args), "multires": 6})
         M.NeRFAll(args2, None)
+
+
+def test_unbuilt_branches_are_refused_not_ignored():
+    """Branches of the cited functions that this build does not implement raise (models/lushnerf.py:709-713 c2w_staticcam,
+    :222-260 / :760 / :817 use_awp); `kernelpixel` / `allkernel` are dead parameters of the reference's render trio (never read
+    in :679-866) and stay accepted."""
+    import argparse
+    from lush_nerf_amd import model as M
+    args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
+                              N_importance=64, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                              rgb_activate="sigmoid", sigma_activate="relu", tone_mapping_type="gamma",
+                              render_rmnearplane=80)
+    net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4))
+    rays = torch.zeros(4, 3, 2)
+    K = [[10., 0, 4], [0, 10., 4], [0, 0, 1]]
+    for fn in (net.render_infer, net.render_train_scene, net.render_train_noise):
+        with pytest.raises(NotImplementedError, match="c2w_staticcam"):
+            fn(8, 8, K, 1024, rays=rays, use_viewdirs=True, c2w_staticcam=torch.eye(4)[:3], N_samples=8)
+        with pytest.raises(NotImplementedError, match="use_awp"):
+            fn(8, 8, K, 1024, rays=rays, use_viewdirs=True, use_awp=True, N_samples=8)
+        with pytest.raises(RuntimeError, match="no CPU path"):      # accepted keywords reach the ops, which refuse CPU tensors
+            fn(8, 8, K, 1024, rays=rays, use_viewdirs=True, kernelpixel=torch.ones(4), allkernel=1, N_samples=8)
+    with pytest.raises(NotImplementedError, match="use_awp"):
+        net._render_train_scene_packed(torch.zeros(4, 11), 1024, use_awp=True, N_samples=8)
+    with pytest.raises(NotImplementedError):
+        M.NeRF(use_awp=True)
+    with pytest.raises(NotImplementedError):
+        M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4, use_awp=True)
 
 
 def test_flat_params_views():
@@ -420,6 +448,25 @@ def test_bench_self_launch_builds_the_documented_command(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.self_launch(argparse.Namespace(gpus=4))
     assert "only 1 GPU" in str(e.value.code) and not seen
+
+
+def test_bench_traffic_child_profiles_the_same_workload():
+    """Advisor (round 4): the child runs behind roofline.traffic (rocprofv3 --pmc passes of `this very command`) dropped the size
+    arguments and profiled the default workload whatever the parent timed.  They are forwarded now, with mode, variant and library."""
+    import argparse
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    a = argparse.Namespace(planes="h,h", config="C2", variant=64, n_rand=2048, n_samples=128, n_importance=128, micro_batch=1024, so="/x/y.so")
+    t = bench.traffic_child_args(a)
+    val = lambda k: t[t.index(k) + 1]
+    assert (val("--n-rand"), val("--n-samples"), val("--n-importance"), val("--micro-batch")) == ("2048", "128", "128", "1024")
+    assert val("--planes") == "h,h" and val("--variant") == "64" and val("--so") == "/x/y.so" and val("--steps") == "2"
+    assert "--no-traffic" in t and "--no-kernel-pass" in t and "--no-cpu-baseline" in t and val("--sustained") == "0"      # no recursion, nothing else timed
+    # and the parser accepts exactly that tail
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *[x for x in t if x != "/x/y.so" and x != "--so"], "--gpus", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert "--gpus must be >= 1" in (r.stderr + r.stdout), r.stderr[-400:]
 
 
 def test_quoted_numbers_match_their_sources():

@@ -21,7 +21,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SECTIONS = ["t_zgrid_pack", "t_gen_rays", "t_composite", "t_sample", "t_mlp_fwd", "t_mlp_ragged", "t_mlp_bwd", "t_rbk", "t_warp_ndc", "t_mix", "t_blur_mix",
-            "t_march_e2e", "t_train_e2e", "t_lindisp_white", "t_eval_forward", "t_consistency", "t_faults", "t_draws"]
+            "t_march_e2e", "t_train_e2e", "t_lindisp_white", "t_eval_forward", "t_consistency", "t_faults", "t_draws", "t_train_c1", "t_consist_step"]
 
 
 @pytest.fixture(scope="module")
@@ -77,6 +77,22 @@ def test_headline_mode_end_to_end(diag, planes, monkeypatch):
         getattr(diag, section)()
         bad = [(n, e, t) for n, e, t, ok in diag.RESULTS if not ok]
         assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("section", ["t_train_c1", "t_consist_step"])
+def test_unverified_gradient_paths_in_the_headline_mode(diag, section, monkeypatch):
+    """Round 5: the two steps whose backward had never met the oracle, in the bench's mode (h,h) (the fp32-equivalent mode runs
+    them in test_kernel_parity).  t_train_c1 = BASELINE config 1's step exactly as bench.py times it (Trainer.step_coarse_only:
+    render_infer at N_rand 256, 32 + 0, one summed loss gradient, Adam), eagerly AND as the replayed HIP graph, against the
+    reference fixture `train_c1` and the masked float64 oracle (models/lushnerf.py:679-763, :354-479).  t_consist_step =
+    Trainer.step(batch, i, consist=...) around noisenerf_start_iter (run_lushnerf.py:625-661) against the reference fixture
+    `train_consist`, incl. the `>` / `>=` edge and step_graph's fall-back."""
+    monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes("h,h"))
+    diag.RESULTS.clear()
+    getattr(diag, section)()
+    torch.cuda.synchronize()
+    bad = [(n, e, t) for n, e, t, ok in diag.RESULTS if not ok]
+    assert diag.RESULTS and not bad, bad[:8]
 
 
 def test_plain_bf16_is_outside_the_parity_bound(diag, monkeypatch):
@@ -699,6 +715,85 @@ def test_step_graph_resynchronises_with_the_host(diag, mode, tmp_path):
     print(f"step_graph after a checkpoint load: losses within {worst:.1e} of the eager steps, parameters within {dp:.1e}")
 
 
+def test_march_backward_uses_the_packed_weights_of_its_forward(diag):
+    """Advisor (round 4): a forward that took the trainer's packed fragments (ops.Hooks.packed) skips the workspace copy, so a
+    backward running AFTER hooks.packed was cleared (outside Trainer.step's try block, a retained graph) must still be handed
+    the forward's buffers -- they are kept by the autograd node now -- instead of chaining over a never-written copy."""
+    from lush_nerf_amd import ops, synth
+    from lush_nerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    n, Ns, Ni, seed = 24, 64, 64, 9
+    batch = diag.nondc_batch(n, seed).to(dev)
+    draws = {k: v.to(dev) for k, v in diag.util.tdraws(n, Ns, Ni, seed).items()}
+    G = diag.gpu(synth.normal((n, 3), 92))
+
+    def grads(packed, clear):
+        net = _model(Ni, diag.ops.parse_planes("h,h"), seed)
+        net.train()
+        tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni)
+        if packed:
+            tr._pack_weights(zero_grad=True)
+            assert net.hooks.packed
+        ret = net.render_rays_nonoise(batch, N_samples=Ns, retraw=True, perturb=1., N_importance=Ni, raw_noise_std=1., draws=draws)
+        if clear:
+            net.hooks.packed = None
+        ((ret["rgb_map"] * G).sum() + (ret["rgb0"] * G).sum()).backward()
+        net.hooks.packed = None
+        return torch.cat([p.grad.reshape(-1) for p in list(net.mlp_coarse.parameters()) + list(net.mlp_fine.parameters())]).clone()
+    ref = grads(False, False)
+    for packed, clear in ((True, False), (True, True)):
+        got = grads(packed, clear)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, (packed, clear, err)
+
+
+def test_second_backward_over_a_retained_graph(diag):
+    """Advisor (round 4): RbkWarp / RbkWarpNdc accumulate d(r, v, w) in the zero tail of the SAVED activation rows;
+    lush_rbk_mlp_bwd now leaves that tail zero again (ABI 9), so a second backward over the same graph adds exactly the first
+    one's gradient once more.  Also: NoiseMlp.backward takes a [:, :3] view's base as its 4-column d_raw only when BlurMix marked
+    it (column 3 = 0); any other such view gets the zero-padded copy."""
+    from lush_nerf_amd import ops, synth
+    dev = torch.device("cuda:0")
+    g = diag.util.golden("rbk")
+    n, seed = (int(x) for x in g["meta"])
+    p = diag.util.params(seed, rbk_scale=3.0e5)
+    b = diag.batch_of(n, seed)
+    for fused in (False, True):
+        tens = [diag.gpu(t).requires_grad_(True) for t in diag.rbk_tensors(p)]
+        rg = diag.gpu(b["rays"]).requires_grad_(True)
+        if fused:
+            out, ccw, _ = ops.RbkWarpNdc.apply(rg, diag.gpu(b["images_idx"]), 4, 0.1, None, None, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF,
+                                               True, 0., 1., *tens)
+        else:
+            out, ccw = ops.RbkWarp.apply(rg, diag.gpu(b["images_idx"]), 4, 0.1, None, None, *tens)
+        loss = (out * diag.gpu(synth.normal(tuple(out.shape), 61))).sum() + (ccw * diag.gpu(synth.normal(tuple(ccw.shape), 62))).sum()
+        loss.backward(retain_graph=True)
+        first = [t.grad.clone() for t in tens]
+        loss.backward()
+        for t, f in zip(tens, first):
+            assert float((t.grad - 2 * f).abs().max()) <= 2e-5 * max(float(f.abs().max()), 1e-30), fused
+
+    class FourColumnView(torch.autograd.Function):      # an upstream op whose gradient is a [:, :3] view of a [R,4] buffer, column 3 != 0
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            buf = torch.cat([gr, torch.full_like(gr[:, :1], 7.0)], 1).contiguous()
+            return buf[:, :3]
+    net = _model(64, (2, 2), 3)
+    batch = diag.nondc_batch(32, 3).to(dev)
+    G = diag.gpu(synth.normal((32, 3), 93))
+    res = []
+    for wrap in (False, True):
+        net.zero_grad(set_to_none=True)
+        noise = net._noise(batch, 64, False)
+        ((FourColumnView.apply(noise) if wrap else noise) * G).sum().backward()
+        res.append(torch.cat([p.grad.reshape(-1) for p in net.mlp_noise_coarse.parameters() if p.grad is not None]).clone())
+    assert float((res[0] - res[1]).abs().max()) <= 2e-5 * float(res[0].abs().max())
+
+
 def test_loss_with_one_tensor_in_both_roles(diag):
     """lush_loss_fwd_bwd with gb == NULL (a == b: no fine pass, the reference's rgb0 = rgb): the one gradient is the sum of the two
     the two-buffer form gives, the loss the same; a != b without a second buffer is refused."""
@@ -983,14 +1078,14 @@ def test_march_through_the_c_abi_alone(diag):
 # < 0.5, every run's fall within a factor 1.5.  A wrong gradient does not land in these bands (a dropped layer gradient or a
 # sign error leaves the cosine below 0.5 and the loss where it started); the precise per-tensor statement is the masked
 # float64 check with its cosine gate (gpu_diag.masked_grad_check), which every mode passes on every fixture.
-LONG_TRAJ_REPS = 4
+LONG_TRAJ_REPS = {"2,2": 4, "2,h": 2, "h,h": 4}      # (the fall-back mode: two runs; the suite has a 900-s limit on the driver's box)
 
 
 @pytest.mark.parametrize("planes", ["2,2", "2,h", "h,h"])
 def test_long_training_trajectory_follows_the_reference(diag, planes):
     """300 optimisation steps of the REAL reference (make_golden.case_trajectory_long) on teacher targets -- what a second
     weight set renders for the same rays, so the loss genuinely falls -- against Trainer.step in the fp32-equivalent mode,
-    the fall-back (2,h) and the bench headline (h,h), LONG_TRAJ_REPS runs each: the windowed loss curve inside one band for
+    the fall-back (2,h) and the bench headline (h,h), LONG_TRAJ_REPS[mode] runs each: the windowed loss curve inside one band for
     all modes, the loss must have fallen as the reference's did, and the final fine rgb head must point the way the
     reference's does."""
     import argparse
@@ -1010,7 +1105,7 @@ def test_long_training_trajectory_follows_the_reference(diag, planes):
     mr = ref[:steps // win * win].reshape(-1, win).mean(1)
     fall_ref = ref[-win:].mean() / ref[:win].mean()
     cosines, devs = [], []
-    for rep in range(LONG_TRAJ_REPS):
+    for rep in range(LONG_TRAJ_REPS[planes]):
         net = M.NeRFAll(args, M.RBK(30, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
                         precision=ops.Precision(*ops.parse_planes(planes)))
         w0 = synth.all_weights(30, seed, sharp=True, rbk_scale=2.0e4)

@@ -185,6 +185,76 @@ def test_consistency_branch_golden():
     util.check_grads({k: v.grad for k, v in p.items()}, g, 2e-4)   # forward is bit-compatible: no kink flips
 
 
+# ----------------------------------------------------------------------------- round-5 fixtures
+def oracle_c1_step(p, rays, target, Ns, draws):
+    """BASELINE config 1 as a training step (tests/golden/make_golden.py case_train_c1): render_infer -> render_rays at
+    N_importance = 0 (models/lushnerf.py:679-763, :354-479), the loss of run_lushnerf.py:652-661 with rgb0 = rgb."""
+    batch = O.pack_rays(util.H, util.W, util.FOCAL, rays)
+    ret, ret_noise = O.render_rays(p, batch, Ns, retraw=True, perturb=1., N_importance=0, raw_noise_std=1., draws=draws)
+    tm = O.tonemap(ret["rgb_map"])
+    return ret, ret_noise, tm, O.train_loss(tm, tm, target)
+
+
+def test_c1_training_step_golden():
+    g = util.golden("train_c1")
+    n, Ns, Ni, seed = (int(x) for x in g["meta"])
+    p = {k: v for k, v in util.params(seed, sharp=True, requires_grad=True).items() if not k.startswith("mlp_fine.")}
+    b = _batch(n, seed)
+    ret, ret_noise, tm, loss = oracle_c1_step(p, b["rays"], b["target"], Ns, util.tdraws(n, Ns, 0, seed))
+    loss.backward()
+    for k, v in (("rgb_map", ret["rgb_map"]), ("depth_map", ret["depth_map"]), ("acc_map", ret["acc_map"]), ("rgb_tm", tm),
+                 ("noise_rgb", ret_noise["rgb_map"])):
+        assert util.relerr(v, g[k]) < TOL, k
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    none = set(str(x) for x in g["grad_none"])
+    for k, v in p.items():
+        assert (v.grad is None) == (k in none), k
+    assert any(v.grad is not None for v in p.values())
+    util.check_grads({k: v.grad for k, v in p.items()}, g, 2e-4)      # naive: the forward is bit-compatible, no kink flips
+
+
+def consist_step_inputs(g):
+    n, Ns, Ni, seed, V, ns, anchor = (int(x) for x in g["meta"])
+    HW = util.H * util.W
+    st = torch.from_numpy(g["samples"])
+    am = torch.zeros(V, HW, 4)
+    am[:, st, 2] = torch.from_numpy(g["ax"])
+    am[:, st, 3] = torch.from_numpy(g["ay"])
+    cm = torch.zeros(V, HW, dtype=torch.bool)
+    cm[:, st] = torch.from_numpy(g["cert_in"]) != 0
+    return n, Ns, Ni, seed, V, ns, anchor, st, am, cm
+
+
+def oracle_consist_step(p, b, Ns, Ni, draws, poses, am, cm, st, weight=1e-2, dt=torch.float32):
+    """The combined step of run_lushnerf.py:625-661 for i > noisenerf_start_iter: image terms of the kernel-on forward plus
+    weight x the masked L1 of the aligned-pixel renders; returns (outputs, rgb_align, loss_img, loss_rgb, loss)."""
+    out = O.forward_train(p, util.H, util.W, util.FOCAL, b["rays"].to(dt), b["images_idx"], Ns, Ni, force_naive=False,
+                          allkernel=False, kernel_pixel=b["fq_mask"], draws=draws)
+    img = O.train_loss(out[0], out[1], b["target"].to(dt))
+    ra, ca = O.render_aligned_pixel(p, util.H, util.W, util.FOCAL, poses.to(dt), am.to(dt), cm, st, Ns, Ni)
+    lrgb = O.consist_loss(ra, ca.to(dt), 0.8)
+    return out, ra, img, lrgb, img + weight * lrgb
+
+
+def test_combined_consistency_step_golden():
+    """One backward through BOTH the ray batch and the aligned-pixel renders (loss += 1e-2 * loss_rgb)."""
+    g = util.golden("train_consist")
+    n, Ns, Ni, seed, V, ns, anchor, st, am, cm = consist_step_inputs(g)
+    p = util.params(seed, sharp=True, rbk_scale=2.0e4, requires_grad=True)
+    b = _batch(n, seed)
+    poses = torch.from_numpy(synth.poses(V, seed))
+    out, ra, img, lrgb, loss = oracle_consist_step(p, b, Ns, Ni, util.tdraws(n * 5, Ns, Ni, seed), poses, am, cm, st)
+    loss.backward()
+    assert util.relerr(out[0], g["rgb_blur"]) < TOL and util.relerr(out[1], g["rgb0_blur"]) < TOL
+    assert util.relerr(ra, g["rgb_align"]) < TOL
+    assert abs(img.item() - float(g["loss_img"])) < 1e-6 and abs(lrgb.item() - float(g["loss_rgb"])) < 1e-6
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    none = set(str(x) for x in g["grad_none"])
+    for k, v in p.items():
+        assert (v.grad is None) == (k in none), k
+    util.check_grads({k: v.grad for k, v in p.items()}, g, 3e-2)      # kernel on: kink flips behind the closed-form warp (see above)
+
+
 def test_lr_schedule_matches_reference_loop():
     """run_lushnerf.py:675-685, 788: the rate is updated after optimizer.step() from the un-incremented global_step."""
     used = O.lr_schedule(5)
