@@ -384,7 +384,7 @@ def main():
         c = CONFIGS["C1"]
         from lush_nerf_amd.trainer import BlobBatch
         batches = [BlobBatch(b) for b in make_batches(c["n_rand"])]      # per-step inputs in one buffer: one copy per replay
-        net = make_model(model_args(0), dev, ops.Precision(pf, pb)).train()
+        net = make_model(model_args(0), dev, ops.Precision(pf, pb, a.variant)).train()
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, c["ns"], 0, kernel_start_iter=1 << 30, distributed=True)
 
         # the step itself is Trainer.step_coarse_only (render_infer at 32 + 0, one summed loss gradient, Adam): the same function

@@ -1072,12 +1072,12 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
         const unsigned base = lds0 + (unsigned)slot * GRP_STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (st.on[i]) dma16s(src, st.voff[i], __builtin_amdgcn_readfirstlane(base + st.dst[i]));
+            if (st.on[i]) dma16s_stream(src, st.voff[i], __builtin_amdgcn_readfirstlane(base + st.dst[i]));
         src += st.stride;
         if constexpr (NV2 > 0) {
             if (x2_wave) {
                 if (!PE || st.xd == nullptr) {
-                    if (st.on2) dma16s(src2, st.voff2, __builtin_amdgcn_readfirstlane(base + st.dst2));
+                    if (st.on2) dma16s_stream(src2, st.voff2, __builtin_amdgcn_readfirstlane(base + st.dst2));
                     src2 += st.stride2;
                 } else {
                     // re-encode this tile's X2 rows from the quadruples in LDS (chunk ti / 16, loaded a chunk ahead)

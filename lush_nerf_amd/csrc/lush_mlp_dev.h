@@ -144,6 +144,16 @@ __device__ __forceinline__ void dma16s(const void* sbase /* uniform */, unsigned
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
 
+// The same for bytes that ONE workgroup reads ONCE (the weight-gradient kernel's stash stream): non-temporal policy
+// (MI355X_MICROARCH.md, row nt-weights: issued -> landed -18 %).  Same-box A/B, fine pass, alternating processes (round 5,
+// tools/ab_r05.sh): 4.093 / 4.098 ms against 4.189 / 4.196 ms with the default policy (-2.3 %).  The weight streams of the
+// forward / chain kernels keep the default policy: every CU re-reads them from L2.
+__device__ __forceinline__ void dma16s_stream(const void* sbase /* uniform */, unsigned voff, unsigned lds_base /* uniform */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
 // Two of them under one M0 save/restore.
 __device__ __forceinline__ void dma16s_x2(const void* sbase, unsigned voff0, unsigned lds0, unsigned voff1, unsigned lds1) {
     unsigned keep;

@@ -329,7 +329,11 @@ struct WdPass {
     static __device__ __forceinline__ void stash_store(const WdCarry& cr, const WdRt& rt) {
         constexpr int c = JOB / 4, j = JOB % 4;      // uniform row-block base + ONE per-lane offset
 #ifndef LUSH_ABL_NOSTORE
+#ifdef LUSH_PLAIN_STASH      // developer A/B: cached stores (tools/micro/mall_probe.hip: a pure write stream is faster with them)
+        *reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off) = cr.sb[I4 % WD_SB];
+#else
         __builtin_nontemporal_store(cr.sb[I4 % WD_SB], reinterpret_cast<u32x4*>(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2 + rt.srow_off));
+#endif
 #else
         asm volatile("" ::"v"(cr.sb[I4 % WD_SB]));
 #endif

@@ -294,7 +294,11 @@ struct WbPass {
 #ifndef LUSH_ABL_NOSTORE
         // (s_nop 1: a store of more than 8 bytes reads its data registers for two more cycles -- the hazard the compiler covers for its
         // own stores; without it the conversion's VALU code, which re-uses the row's registers at once, reached memory in some lanes)
+#ifdef LUSH_PLAIN_STASH      // developer A/B: cached stores
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(rt.srow_off), "v"(cr.sb[I4 % WB_SB]), "s"(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2) : "memory");
+#else
         asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(rt.srow_off), "v"(cr.sb[I4 % WB_SB]), "s"(rt.srows + ((c * 32 + 8 * I4) * LD + j * 64) * 2) : "memory");
+#endif
 #else
         asm volatile("" ::"v"(cr.sb[I4 % WB_SB]));
 #endif

