@@ -23,6 +23,7 @@ dev = torch.device("cuda:0")
 E2E_PLANES = ops.parse_planes(os.environ.get("LUSH_PLANES", "2,2"))
 H, W, F = util.H, util.W, util.FOCAL
 RESULTS = []
+PER_TENSOR = []      # masked_grad_check appends (tag, tensor, e_gpu, e_f32, 1 - cos gpu, 1 - cos f32) per parameter tensor (tools/parity_table.py)
 
 
 def rep(name, got, ref, tol):
@@ -804,6 +805,12 @@ MASKED_FACTOR = 32.0
 # modes the training-trajectory test (tests/test_gpu_parity.py) is the arbiter of whether such gradients train alike.
 MASKED_FACTOR_F16_FWD = 2048.0
 MASKED_CAP = 1e-1
+# Round 5: the cap per case = 2 x the worst tensor seen there in (h,h) / (h,1) (profiles/r05_parity_summary.md), never above the
+# round figure: the bench's own regime and the two steps added this round are held to what was measured, not to 1e-1.  The
+# fixtures whose worst tensor is the 1-element alpha bias of a sharp net (lindisp + white: 8.1e-2) keep 1e-1 = 1.23 x the worst seen.
+MASKED_CAP_BY_TAG = {"bench regime": 2.5e-2, "bench regime 128+128": 1e-2, "c1 step": 5e-2, "consist step": 3.5e-2,
+                     "consistency": 1e-2, "train train_naive_sharp": 3e-2, "train train_kernel_sharp": 3e-2,
+                     "train train_kernel_default": 6.5e-2}
 MASKED_GATE = MASKED_FLOOR      # (name kept for the sections that only need the floor)
 
 
@@ -826,13 +833,14 @@ def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
     items += [(k, v, x64[k].grad, x32[k].grad) for k, v in gpu_extra.items() if v is not None and x64[k].grad is not None]
     for k, got, t64, t32 in items:
         e_gpu, e_f32 = util.relerr(got, t64), util.relerr(t32, t64)
-        excess = e_gpu / max(floor, min(MASKED_CAP, factor * e_f32))
+        PER_TENSOR.append((tag, k, e_gpu, e_f32))
+        excess = e_gpu / max(floor, min(MASKED_CAP_BY_TAG.get(tag, MASKED_CAP), factor * e_f32))
         if not excess <= worst_excess:          # NaN propagates
             worst_excess, worst = excess, (k, e_gpu, e_f32)
     ok = bool(worst_excess <= 1.0)
     RESULTS.append((f"{tag} MASKED grads vs float64 [{worst[0]}] (e_gpu / allowed)", worst_excess, 1.0, ok))
     print(f"{'ok  ' if ok else 'FAIL'} {tag} masked oracle: worst tensor {worst[0]}: e_gpu {worst[1]:.2e}, fp32 oracle {worst[2]:.2e}, "
-          f"allowed max({floor:.0e}, min({MASKED_CAP:.0e}, {factor:.0f} x fp32)) -> {worst_excess:.2f} of the allowance", flush=True)
+          f"allowed max({floor:.0e}, min({MASKED_CAP_BY_TAG.get(tag, MASKED_CAP):.1e}, {factor:.0f} x fp32)) -> {worst_excess:.2f} of the allowance", flush=True)
     # direction of every gradient tensor: cosine with the float64 oracle's.  A gate that does not scale with the mode's
     # element-wise allowance: whatever the operand width, a parameter tensor must be pushed the way float64 pushes it --
     # 0.999 with 16-bit operands in the backward, 0.999999 fp32-equivalent; tensors on which the fp32 oracle itself
@@ -1209,6 +1217,8 @@ def t_consist_step():
     for i in range(2):       # the two plain steps after which step_graph would capture
         tr2.step_graph(gb, i)
         tr3.step(gb, i)
+    for dst, src in ((tr3.flat.param, tr2.flat.param), (tr3.m, tr2.m), (tr3.v, tr2.v)):      # (one common state: two free-running
+        dst.copy_(src)                                                                        # trainers drift by Adam's sign-sensitive entries)
     l2 = tr2.step_graph(gb, START + 1, consist=consist)
     l3 = tr3.step(gb, START + 1, consist=consist)
     rep("step_graph(consist=...) falls back: loss", l2.reshape(1), l3.reshape(1), 2e-6)
