@@ -15,6 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 MODES = os.environ.get("MODES", "h,h;2,h;h,1;2,2").split(";")
+CASES = os.environ.get("CASES", "")      # substring filter on the case names (re-run one case)
 
 
 def collect():
@@ -29,6 +30,8 @@ def collect():
                          ("fixture: combined consistency step", D.t_consist_step),
                          ("bench regime 64+64 (N_rand 512)", lambda: D.t_train_bench_regime(512, 21, 64, 64)),
                          ("bench regime 128+128 (N_rand 256)", lambda: D.t_train_bench_regime(256, 21, 128, 128))):
+            if CASES and CASES not in name:
+                continue
             D.RESULTS.clear()
             D.PER_TENSOR.clear()
             print(f"== {mode} {name}", file=sys.stderr, flush=True)
@@ -43,6 +46,17 @@ def collect():
 
 def summarize(path):
     rows = [json.loads(l) for l in open(path) if l.startswith("{")]
+    last = {}
+    for i, r in enumerate(rows):      # a (mode, case) that was run again replaces its earlier lines
+        if "checks" in r:
+            last[(r["mode"], r["case"])] = i
+    keep, start = [], 0
+    for i, r in enumerate(rows):
+        if "checks" in r:
+            if last[(r["mode"], r["case"])] == i:
+                keep += rows[start:i + 1]
+            start = i + 1
+    rows = keep
     per = [r for r in rows if "tensor" in r]
     meta = [r for r in rows if "checks" in r]
     modes = []
