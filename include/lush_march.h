@@ -271,7 +271,11 @@ typedef struct {
                                       * instead of 32 bytes per point that the weight-gradient kernel re-encodes; pass the SAME variant word
                                       * to the forward and the backward of a pass */
 /* (bit 32 was round 3's LUSH_VARIANT_NO_OVERLAP -- lush_march_bwd no longer uses a second stream -- and is ignored) */
-#define LUSH_VARIANT_KERNEL_BITS 0xDF /* every bit above that selects a kernel; anything else in the word is ignored */
+#define LUSH_VARIANT_DW_SPLIT 128    /* weight gradients of a large pass: ONE job per workgroup on a slice sized by the job's cost per point (round 5
+                                      * experiment: one drain / flush / refill per workgroup instead of ten, but the launch then lasts as long as
+                                      * its slowest job -- 5.5 ms against the walk's 4.1 ms) instead of every workgroup walking
+                                      * all the jobs of its slice of the points */
+#define LUSH_VARIANT_KERNEL_BITS 0x1DF /* every bit above that selects a kernel; anything else in the word is ignored */
 
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Pack PLANS (ABI 7): the fragments and fp32 blocks of up to 8 (network, plane code) pairs as ONE launch.  A training step

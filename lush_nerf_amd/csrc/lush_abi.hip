@@ -564,7 +564,12 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
                 DwJob& j = job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], XV + n.HW, XV, g->b[l]);
                 with_pe(j, 0, XV, g->w[l], XV + n.HW, 0);
             } else {
-                job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], n.HW, 0, g->b[l]);
+                DwJob& j = job(dzp[l], n.HW, n.HW, H(l - 1), n.HW, 0, n.HW, g->w[l], n.HW, 0, g->b[l]);
+#ifdef LUSH_ABL_H0
+                if (l == 1) j.pe_mode = 9;
+#else
+                (void)j;
+#endif
             }
         }
         // feature + views layers: G = dZv^T h_{NL-1} and s = sum dZv into scratch (launch_feat_factor below turns them
@@ -599,9 +604,9 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
 #endif
         int splits = dw_splits(L.Ppad);
         G.per_job = 0;
+        int dev = 0, cus = 256;
+        if (current_device_cus(dev, cus) != 0) cus = 256;
         if (L.Ppad <= LUSH_DW_PERJOB_MAX_PTS) {
-            int dev = 0, cus = 256;
-            if (current_device_cus(dev, cus) != 0) cus = 256;
             long long sp = cus / G.n, most = L.Ppad / LUSH_DW_PERJOB_MIN_PTS;
             if (sp > most) sp = most;
             splits = sp < 1 ? 1 : (int)sp;
@@ -612,7 +617,60 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         G.Ppad = (int)L.Ppad;
         G.pts_per_split = (int)pps;
         G.scale = gscale;
-        rc = launch_dw_group(G, (int)((L.Ppad + pps - 1) / pps), planes_b, x_f16, z_f16, st);
+        int grid_x = (int)((L.Ppad + pps - 1) / pps);
+        if (!G.per_job && (variant & LUSH_VARIANT_DW_SPLIT) && cus >= 4 * G.n) {
+            // Variant (round 5 experiment, NOT the product's choice: measured slower, see include/lush_march.h): ONE job per
+            // workgroup.  A workgroup that walks the ten jobs of its slice drains its ring,
+            // flushes 40 K atomics, zeroes and refills the ring ten times -- the launch averaged 86 % of its own streaming rate.
+            // Here job j gets n_j of the chip's workgroups, n_j proportional to what a point of that job costs a workgroup, and
+            // slices of Ppad / n_j points: every workgroup is busy for the same time and has ONE boundary.  The grid is flat,
+            // sum n_j = CUs workgroups: every one is resident from the start.
+            // Cost per point, in bytes-equivalent (profiles/r05_dw_jobs.md: per-workgroup durations of a byte-proportional
+            // split, -DLUSH_CLOCK): the bytes the job streams (Z row + X row), at least 512 (a narrow job is latency-bound: three
+            // small stages in flight), plus DW_PE_COST for a block that is re-encoded from the 32-byte point record (the
+            // encoding's ~150 VALU instructions per stage run on four of the eight waves: 27 ns per point).
+#ifndef LUSH_DW_PE_COST
+#define LUSH_DW_PE_COST 860
+#endif
+            long long w[DW_MAX_JOBS], W = 0;
+            for (int i = 0; i < G.n; ++i) {
+                const DwJob& j = G.j[i];
+                const bool pe = j.X2 != nullptr && G.xd != nullptr && j.pe_mode != 0;
+                w[i] = 2LL * (j.n_out + j.k_in) + (j.X2 && !pe ? 2LL * j.k2_in : 0);
+                if (w[i] < 512) w[i] = 512;
+                if (pe) w[i] += 32 + LUSH_DW_PE_COST;
+                W += w[i];
+            }
+            int nj[DW_MAX_JOBS], used = 0;
+            double frac[DW_MAX_JOBS];
+            for (int i = 0; i < G.n; ++i) {
+                const double x = (double)cus * (double)w[i] / (double)W;
+                nj[i] = (int)x < 1 ? 1 : (int)x;
+                frac[i] = x - (int)x;
+                used += nj[i];
+            }
+            while (used < cus) {                       // the CUs left over go to the jobs that were rounded down the most
+                int b = 0;
+                for (int i = 1; i < G.n; ++i) if (frac[i] > frac[b]) b = i;
+                ++nj[b]; frac[b] = -1.0; ++used;
+            }
+            while (used > cus) {                       // (only when a narrow job was lifted to one workgroup)
+                int b = 0;
+                for (int i = 1; i < G.n; ++i) if (nj[i] > nj[b]) b = i;
+                --nj[b]; --used;
+            }
+            grid_x = 0;
+            for (int i = 0; i < G.n; ++i) {
+                long long p = (L.Ppad + nj[i] - 1) / nj[i];
+                p = (p + 31) / 32 * 32;
+                G.j[i].pps = (int)p;
+                G.first[i] = grid_x;
+                grid_x += (int)((L.Ppad + p - 1) / p);
+            }
+            G.first[G.n] = grid_x;
+            G.per_job = 2;
+        }
+        rc = launch_dw_group(G, grid_x, planes_b, x_f16, z_f16, st);
         if (rc) return rc;
         FeatFactorArgs F{};
         F.G = facG; F.s = facS;

@@ -19,9 +19,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LUSH_CLOCK_DECL(name) __device__ unsigned long long name[1024][4];
 #define LUSH_CLOCK_STAMP(name, k)                                                                      \
     do {                                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {                                \
-            name[blockIdx.x][2 * (k)] = __builtin_amdgcn_s_memtime();                                  \
-            name[blockIdx.x][2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();                          \
+        const unsigned lc_b = blockIdx.x + blockIdx.y * gridDim.x;                                     \
+        if (threadIdx.x == 0 && lc_b < 1024) {                                                         \
+            name[lc_b][2 * (k)] = __builtin_amdgcn_s_memtime();                                        \
+            name[lc_b][2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();                                \
         }                                                                                              \
     } while (0)
 #define LUSH_CLOCK_EXPORT(fn, name)                                                                    \

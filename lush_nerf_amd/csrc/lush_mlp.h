@@ -17,7 +17,7 @@ enum { NET_MAX_LAYERS = 8 };
 enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
 // kernel-variant bits of the C ABI (include/lush_march.h LUSH_VARIANT_*): 0 = the product's choice
 enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16,
-       LUSH_VARIANT_PE_ROWS = 64, LUSH_VARIANT_KERNEL_BITS = 0xDF };
+       LUSH_VARIANT_PE_ROWS = 64, LUSH_VARIANT_DW_SPLIT = 128, LUSH_VARIANT_KERNEL_BITS = 0x1DF };
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -221,6 +221,7 @@ struct DwJob {
     float* dW2; int ldw2; int wcol2; int n_out2;            // where the X2 columns go (usually dW / ldw again), rows < n_out2
     int pe_mode;                                            // DwGroup::xd given: X2 is computed, not read: 1 = gamma(x), 2 = gamma(viewdir)
     float* db;                                              // may be null
+    int pps;                                                // DwGroup::per_job == 2: points per slice of THIS job (multiple of 32)
 };
 enum { DW_MAX_JOBS = 12 };
 // A one-plane dZv row carries 8 more columns: the head gradients [d_r d_g d_b d_alpha] as a hi and a lo 16-bit plane
@@ -249,7 +250,12 @@ struct DwGroup {
     const float* scale;            // {loss scale, 1/scale} when Z is loss-scaled fp16, else null
     const float* xd;               // [Ppad][8] points and view directions (MlpFwdArgs::xd), or null: every X2 is read from its rows
     int per_job;                   // 1: grid (splits, n) -- a workgroup takes ONE job of its slice (launches whose slices alone leave
-                                   // CUs idle); 0: grid (splits) -- a workgroup takes every job of its slice in turn
+                                   // CUs idle); 0: grid (splits) -- a workgroup takes every job of its slice in turn;
+                                   // 2: grid (sum of the jobs' slice counts) -- ONE job per workgroup on a slice of DwJob::pps points;
+                                   // workgroup b belongs to the job j with first[j] <= b < first[j + 1].  The slice counts are
+                                   // proportional to the jobs' cost per point, so every workgroup is busy for the same time and
+                                   // drains / flushes / refills ONCE (a walking workgroup does it per job: ten times)
+    int first[DW_MAX_JOBS + 1];    // per_job == 2: prefix sums of the jobs' slice counts
 };
 
 }  // namespace lush

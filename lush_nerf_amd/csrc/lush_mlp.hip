@@ -1191,8 +1191,18 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
     const int wo = w >> 2, wi = w & 3;
     DPROF_T(t_kernel);
     LUSH_CLOCK_STAMP(lush_clock_dw, 0);
-    const long long p_begin = (long long)blockIdx.x * G.pts_per_split;
-    long long p_end = p_begin + G.pts_per_split;
+    // per_job == 2: a flat grid; this workgroup's job and slice from the prefix sums of the jobs' slice counts (a flat grid of
+    // exactly as many workgroups as CUs puts 32 of them on each XCD under the dispatcher's round-robin: as a (slices, jobs)
+    // grid with idle surplus workgroups some XCDs received 35 working ones, and the launch waited for their second round)
+    int my_job = (int)blockIdx.y, my_slice = (int)blockIdx.x;
+    if (G.per_job == 2) {
+        my_job = 0;
+        for (int j = 1; j < G.n; ++j) my_job = (int)blockIdx.x >= G.first[j] ? j : my_job;
+        my_slice = (int)blockIdx.x - G.first[my_job];
+    }
+    const int pps = G.per_job == 2 ? G.j[my_job].pps : G.pts_per_split;
+    const long long p_begin = (long long)my_slice * pps;
+    long long p_end = p_begin + pps;
     if (p_end > G.Ppad) p_end = G.Ppad;
     const int n_tiles = (int)((p_end - p_begin) / KT);
     if (n_tiles <= 0) return;
@@ -1209,7 +1219,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
 
     // (a small launch -- the 4 096-point noise net, configuration 1 -- has fewer slices than the chip has CUs and spent its time
     // walking 7-19 jobs in series, each a ring refill + a few tiles + 64 K atomics: 69 us for 0.4 GFLOP; one job per workgroup then)
-    const int j_begin = G.per_job ? (int)blockIdx.y : 0, j_end = G.per_job ? (int)blockIdx.y + 1 : G.n;
+    const int j_begin = G.per_job ? my_job : 0, j_end = G.per_job ? my_job + 1 : G.n;
     for (int jj = j_begin; jj < j_end; ++jj) {
         int jsel = G.per_job ? jj : (int)((blockIdx.x + (unsigned)jj) % (unsigned)G.n);
         jsel = __builtin_amdgcn_readfirstlane(jsel);
@@ -1252,6 +1262,9 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                 st.voff[i] = (unsigned)(((row % KT) * ld + gch * 8) * 2);
                 st.dst[i] = (unsigned)(op * DMA_OPER + 2 * rp * DMA_ROWB);
                 st.on[i] = gch * 8 < ncols;
+#ifdef LUSH_ABL_H0      // timing ablation only (wrong results): the job marked pe_mode 9 (layer 1: X = h_0) streams no X
+                if (op && A.pe_mode == 9) st.on[i] = false;
+#endif
             }
             st.src2 = nullptr; st.stride2 = 0; st.voff2 = 0; st.dst2 = 0; st.on2 = false;
             st.xd = nullptr; st.pe_last = 0; st.pe_row16 = 0; st.pe_dst = 0; st.pe_gch = 0; st.pe_nvalid = 0;
@@ -1659,7 +1672,7 @@ static int launch_dw_group_t(const DwGroup& g, int splits, hipStream_t s) {
     const size_t lds = (size_t)DMA_STAGES * GRP_STAGE + (g.xd ? 2 * GRP_PE_BYTES : 0);
     auto k = dw_group_kernel<XF16, ZF16, NS>;
     LUSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(splits, g.per_job ? g.n : 1), dim3(DW_THREADS2), lds, s, g);
+    hipLaunchKernelGGL(k, dim3(splits, g.per_job == 1 ? g.n : 1), dim3(DW_THREADS2), lds, s, g);
     LUSH_HIP(hipGetLastError());
     return 0;
 }

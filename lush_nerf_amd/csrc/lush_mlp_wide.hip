@@ -616,7 +616,11 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
             const bool feat = l == NL;
             const float* bl = btr + l * HW;                         // (the feature biases follow the trunk biases)
             rt.pre_on = l == N::SKIP;
+#ifdef LUSH_ABL_H0      // timing ablation only (wrong results): the h_0 rows go to one tile's worth of rows per workgroup (no HBM traffic)
+            rt.srows = reinterpret_cast<char*>(A.h0 + (long long)(l - 1) * A.h_stride + (l == 1 ? (long long)blockIdx.x * WD_MT + (wpt % WD_MT) : wpt) * HW);
+#else
             rt.srows = reinterpret_cast<char*>(A.h0 + (long long)(l - 1) * A.h_stride + wpt * HW);
+#endif
             // pass 0: set A accumulates rows 0..63; set B (last quarter of the previous layer) -> xin k-blocks 12..15
             rt.clamp = 0u; mset(l - 1, 6, false); rt.nextbias = bl + 64;
             WdPass<2, 4, WB_REG, 0, WB_PEX, WC_ACT, 2, 12, MASK, 2, 48, 0, (SPK > 0), HW>::run(cx, accA, accB, xin, xin, a0, peimg, row0, rt, alpha);

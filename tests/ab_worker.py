@@ -12,7 +12,7 @@ from lush_nerf_amd import ops, synth
 from oracle import lush_oracle as O       # (test infrastructure: ray packing of the synthetic batch only)
 
 dev = torch.device("cuda:0")
-R, S = 96, 100
+R, S = int(os.environ.get("LUSH_AB_R", 96)), int(os.environ.get("LUSH_AB_S", 100))
 pf, pb = ops.parse_planes(os.environ.get("LUSH_PLANES", "h,h"))
 variant = int(os.environ.get("LUSH_VARIANT", "0"))
 w = synth.all_weights(30, 3, sharp=True)

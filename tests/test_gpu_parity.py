@@ -996,6 +996,32 @@ def test_variants_agree(tmp_path, planes, variant):
     print(f"variant {variant} ({planes}): outputs differ by {worst.get('raw', 0.0):.1e}, gradients by {worst.get('grads', 0.0):.1e}")
 
 
+def test_weight_gradient_split_agrees_with_the_walk(tmp_path):
+    """Round 5 experiment kept as a variant: LUSH_VARIANT_DW_SPLIT runs the grouped weight-gradient launch of a large pass as ONE
+    job per workgroup on slices sized by the job's cost per point (DwGroup::per_job == 2) instead of every workgroup walking every
+    job of its slice.  Same sums, other order of the fp32 atomics: 294 912 points (2 304 rays x 128 samples), every gradient."""
+    import os, subprocess, sys
+    import numpy as np
+    from lush_nerf_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for var in (0, lib.VARIANT_DW_SPLIT):
+        env = dict(os.environ, LUSH_PLANES="h,h", LUSH_VARIANT=str(var), LUSH_AB_R="2304", LUSH_AB_S="128")
+        out = str(tmp_path / f"dw_{var}.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tests", "ab_worker.py"), out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    a, b = outs
+    worst = 0.0
+    for k in a.files:
+        if k == "dpts" or k == "raw":
+            assert np.array_equal(a[k], b[k]), k           # the forward and the chain are the same launches
+            continue
+        err = float(np.abs(a[k] - b[k]).max()) / max(float(np.abs(b[k]).max()), 1e-30)
+        worst = max(worst, err)
+        assert np.isfinite(a[k]).all() and err < 2e-5, (k, err)
+    print(f"one job per workgroup against the walk: parameter gradients within {worst:.1e}")
+
+
 def test_march_through_the_c_abi_alone(diag):
     """the march is ONE C-ABI call per direction.  This test drives include/lush_march.h with ctypes and torch
     memory only -- lush_pack_rays_fwd, lush_march_workspace_bytes, lush_march_fwd, lush_march_view, lush_march_bwd -- without

@@ -70,6 +70,8 @@ def stamps(fn_name):
     if rc != 0:
         raise SystemExit(f"{fn_name} failed")
     a = np.frombuffer(out, dtype=np.uint64).reshape(1024, 4).astype(np.float64)
+    if os.environ.get("DUMP_WG_US") and "dw" in fn_name:      # per-workgroup durations in launch order (x + gridDim.x * y): job balance
+        print(json.dumps({"dw_workgroup_us": [round(float(x), 1) for x in (a[:, 3] - a[:, 1]) / 100.0 if x > 0]}), flush=True)
     a = a[(a[:, 2] > a[:, 0]) & (a[:, 3] > a[:, 1])]
     mhz = (a[:, 2] - a[:, 0]) / (a[:, 3] - a[:, 1]) * 100.0
     us = (a[:, 3] - a[:, 1]) / 100.0
@@ -105,6 +107,9 @@ def run(label, fns, readers):
 print(json.dumps({"device": torch.cuda.get_device_name(0), "R": R, "S": S, "points": R * S, "mode": "h,h",
                   "method": "d(s_memtime)/d(s_memrealtime) x 100 MHz per workgroup, last launch after SECONDS of back-to-back launches",
                   "SECONDS": SECONDS}), flush=True)
+if os.environ.get("ONLY_DW"):
+    run("weight gradients", [weights], ["lush_debug_clock_dw"])
+    sys.exit(0)
 run("forward, stash on (training)", [fwd], ["lush_debug_clock_fwd"])
 run("forward, no stash (eval)", [fwd_nostash], ["lush_debug_clock_fwd"])
 run("dX chain", [chain], ["lush_debug_clock_chain"])
