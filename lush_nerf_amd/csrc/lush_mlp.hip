@@ -1021,6 +1021,38 @@ __device__ __forceinline__ void dw_pe_write(char* dst, const f32x4 c, int gch, i
     }
 }
 
+// The same for 4 columns [8 gch + 4 half, .. + 4): 8 bytes per lane, so that ALL eight waves share a tile's 32 rows x 64 columns
+// (16 lanes per row).  With four waves re-encoding 16 bytes per lane the other four idled behind them at the stage's barrier and
+// a workgroup spent 27 ns per point in its three re-encoding jobs (profiles/r05_dw_jobs.md) -- the jobs ran 1.3 x .. 1.9 x their
+// streaming time.
+__device__ __forceinline__ void dw_pe_write4(char* dst, const f32x4 c, int gch, int half, int nvalid) {
+    float hi[3], lo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rev_split(c[i], &hi[i], &lo[i]);
+#pragma unroll 1
+    for (int p = 0; p < 2; ++p) {
+        float v[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = 8 * gch + 4 * half + 2 * p + t;
+            const int q = j < 3 ? 0 : j - 3;
+            const int k = (q * 43) >> 8;                 // q / 6 for 0 <= q < 64
+            const int r = q - 6 * k;
+            const int i = j < 3 ? j : (r < 3 ? r : r - 3);
+            const float ci = i == 0 ? c[0] : (i == 1 ? c[1] : c[2]);
+            const float h_ = i == 0 ? hi[0] : (i == 1 ? hi[1] : hi[2]);
+            const float l_ = i == 0 ? lo[0] : (i == 1 ? lo[1] : lo[2]);
+            const float s = __builtin_ldexpf(1.0f, k);
+            const float rr = __builtin_amdgcn_fractf(h_ * s) + l_ * s;
+            const float sc = r < 3 ? __builtin_amdgcn_sinf(rr) : __builtin_amdgcn_cosf(rr);
+            v[t] = j < 3 ? ci : (j < nvalid ? sc : 0.f);
+        }
+        unsigned w_[1];
+        split_pair<1, DT_F16>(v[0], v[1], w_);
+        *reinterpret_cast<unsigned*>(dst + 4 * p) = w_[0];
+    }
+}
+
 // The streaming loop of one job, specialised on the number of 32-column X2 blocks (0: none, the side accumulator is the
 // bias alone).  Nothing in it depends on the job except through `st` (registers) and three wave-uniform flags.
 LUSH_CLOCK_DECL(lush_clock_dw)
@@ -1075,15 +1107,13 @@ __device__ __forceinline__ void grp_stream(const GrpStream& st, const char* tile
             if (st.on[i]) dma16s_stream(src, st.voff[i], __builtin_amdgcn_readfirstlane(base + st.dst[i]));
         src += st.stride;
         if constexpr (NV2 > 0) {
-            if (x2_wave) {
-                if (!PE || st.xd == nullptr) {
-                    if (st.on2) dma16s_stream(src2, st.voff2, __builtin_amdgcn_readfirstlane(base + st.dst2));
-                    src2 += st.stride2;
-                } else {
-                    // re-encode this tile's X2 rows from the quadruples in LDS (chunk ti / 16, loaded a chunk ahead)
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(coords + ((ti >> 4) & 1) * GRP_PE_BYTES + (ti & 15) * (KT_ * 16) + st.pe_row16);
-                    dw_pe_write(const_cast<char*>(tiles) + slot * GRP_STAGE + st.pe_dst, c, st.pe_gch, st.pe_nvalid);
-                }
+            if (PE && st.xd != nullptr) {
+                // re-encode this tile's X2 rows from the quadruples in LDS (chunk ti / 16, loaded a chunk ahead): every wave, 4 rows each
+                const f32x4 c = *reinterpret_cast<const f32x4*>(coords + ((ti >> 4) & 1) * GRP_PE_BYTES + (ti & 15) * (KT_ * 16) + st.pe_row16);
+                dw_pe_write4(const_cast<char*>(tiles) + slot * GRP_STAGE + st.pe_dst, c, st.pe_gch, lane & 1, st.pe_nvalid);
+            } else if (x2_wave) {
+                if (st.on2) dma16s_stream(src2, st.voff2, __builtin_amdgcn_readfirstlane(base + st.dst2));
+                src2 += st.stride2;
             }
             if (PE && st.xd != nullptr) {      // every wave: its 64 points of the NEXT chunk when a chunk begins
                 if ((ti & 15) == 0) pe_chunk(ti / 16 + 1);
@@ -1272,12 +1302,12 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                 st.xd = reinterpret_cast<const char*>(G.xd + p_begin * 8 + (A.pe_mode == 2 ? 4 : 0));
                 st.pe_last = (long long)G.Ppad - 1 - p_begin;
             }
-            if (x2_wave && st.xd != nullptr) {
-                const int row = 8 * w + (lane >> 3);
-                st.pe_gch = (lane & 7) ^ (((row >> 1) & 1) << 2);
+            if (st.xd != nullptr) {      // every wave: tile rows 4 w .. 4 w + 3, 16 lanes per row, 4 columns (8 bytes) per lane
+                const int row = 4 * w + (lane >> 4);
+                st.pe_gch = ((lane >> 1) & 7) ^ (((row >> 1) & 1) << 2);
                 st.pe_nvalid = A.k2_in;
                 st.pe_row16 = (unsigned)((row % KT) * 16);
-                st.pe_dst = (unsigned)(2 * DMA_OPER + 8 * w * GRP_X2_ROWB + lane * 16);
+                st.pe_dst = (unsigned)(2 * DMA_OPER + 4 * w * GRP_X2_ROWB + lane * 8);
             } else if (x2_wave) {
                 const int row = 8 * w + (lane >> 3);
                 const int gch = (lane & 7) ^ (((row >> 1) & 1) << 2);
