@@ -4,12 +4,12 @@
 # 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command (MI355X_MICROARCH.md: TCC slots)
 # Raw CSVs go to gpurun_out/ (scratch); profiles/summarize.py condenses them into profiles/<tag>_* and pmc_traffic.json.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --also= --extra= --no-traffic"
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --also= --extra= --no-traffic --sustained 0"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py $ARGS > $OUT/bench_$c.json 2> $OUT/pmc_$c.err

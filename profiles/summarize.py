@@ -17,6 +17,7 @@ _pf, _pb = str(bench.get("config", {}).get("planes_fwd", "?")), str(bench.get("c
 planes = ("h" if _pf.startswith("fp16") else _pf.replace("bf16x", "")) + "," + ("h" if _pb.startswith("fp16") else _pb.replace("bf16x", ""))
 # round 3: bench.py runs the timed steps twice (the timed region, then once more with HIP events around each kernel group)
 steps = bench.get("steps", 4) * (2 if "kernel_timing" in bench else 1) + bench.get("warmup", 2)
+steps += (bench.get("sustained") or {}).get("steps", 0)      # round 5: the >= 3 s of steps behind the timed region (collect.sh passes --sustained 0)
 
 GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
