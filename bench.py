@@ -200,7 +200,7 @@ def measure_traffic(argv_tail, kernel_key, progress=None, timeout=240):
 def traffic_child_args(a):
     """Arguments of the child runs measure_traffic profiles: the SAME workload as this run (sizes, micro-batch, mode, variant,
     library), two steps, nothing else timed."""
-    return ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--also=", "--extra=", "--no-kernel-pass", "--no-traffic", "--sustained", "0",
+    return ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--also=", "--extra=", "--no-kernel-pass", "--no-traffic", "--sustained", "0", "--no-dense",
             "--planes", a.planes, "--config", a.config, "--variant", str(a.variant), "--n-rand", str(a.n_rand), "--n-samples", str(a.n_samples),
             "--n-importance", str(a.n_importance), "--micro-batch", str(a.micro_batch)] + (["--so", a.so] if a.so else [])
 
@@ -256,6 +256,7 @@ def main():
                     "then carries its path under `library` -- a reported line has none")
     ap.add_argument("--sustained", type=float, default=3.0, help="seconds of back-to-back headline steps behind the timed region, reported "
                     "under `sustained` (0 to skip)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the comparison run with the backward over all the points (dense_backward)")
     ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
     ap.add_argument("--config", type=str, default="C2", choices=["C2", "C3", "C5"],
                     help="BASELINE config timed as the headline workload (C2 = the one the metric is quoted on)")
@@ -322,18 +323,21 @@ def main():
     def evals_per_step(n_rand, ns, ni, kernel=True):
         return n_rand * (M if kernel else 1) * (ns + (ns + ni if ni else 0))
 
-    def run_mode(pf, pb, steps, warmup, cfg=None, sustained_s=0.0):
+    def run_mode(pf, pb, steps, warmup, cfg=None, sustained_s=0.0, variant=None):
         """Time `steps` optimisation steps of one BASELINE config in one precision mode (max over ranks).  sustained_s > 0: after
         the timed region, the same steps back to back for at least that many seconds (the timed region of the driver's
         `--steps 20` is a third of a second on a chip that runs at its power cap: this is its steady-state neighbour)."""
         cfg = cfg or dict(n_rand=a.n_rand, ns=a.n_samples, ni=a.n_importance, kernel=True, micro=a.micro_batch)
         batches = make_batches(cfg["n_rand"])
-        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb, a.variant))
+        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb, a.variant if variant is None else variant))
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, cfg["ns"], cfg["ni"], kernel_start_iter=0,
                      allkernel_start_iter=1 << 30, distributed=True, micro_batch=cfg["micro"])
         for i in range(warmup):
             tr.step(batches[i % n_batches], i)
         sync()
+        # the share of MLP evaluation points whose backward ran (the live-point march, include/lush_march.h): the trainer counts
+        # them on the device (one small add per march, no synchronisation); read around the timed region
+        live0 = tr.live_counts()
         tr.allreduce_events = []
         t0 = time.perf_counter()
         for i in range(steps):
@@ -342,22 +346,16 @@ def main():
         dt = time.perf_counter() - t0
         ar_ms = sum(a_.elapsed_time(b_) for a_, b_ in tr.allreduce_events) / max(len(tr.allreduce_events), 1)
         tr.allreduce_events = None
-        sustained = None
-        if sustained_s > 0:
-            n_sus = max(steps, int(sustained_s / max(dt / steps, 1e-6)) + 1)
-            sync()
-            t1 = time.perf_counter()
-            for i in range(n_sus):
-                tr.step(batches[(warmup + steps + i) % n_batches], warmup + steps + i)
-            sync()
-            sdt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
-            sustained = {"steps": n_sus, "seconds": round(float(sdt.item()), 3), "ms_per_step": round(float(sdt.item()) / n_sus * 1e3, 3),
-                         "value": round(cfg["n_rand"] * world * n_sus / float(sdt.item()), 1), "unit": "rays/s",
-                         "note": "the headline configuration for >= %g s back to back, right behind the timed region" % sustained_s}
-        # kernel groups: the SAME steps once more with HIP events around each MLP kernel group on the launch stream.  The
-        # timed region above runs the march as one C-ABI call per direction (lush_march_fwd / lush_march_bwd); with the
-        # timer set the same kernels are launched group by group through the piecewise entry points.
+
+        def live_share(c0, c1):
+            fl, fa, cl, ca = (b_ - a_ for a_, b_ in zip(c0, c1))
+            return None if fa + ca == 0 else {"share": round((fl + cl) / (fa + ca), 4), "fine": round(fl / fa, 4) if fa else None,
+                                               "coarse": round(cl / ca, 4) if ca else None}
+        live = live_share(live0, tr.live_counts())
+        # kernel groups: the SAME steps once more with HIP events around each MLP kernel group on the launch stream, right behind the
+        # timed region (the model keeps training: the live share drifts, so the sustained run comes AFTER this pass).  The timed
+        # region above runs the march as one C-ABI call per direction (lush_march_fwd / lush_march_bwd); with the timer set the same
+        # kernels are launched group by group through the piecewise entry points.
         timer = ops.KernelTimer()
         if not a.no_kernel_pass:
             net.hooks.timer = timer
@@ -365,6 +363,23 @@ def main():
                 tr.step(batches[(warmup + i) % n_batches], warmup + steps + i)
             sync()
             net.hooks.timer = None
+        sustained = None
+        if sustained_s > 0:
+            n_sus = max(steps, int(sustained_s / max(dt / steps, 1e-6)) + 1)
+            live1 = tr.live_counts()
+            sync()
+            t1 = time.perf_counter()
+            for i in range(n_sus):
+                tr.step(batches[(warmup + steps + i) % n_batches], warmup + 2 * steps + i)
+            sync()
+            sdt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+            sustained = {"steps": n_sus, "seconds": round(float(sdt.item()), 3), "ms_per_step": round(float(sdt.item()) / n_sus * 1e3, 3),
+                         "value": round(cfg["n_rand"] * world * n_sus / float(sdt.item()), 1), "unit": "rays/s",
+                         "live_points": live_share(live1, tr.live_counts()),
+                         "note": "the headline configuration for >= %g s back to back, behind the timed region and the kernel-group pass: "
+                                 "the model keeps training on the synthetic targets, and with it the share of points whose density the ReLU "
+                                 "clamps -- whose backward the live-point march skips -- moves (live_points): read ms_per_step with it" % sustained_s}
         tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)       # the slowest rank's clock
         dt = float(tdt.item())
@@ -376,6 +391,7 @@ def main():
         summ = timer.summary()
         summ["_allreduce_ms"] = ar_ms
         summ["_sustained"] = sustained
+        summ["_live"] = live
         return dt, summ
 
     def run_c1(pf, pb, steps, warmup):
@@ -436,11 +452,12 @@ def main():
         sp = ops.nplanes(ops.stash_code(pf, pb))
         pbn = ops.nplanes(pb)
         ree = pf == ops.PLANES_F16 and pbn == 1 and not (a.variant & (lib.VARIANT_FWD_HALF | lib.VARIANT_FWD_512 | lib.VARIANT_PE_ROWS))
-        bytes_eval = {"mlp_fwd": sp * BYTES_X_STASH(sp, ree) + 16 + 44 / 64,
+        bytes_eval = {"mlp_fwd_all": 16 + 44 / 64,      # the forward over ALL the points of a live-point march: no stash, 16 bytes of raw output
+                      "mlp_fwd": sp * BYTES_X_STASH(sp, ree) + 16 + 44 / 64,
                       "mlp_bwd_chain": pbn * BYTES_DZ_STASH(pbn) + 288 + 16 + 32,
                       "mlp_bwd_weights": pbn * (BYTES_X_STASH(pbn, ree) + BYTES_DZ_STASH(pbn))}
         per_prod = lambda c: {1: 1, 2: 3, 3: 6}[ops.nplanes(c)]
-        mfma_mult = {"mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
+        mfma_mult = {"mlp_fwd_all": per_prod(pf), "mlp_fwd": per_prod(pf), "mlp_bwd_chain": per_prod(pb), "mlp_bwd_weights": per_prod(pb)}
         kern = {}
         for g, d in groups.items():
             if g not in bytes_eval or not isinstance(d, dict):
@@ -463,6 +480,16 @@ def main():
     dt, groups = run_mode(pf, pb, a.steps, a.warmup, sustained_s=a.sustained)
     progress(f"headline: {dt / a.steps * 1e3:.2f} ms/step" + (f"; sustained {groups['_sustained']['ms_per_step']:.2f} ms/step over "
                                                                f"{groups['_sustained']['seconds']:.1f} s" if groups.get("_sustained") else ""))
+    # the same configuration with the backward over ALL the points (LUSH_VARIANT_DENSE_BWD: rounds 1-4; what the step costs
+    # whatever the data): reported next to the headline whenever the headline's march is the live-point one
+    dense = None
+    if ops.live_backward(ops.Precision(pf, pb, a.variant), None) and not a.no_dense:
+        dsteps = max(4, a.steps // 2)
+        ddt, _ = run_mode(pf, pb, dsteps, 2, variant=a.variant | lib.VARIANT_DENSE_BWD)
+        dense = {"value": round(a.n_rand * world * dsteps / ddt, 1), "unit": "rays/s", "ms_per_step": round(ddt / dsteps * 1e3, 3), "steps": dsteps,
+                 "note": "LUSH_VARIANT_DENSE_BWD: the forward stashes every point and the backward runs over all of them (rounds 1-4): "
+                         "the step's cost independent of the data"}
+        progress(f"dense backward (all points): {dense['ms_per_step']:.2f} ms/step")
     others = []
     for m in [x for x in a.also.split(";") if x and x != a.planes]:
         qf, qb = ops.parse_planes(m)
@@ -508,7 +535,8 @@ def main():
             k = kern[dom]
             hbm_bound = k["frac_hbm"] >= k["frac_mfma_executed"]      # the roof this kernel would hit first
             traffic, traffic_source = None, None
-            dom_kernel = {"mlp_bwd_weights": "dw_group_kernel<true", "mlp_fwd": "mlp_wide_fwd_kernel", "mlp_bwd_chain": "mlp_wide_bwd_kernel"}.get(dom)
+            dom_kernel = {"mlp_bwd_weights": "dw_group_kernel<true", "mlp_fwd": "mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 1>",
+                          "mlp_fwd_all": "mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 0>", "mlp_bwd_chain": "mlp_wide_bwd_kernel"}.get(dom)
             if world == 1 and not a.no_traffic and dom_kernel and a.planes == "h,h":
                 tail = traffic_child_args(a)
                 torch.cuda.empty_cache()
@@ -560,7 +588,15 @@ def main():
                                    f"one RCCL all-reduce of the flat gradient (BASELINE config {a.config if world == 1 else '4' if a.config == 'C2' else a.config})",
                        "rays_per_gpu": a.n_rand, "marched_rays_per_gpu": a.n_rand * M, "mlp_evals_per_step": evals_step,
                        "planes_fwd": ("fp16x1" if pf == ops.PLANES_F16 else f"bf16x{pf}"), "planes_bwd": ("fp16x1 (loss-scaled)" if pb == ops.PLANES_F16 else f"bf16x{pb}"), "parallelism": f"dp{world}"},
+            # the share of MLP evaluation points whose d_raw row is non-zero in the timed steps: the live-point march (round 5) re-runs
+            # the forward with the stash and runs the gradient chain and the weight gradients on THOSE points only (a point whose
+            # density pre-activation the ReLU of raw2outputs clamps -- with raw_noise_std = 1 and a near-zero density, half of them --
+            # has an exactly zero gradient); null: the backward ran over all the points
+            "live_points": groups.get("_live"),
+            "dense_backward": dense,
             "step_tflops_algorithmic": round(flop_step * world * a.steps / dt / 1e12, 2),
+            # ... and what the kernels executed: one forward over all the points + (forward, chain, weight gradients) on the live ones
+            "step_tflops_executed": round((1 + 3 * (groups["_live"]["share"] if groups.get("_live") else 2 / 3)) / 3 * flop_step * world * a.steps / dt / 1e12, 2),
             # whole step against the survey's two ceilings: 3 x 1 186 816 FLOP per evaluation on the dense
             # bf16 MFMA peak, and the stash written once + read once at 4.35 KB per evaluation on the HBM peak
             "step_frac_mfma": round(flop_step * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -28,7 +28,9 @@ extern "C" {
 typedef void* lush_stream_t;
 
 const char* lush_last_error(void);
-int lush_abi_version(void);   /* 8 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
+int lush_abi_version(void);   /* 10 (round 5; 9: lush_rbk_mlp_bwd consumes its d_rvw rows; 10: the live-point entry points lush_live_compact /
+                             * lush_mlp_fwd_live / lush_mlp_bwd_*_live / lush_ray_grad_reduce_live, LUSH_VARIANT_DENSE_BWD,
+                             * LUSH_VIEW_LIVE_COUNTS; the march's one-fp16-plane backward runs on the live points).  Earlier: 8 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
                              * backward entry points write their outputs instead of accumulating; 7, round 4: the fused ray-level
                              * entry points lush_rbk_warp_ndc_* and lush_blur_mix_*, an explicit d_rvw row stride, and no second
                              * stream inside lush_march_bwd; 8: lush_pack_plan_run takes a buffer to clear, lush_adam_multi /
@@ -275,7 +277,9 @@ typedef struct {
                                       * experiment: one drain / flush / refill per workgroup instead of ten, but the launch then lasts as long as
                                       * its slowest job -- 5.5 ms against the walk's 4.1 ms) instead of every workgroup walking
                                       * all the jobs of its slice of the points */
-#define LUSH_VARIANT_KERNEL_BITS 0x1DF /* every bit above that selects a kernel; anything else in the word is ignored */
+#define LUSH_VARIANT_DENSE_BWD 256   /* lush_march_fwd / _bwd in the headline mode: stash every point in the forward and run the backward over all of them
+                                      * (rounds 1-4) instead of re-running the forward and the backward on the live points only (round 5) */
+#define LUSH_VARIANT_KERNEL_BITS 0x3DF /* every bit above that selects a kernel; anything else in the word is ignored */
 
 size_t lush_mlp_packed_bytes(int net, int planes);
 /* Pack PLANS (ABI 7): the fragments and fp32 blocks of up to 8 (network, plane code) pairs as ONE launch.  A training step
@@ -338,6 +342,31 @@ int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, cons
 int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays,
                          lush_stream_t stream);
 
+/* Live points (round 5).  A sample whose density pre-activation the ReLU of raw2outputs clamps (models/lushnerf.py:313:
+ * relu(raw[..., 3] + noise)) has alpha = 0, weight = 0 and d alpha / d raw = 0: its d_raw row is exactly zero and nothing flows
+ * back through its MLP evaluation -- with raw_noise_std = 1 and a density near zero, half of all the points.  The one-fp16-plane
+ * backward of the 8x256 net runs on the live points only: lush_live_compact lists them in grid order (live_idx [R*S] int32, the
+ * first cnt[0] entries valid), gathers their d_raw rows (draw_c [R*S][4], rows behind the list zeroed) and gives ray r the range
+ * [ray_start[r], ray_start[r+1]) of the list (ray_start [R+1]); cnt [2] int32 = {live points, R*S}; aux: lush_live_aux_bytes(R*S).
+ * lush_mlp_fwd_live re-runs the forward with the stash on the list (its i-th point = grid point live_idx[i]; no raw output),
+ * lush_mlp_bwd_chain_live / lush_mlp_bwd_weights_live are the launches of lush_mlp_bwd_chain / _weights on those cnt[0] points
+ * (the count is read on the device: nothing synchronises), lush_ray_grad_reduce_live folds the list's d(point) rows per ray.
+ * Zero rows only are skipped: the gradients are those of the launches over all the points (test: tests/test_gpu_parity.py). */
+size_t lush_live_aux_bytes(long long P);
+int lush_live_compact(const float* draw, int R, int S, int* live_idx, float* draw_c, int* ray_start, int* cnt, void* aux,
+                      lush_stream_t stream);
+int lush_mlp_fwd_live(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S, const void* packed,
+                      const lush_mlp_params* prm, void* stash, const int* live_idx, const int* live_cnt, int variant,
+                      lush_stream_t stream);
+int lush_mlp_bwd_chain_live(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                            const void* packed_b, const lush_mlp_params* prm, const float* draw_c, const void* stash, void* dstash,
+                            float* dpts, const int* live_idx, const int* live_cnt, int variant, lush_stream_t stream);
+int lush_mlp_bwd_weights_live(int net, int planes_f, int planes_b, int R, int S, const lush_mlp_params* prm, const float* draw_c,
+                              const void* stash, void* dstash, const lush_mlp_grads* grads, const int* live_cnt, int variant,
+                              lush_stream_t stream);
+int lush_ray_grad_reduce_live(const float* dpts, const float* z, const int* live_idx, const int* ray_start, int R, float* drays,
+                              lush_stream_t stream);
+
 /* ------------------------------------------------------ the march in one call
  * NeRFAll.render_rays_nonoise (models/lushnerf.py:481-583) -- z grid + jitter (:501-523), coarse MLP
  * (mlpforward :234-266), raw2outputs (:296-352), sample_pdf + sort (:544-549, utils/run_lushnerf_helpers.py:566-609),
@@ -379,6 +408,7 @@ size_t lush_march_workspace_bytes(const lush_march_cfg* cfg);     /* 0 = bad con
 #define LUSH_VIEW_Z_COARSE 3      /* z_vals of the coarse pass [R][S] */
 #define LUSH_VIEW_STASH_COARSE 4  /* activation stash of the coarse / fine MLP evaluation (tests: lush_debug_stash_layout) */
 #define LUSH_VIEW_STASH_FINE 5
+#define LUSH_VIEW_LIVE_COUNTS 6   /* int32 [4] after lush_march_bwd of a live-point configuration: {live, all} points of the fine pass (or the only pass), then of the coarse pass */
 int lush_march_view(const lush_march_cfg* cfg, int which, size_t* offset, size_t* bytes);
 /* rays [R][11]; flags: the numerical-fault word (may be NULL).  fine may be NULL when same_net or N_importance == 0. */
 int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_params* coarse, const lush_mlp_params* fine,

@@ -412,8 +412,16 @@ int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
     return 0;
 }
 
-int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
-                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash, int variant, lush_stream_t stream) {
+// a live-point launch is the 64-points-per-wave kernels' (one fp16 plane on the 8x256 net, no older-kernel variant bit)
+static bool live_kernels(int net, int planes_f, int planes_b, int variant) {
+    const int older = LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_BWD_HALF | LUSH_VARIANT_BWD_512 | LUSH_VARIANT_PE_ROWS |
+                      LUSH_VARIANT_HEAD_KERNEL | LUSH_VARIANT_DW_SPLIT;
+    return net == 0 && planes_f == PLANES_F16 && planes_b == PLANES_F16 && !(variant & older);
+}
+
+static int mlp_fwd_impl(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
+                        const void* packed, const lush_mlp_params* prm, float* raw, void* stash, int variant, lush_stream_t stream,
+                        const int* live_idx, const int* live_cnt) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_fwd: bad net");
     if (!code_ok(planes)) return set_error("lush_mlp_fwd: planes must be 1..3 or 17 (one fp16 plane)");
@@ -448,9 +456,24 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
     a.feat = (__bf16*)(b + L.feat);
     a.hv = (__bf16*)(b + L.hv);
     a.plane_pe = L.Ppad * PE_ROW; a.plane_h = L.Ppad * n.HW; a.plane_hv = L.Ppad * n.HV;
+    a.live_idx = live_idx; a.live_cnt = live_cnt;
+    if (live_idx || live_cnt) {
+        if (!live_idx || !live_cnt) return set_error("lush_mlp_fwd_live: the list and its count come together");
+        if (!live_kernels(net, planes, stash_planes == 1 ? PLANES_F16 : 0, variant) || !chain) return set_error("lush_mlp_fwd_live: one fp16 plane with the stash, 8x256 net, the product's kernels only");
+    }
     if (chain) return launch_mlp_chain_fwd(net, planes, a, variant, (hipStream_t)stream);
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     return launch_mlp_fwd(net, planes, a, grid, (hipStream_t)stream);
+}
+
+int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
+                 const void* packed, const lush_mlp_params* prm, float* raw, void* stash, int variant, lush_stream_t stream) {
+    return mlp_fwd_impl(net, planes, stash_planes, rays, z, R, S, packed, prm, raw, stash, variant, stream, nullptr, nullptr);
+}
+int lush_mlp_fwd_live(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S, const void* packed,
+                      const lush_mlp_params* prm, void* stash, const int* live_idx, const int* live_cnt, int variant, lush_stream_t stream) {
+    if (!live_idx || !live_cnt) return set_error("lush_mlp_fwd_live: live_idx and live_cnt are required");
+    return mlp_fwd_impl(net, planes, stash_planes, rays, z, R, S, packed, prm, nullptr, stash, variant, stream, live_idx, live_cnt);
 }
 
 // prepared != 0: the caller's lush_composite_bwd already computed the loss scale into the dstash header and zeroed the
@@ -458,9 +481,10 @@ int lush_mlp_fwd(int net, int planes, int stash_planes, const float* rays, const
 static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                         const void* packed_b, const lush_mlp_params* prm, const float* draw, const void* stash,
                         void* dstash, const lush_mlp_grads* g, float* dpts, int variant, lush_stream_t stream, int do_chain,
-                        int do_weights, int prepared = 0) {
+                        int do_weights, int prepared = 0, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
+    if (live_cnt && !live_kernels(net, planes_f, planes_b, variant)) return set_error("lush_mlp_bwd (live points): one fp16 plane each way, 8x256 net, the product's kernels only");
     const bool x_f16 = planes_f == PLANES_F16;     // the stash was written by the fp16 forward
     if (x_f16) planes_f = 1;
     const bool z_f16 = planes_b == PLANES_F16;     // loss-scaled fp16 gradient chain (one plane)
@@ -494,6 +518,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
     a.dzv = (__bf16*)(db + D.dzv);
     a.plane_h = plane_h; a.plane_hv = plane_hv;
     a.dpts = dpts;
+    a.live_idx = live_idx; a.live_cnt = live_cnt;
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
     int rc = 0;
     bool fac_zeroed = false;       // the feature-factor scratch of the grouped weight gradients was zeroed by the loss-scale launch
@@ -604,9 +629,10 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
 #endif
         int splits = dw_splits(L.Ppad);
         G.per_job = 0;
+        G.live_cnt = live_cnt;
         int dev = 0, cus = 256;
         if (current_device_cus(dev, cus) != 0) cus = 256;
-        if (L.Ppad <= LUSH_DW_PERJOB_MAX_PTS) {
+        if (L.Ppad <= LUSH_DW_PERJOB_MAX_PTS && !live_cnt) {      // (a live-point launch walks: its size is known on the device only)
             long long sp = cus / G.n, most = L.Ppad / LUSH_DW_PERJOB_MIN_PTS;
             if (sp > most) sp = most;
             splits = sp < 1 ? 1 : (int)sp;
@@ -618,7 +644,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         G.pts_per_split = (int)pps;
         G.scale = gscale;
         int grid_x = (int)((L.Ppad + pps - 1) / pps);
-        if (!G.per_job && (variant & LUSH_VARIANT_DW_SPLIT) && cus >= 4 * G.n) {
+        if (!G.per_job && !live_cnt && (variant & LUSH_VARIANT_DW_SPLIT) && cus >= 4 * G.n) {
             // Variant (round 5 experiment, NOT the product's choice: measured slower, see include/lush_march.h): ONE job per
             // workgroup.  A workgroup that walks the ten jobs of its slice drains its ring,
             // flushes 40 K atomics, zeroes and refills the ring ten times -- the launch averaged 86 % of its own streaming rate.
@@ -724,21 +750,38 @@ int lush_mlp_bwd_weights(int net, int planes_f, int planes_b, int R, int S, cons
     return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, prm, draw, stash, dstash, g, nullptr, variant, stream, 0, 1);
 }
 
+int lush_mlp_bwd_chain_live(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
+                            const void* packed_b, const lush_mlp_params* prm, const float* draw_c, const void* stash, void* dstash,
+                            float* dpts, const int* live_idx, const int* live_cnt, int variant, lush_stream_t stream) {
+    if (!live_idx || !live_cnt) return set_error("lush_mlp_bwd_chain_live: live_idx and live_cnt are required");
+    // (the loss scale is taken over all R*S rows of draw_c: lush_live_compact zeroed the rows behind the list)
+    return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, prm, draw_c, stash, dstash, nullptr, dpts, variant, stream, 1, 0, 0,
+                        live_idx, live_cnt);
+}
+int lush_mlp_bwd_weights_live(int net, int planes_f, int planes_b, int R, int S, const lush_mlp_params* prm, const float* draw_c,
+                              const void* stash, void* dstash, const lush_mlp_grads* g, const int* live_cnt, int variant,
+                              lush_stream_t stream) {
+    if (!live_cnt) return set_error("lush_mlp_bwd_weights_live: live_cnt is required");
+    return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, prm, draw_c, stash, dstash, g, nullptr, variant, stream, 0, 1, 0,
+                        nullptr, live_cnt);
+}
+
 }  // extern "C"
 
 // ---- for lush_march_bwd (lush_march_abi.hip), whose compositing backward has already prepared the dstash header ----
 namespace lush {
 int mlp_bwd_chain_prepared(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                            const void* packed_b, const void* prm, const float* draw, const void* stash,
-                           void* dstash, float* dpts, int variant, void* stream) {
+                           void* dstash, float* dpts, int variant, void* stream, const int* live_idx, const int* live_cnt) {
     return mlp_bwd_impl(net, planes_f, planes_b, rays, z, R, S, packed_b, (const lush_mlp_params*)prm, draw, stash, dstash, nullptr, dpts,
-                        variant, (lush_stream_t)stream, 1, 0, 1);
+                        variant, (lush_stream_t)stream, 1, 0, 1, live_idx, live_cnt);
 }
 int mlp_bwd_weights_prepared(int net, int planes_f, int planes_b, int R, int S, const void* prm, const float* draw,
-                             const void* stash, void* dstash, const void* g, int variant, void* stream) {
+                             const void* stash, void* dstash, const void* g, int variant, void* stream, const int* live_cnt) {
     return mlp_bwd_impl(net, planes_f, planes_b, nullptr, nullptr, R, S, nullptr, (const lush_mlp_params*)prm, draw, stash, dstash,
-                        (const lush_mlp_grads*)g, nullptr, variant, (lush_stream_t)stream, 0, 1, 1);
+                        (const lush_mlp_grads*)g, nullptr, variant, (lush_stream_t)stream, 0, 1, 1, nullptr, live_cnt);
 }
+bool mlp_live_kernels(int net, int planes_f, int planes_b, int variant) { return live_kernels(net, planes_f, planes_b, variant); }
 // where the header of a dstash holds {scale, 1/scale, work, work} and the scratch the weight-gradient launch accumulates into
 bool mlp_dstash_header(int net, int planes_b, long long P, void* dstash, float** scale4, float** zero_buf, long long* zero_n) {
     NetInfo n;

@@ -47,9 +47,10 @@ inline int kernel_lds_once(KernelOnce& once, int dev, const void* kernel, size_t
 // depend on include/lush_march.h)
 int mlp_bwd_chain_prepared(int net, int planes_f, int planes_b, const float* rays, const float* z, int R, int S,
                            const void* packed_b, const void* prm, const float* draw, const void* stash,
-                           void* dstash, float* dpts, int variant, void* stream);
+                           void* dstash, float* dpts, int variant, void* stream, const int* live_idx = nullptr, const int* live_cnt = nullptr);
 int mlp_bwd_weights_prepared(int net, int planes_f, int planes_b, int R, int S, const void* prm, const float* draw,
-                             const void* stash, void* dstash, const void* g, int variant, void* stream);
+                             const void* stash, void* dstash, const void* g, int variant, void* stream, const int* live_cnt = nullptr);
+bool mlp_live_kernels(int net, int planes_f, int planes_b, int variant);      // the kernels of this mode take live-point launches
 bool mlp_dstash_header(int net, int planes_b, long long P, void* dstash, float** scale4, float** zero_buf, long long* zero_n);
 
 // lush_mlp.hip

@@ -1416,6 +1416,109 @@ __global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void ray_grad_reduce_kernel(co
     if (lane < 9) atomicAdd(drays + (long long)ray * 11 + (lane < 6 ? lane : lane + 2), mine);
 }
 
+// ------------------------------------------------------- live points (round 5)
+// A sample whose density pre-activation is clamped by the ReLU of raw2outputs (models/lushnerf.py:313: relu(raw + noise)) has
+// alpha = 0, weight = 0 and d alpha / d raw = 0: its d_raw row is EXACTLY zero and nothing flows back through its MLP
+// evaluation.  With raw_noise_std = 1 (every shipped config) and a density near zero that is half of all the points.  The
+// backward therefore runs on the LIVE points only: this compaction lists them (in grid order: deterministic), gathers their
+// d_raw rows and gives every ray its range of the list; the forward is re-run with the stash on that list, the gradient
+// chain and the weight gradients see a dense launch of `cnt` points.  Sums skip exact zeros only: same gradients.
+constexpr int LIVE_BLK = 1024;
+__device__ __forceinline__ bool live_row(const float4 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f; }      // (NaN counts as live)
+
+__global__ __launch_bounds__(256) void live_count_kernel(const float4* __restrict__ draw, int P, int* __restrict__ blk) {
+    const int p0 = blockIdx.x * LIVE_BLK + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (p0 + k < P) c += live_row(draw[p0 + k]) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    __shared__ int sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+// one workgroup: exclusive scan of the block counts in place; cnt[0] = the number of live points, cnt[1] = P
+__global__ __launch_bounds__(1024) void live_scan_kernel(int* __restrict__ blk, int nblk, int P, int* __restrict__ cnt) {
+    __shared__ int sm[1024];
+    int carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int i = b0 + (int)threadIdx.x;
+        const int v = i < nblk ? blk[i] : 0;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int a = (int)threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+            __syncthreads();
+            sm[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < nblk) blk[i] = carry + sm[threadIdx.x] - v;
+        const int tot = sm[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { cnt[0] = carry; cnt[1] = P; }
+}
+__global__ __launch_bounds__(256) void live_scatter_kernel(const float4* __restrict__ draw, int P, int S, int R, const int* __restrict__ blk_off,
+                                                          const int* __restrict__ cnt, int* __restrict__ live_idx,
+                                                          float4* __restrict__ draw_c, int* __restrict__ ray_start) {
+    const int p0 = blockIdx.x * LIVE_BLK + threadIdx.x * 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 v[4];
+    int f[4], c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = p0 + k < P ? draw[p0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        f[k] = live_row(v[k]) ? 1 : 0;
+        c += f[k];
+    }
+    int incl = c;                                   // inclusive scan over the workgroup's 256 threads
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(incl, o, 64); if (lane >= o) incl += a; }
+    __shared__ int sm[4];
+    if (lane == 63) sm[w] = incl;
+    __syncthreads();
+    int base = blk_off[blockIdx.x];
+    for (int i = 0; i < w; ++i) base += sm[i];
+    int pos = base + incl - c;
+    const int total = cnt[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        if (p < P) {
+            if (p % S == 0) ray_start[p / S] = pos;          // where ray p / S begins in the list
+            if (f[k]) { live_idx[pos] = p; draw_c[pos] = v[k]; ++pos; }
+            if (p >= total) draw_c[p] = make_float4(0.f, 0.f, 0.f, 0.f);      // rows behind the list: zero (tile padding, the loss scale's pass)
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ray_start[R] = total;
+}
+
+// d rays from the d(point) rows of a live-point launch: ray r owns rows [ray_start[r], ray_start[r + 1]) of the list
+__global__ __launch_bounds__(RAYS_PER_BLOCK * 64) void ray_grad_reduce_live_kernel(const float* __restrict__ dpts, const float* __restrict__ z,
+        const int* __restrict__ live_idx, const int* __restrict__ ray_start, int R, float* __restrict__ drays) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const int b = ray_start[ray], e = ray_start[ray + 1];
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = b + lane; i < e; i += 64) {
+        const float4 gx = *reinterpret_cast<const float4*>(dpts + (long long)i * 8);
+        const float4 gv = *reinterpret_cast<const float4*>(dpts + (long long)i * 8 + 4);
+        const float zz = z[live_idx[i]];
+        a[0] += gx.x; a[1] += gx.y; a[2] += gx.z;
+        a[3] += gx.x * zz; a[4] += gx.y * zz; a[5] += gx.z * zz;
+        a[6] += gv.x; a[7] += gv.y; a[8] += gv.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = wave_sum(a[i]);
+    float mine = a[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) mine = lane == i ? a[i] : mine;
+    if (lane < 9) atomicAdd(drays + (long long)ray * 11 + (lane < 6 ? lane : lane + 2), mine);
+}
+
 // ------------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
@@ -1525,7 +1628,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" {
 
 const char* lush_last_error(void) { return g_err.c_str(); }
-int lush_abi_version(void) { return 9; }
+int lush_abi_version(void) { return 10; }
 
 int lush_zgrid(const float* rays, int R, int S, int lindisp, const float* t_rand, float* z, lush_stream_t st) {
     if (R <= 0 || S <= 0) return set_error("lush_zgrid: empty");
@@ -1805,6 +1908,30 @@ int lush_draws_state(unsigned long long seed, unsigned long long offset, const v
 
 int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float* drays, lush_stream_t st) {
     hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3(cdiv(R, RAYS_PER_BLOCK)), dim3(RAYS_PER_BLOCK * 64), 0, S_(st), dpts, z, R, S, drays);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+size_t lush_live_aux_bytes(long long P) { return P > 0 ? (size_t)((P + LIVE_BLK - 1) / LIVE_BLK) * sizeof(int) : 0; }
+
+int lush_live_compact(const float* draw, int R, int S, int* live_idx, float* draw_c, int* ray_start, int* cnt, void* aux, lush_stream_t st) {
+    const long long P = (long long)R * S;
+    if (R <= 0 || S <= 0 || P >= (1LL << 27)) return set_error("lush_live_compact: 1 .. 2^27 - 1 points");
+    if (!draw || !live_idx || !draw_c || !ray_start || !cnt || !aux) return set_error("lush_live_compact: every buffer is required");
+    const int nblk = (int)((P + LIVE_BLK - 1) / LIVE_BLK);
+    int* blk = (int*)aux;
+    hipLaunchKernelGGL(live_count_kernel, dim3(nblk), dim3(256), 0, S_(st), (const float4*)draw, (int)P, blk);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(live_scan_kernel, dim3(1), dim3(1024), 0, S_(st), blk, nblk, (int)P, cnt);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(live_scatter_kernel, dim3(nblk), dim3(256), 0, S_(st), (const float4*)draw, (int)P, S, R, (const int*)blk, (const int*)cnt,
+                       live_idx, (float4*)draw_c, ray_start);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int lush_ray_grad_reduce_live(const float* dpts, const float* z, const int* live_idx, const int* ray_start, int R, float* drays, lush_stream_t st) {
+    hipLaunchKernelGGL(ray_grad_reduce_live_kernel, dim3(cdiv(R, RAYS_PER_BLOCK)), dim3(RAYS_PER_BLOCK * 64), 0, S_(st), dpts, z, live_idx, ray_start, R, drays);
     CHECK_LAUNCH();
     return 0;
 }

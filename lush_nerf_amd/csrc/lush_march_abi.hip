@@ -23,9 +23,19 @@ struct Layout {
     size_t zf, zs, wf, rawf, pkf, stashf;        // fine pass (N_importance > 0)
     size_t pkbc, pkbf;                           // packed weights of the backward when its plane code differs
     size_t draw, dstash, dpts;                   // backward scratch, shared by the passes (they run one after the other)
+    size_t live_idx, draw_c, ray_start, live_cnt, live_aux;     // live-point backward (round 5): the list, its d_raw rows, per-ray ranges, count, scan scratch
     size_t total;
     size_t stashc_bytes, stashf_bytes;
+    bool live;                                   // the backward re-runs the forward on the live points (the forward call keeps no stash)
 };
+
+// The headline mode's march (one fp16 plane each way, the 64-points-per-wave kernels) keeps NO stash in its forward: the
+// backward lists the points whose d_raw row is non-zero, re-runs the forward with the stash on that list and chains / forms the
+// weight gradients on it (include/lush_march.h "Live points").  LUSH_VARIANT_DENSE_BWD keeps the rounds 1-4 form.
+inline bool live_mode(const lush_march_cfg* c) {
+    return c->planes_bwd != 0 && !(c->variant & LUSH_VARIANT_DENSE_BWD) &&
+           mlp_live_kernels(0, c->planes_fwd, c->planes_bwd, c->variant & LUSH_VARIANT_KERNEL_BITS & ~LUSH_VARIANT_DENSE_BWD);
+}
 
 bool layout(const lush_march_cfg* c, Layout& L) {
     if (!c || c->R <= 0 || c->N_samples < 2 || c->N_importance < 0) return false;
@@ -52,6 +62,14 @@ bool layout(const lush_march_cfg* c, Layout& L) {
         L.draw = take(Pmax * 16);
         L.dstash = take(lush_mlp_dstash_bytes(0, pb, Pmax));
         L.dpts = take(Pmax * 32);
+        L.live = live_mode(c);
+        if (L.live) {
+            L.live_idx = take(Pmax * 4);
+            L.draw_c = take(Pmax * 16);
+            L.ray_start = take(((size_t)R + 1) * 4);
+            L.live_cnt = take(256);
+            L.live_aux = take(lush_live_aux_bytes(Pmax));
+        }
     }
     L.total = off;
     return true;
@@ -80,6 +98,9 @@ int lush_march_view(const lush_march_cfg* cfg, int which, size_t* offset, size_t
         case LUSH_VIEW_STASH_FINE:
             if (!fine) return set_error("lush_march_view: no fine pass");
             *offset = L.stashf; *bytes = L.stashf_bytes; return 0;
+        case LUSH_VIEW_LIVE_COUNTS:
+            if (!L.live) return set_error("lush_march_view: this configuration's backward runs over all the points");
+            *offset = L.live_cnt; *bytes = 16; return 0;
         default: return set_error("lush_march_view: unknown view");
     }
 }
@@ -96,7 +117,8 @@ int lush_march_fwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     if (two && (!out->rgb0 || !out->depth0 || !out->acc0 || !out->density0 || !out->z_std)) return set_error("lush_march_fwd: the coarse outputs and z_std are required when N_importance > 0");
     const lush_mlp_params* pfine = cfg->same_net ? coarse : fine;
     char* w = (char*)workspace;
-    const int pf = cfg->planes_fwd, sc = stash_code(pf, cfg->planes_bwd), var = cfg->variant;
+    const int pf = cfg->planes_fwd, var = cfg->variant;
+    const int sc = L.live ? 0 : stash_code(pf, cfg->planes_bwd);      // live-point backward: the forward keeps raw, z, weights only
     const float* t_rand = draws && cfg->perturb > 0.f ? draws->t_rand : nullptr;
     const float* noise_c = draws && cfg->raw_noise_std > 0.f ? draws->noise_c : nullptr;
     const float* u = draws && cfg->perturb > 0.f ? draws->u : nullptr;
@@ -159,7 +181,7 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     // fragments of the backward's plane code: the caller's (cfg->packed_*), else the forward's copy in the workspace when the
     // codes agree, else packed here
     auto chain = [&](const lush_mlp_params* prm, size_t zoff, size_t rawoff, size_t stashoff, const void* pk_ready, size_t pkboff, bool repack,
-                     int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc) -> int {
+                     int Sp, const float* noise, const float* g_rgb, const float* g_depth, const float* g_acc, const void* pk_fwd, int slot) -> int {
         const float* z = (const float*)(w + zoff);
         // the compositing backward also leaves the per-workgroup maxima of |d_raw| (in the d(point) array, which the chain only
         // writes afterwards) for the fp16 chain's loss scale, zeroes the weight-gradient scratch and, in the march's first pass,
@@ -184,11 +206,27 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
             }
             pk = w + pkboff;
         }
+        if (L.live) {
+            // the live points of this pass: list, gathered d_raw rows, per-ray ranges (three small launches); the forward once
+            // more, WITH the stash, on the list; then chain and d(ray) on `cnt` points (read on the device)
+            int* lidx = (int*)(w + L.live_idx);
+            int* lcnt = (int*)(w + L.live_cnt) + 2 * slot;      // {live points, points} of the fine (slot 0) / coarse (slot 1) pass: LUSH_VIEW_LIVE_COUNTS
+            float* draw_c = (float*)(w + L.draw_c);
+            rc = lush_live_compact(x.draw, R, Sp, lidx, draw_c, (int*)(w + L.ray_start), lcnt, w + L.live_aux, st);
+            if (rc) return rc;
+            const void* pkf = pk_fwd;            // forward fragments: the caller's buffer or the forward call's copy in the workspace
+            rc = lush_mlp_fwd_live(0, pf, sc, rays, z, R, Sp, pkf, prm, w + stashoff, lidx, lcnt, var, st);
+            if (rc) return rc;
+            rc = mlp_bwd_chain_prepared(0, sc, pb, rays, z, R, Sp, pk, prm, draw_c, w + stashoff, x.dstash, x.dpts, var, st, lidx, lcnt);
+            if (rc) return rc;
+            return lush_ray_grad_reduce_live(x.dpts, z, lidx, (const int*)(w + L.ray_start), R, drays, st);
+        }
         rc = mlp_bwd_chain_prepared(0, sc, pb, rays, z, R, Sp, pk, prm, x.draw, w + stashoff, x.dstash, x.dpts, var, st);
         if (rc) return rc;
         return lush_ray_grad_reduce(x.dpts, z, R, Sp, drays, st);
     };
-    auto weights = [&](const lush_mlp_params* prm, const lush_mlp_grads* gr, size_t stashoff, int Sp) -> int {
+    auto weights = [&](const lush_mlp_params* prm, const lush_mlp_grads* gr, size_t stashoff, int Sp, int slot) -> int {
+        if (L.live) return mlp_bwd_weights_prepared(0, sc, pb, R, Sp, prm, (const float*)(w + L.draw_c), w + stashoff, x.dstash, gr, var, st, (const int*)(w + L.live_cnt) + 2 * slot);
         return mlp_bwd_weights_prepared(0, sc, pb, R, Sp, prm, x.draw, w + stashoff, x.dstash, gr, var, st);
     };
     const bool any_main = g->rgb || g->depth || g->acc;
@@ -201,17 +239,18 @@ int lush_march_bwd(const lush_march_cfg* cfg, const float* rays, const lush_mlp_
     const void* ready_c = pb == pf ? cfg->packed_coarse : cfg->packed_bwd_coarse;
     const void* ready_f = cfg->same_net ? ready_c : (pb == pf ? cfg->packed_fine : cfg->packed_bwd_fine);
     if (two && any_main) {
-        rc = chain(pfine, L.zf, L.rawf, L.stashf, ready_f, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc);
+        rc = chain(pfine, L.zf, L.rawf, L.stashf, ready_f, L.pkbf, pb != pf, Sf, noise_f, g->rgb, g->depth, g->acc,
+                   cfg->same_net ? (cfg->packed_coarse ? cfg->packed_coarse : (const void*)(w + L.pkc)) : (cfg->packed_fine ? cfg->packed_fine : (const void*)(w + L.pkf)), 0);
         if (rc) return rc;
         packed_b_c = cfg->same_net && pb != pf;     // the shared net's backward fragments are packed now
-        rc = weights(pfine, gfine, L.stashf, Sf);
+        rc = weights(pfine, gfine, L.stashf, Sf, 0);
         if (rc) return rc;
     }
     if (any_c) {
         rc = chain(coarse, L.zc, L.rawc, L.stashc, ready_c, L.pkbc, pb != pf && !packed_b_c, S, noise_c, two ? g->rgb0 : g->rgb,
-                   two ? g->depth0 : g->depth, two ? g->acc0 : g->acc);
+                   two ? g->depth0 : g->depth, two ? g->acc0 : g->acc, cfg->packed_coarse ? cfg->packed_coarse : (const void*)(w + L.pkc), two ? 1 : 0);
         if (rc) return rc;
-        rc = weights(coarse, g_coarse, L.stashc, S);
+        rc = weights(coarse, g_coarse, L.stashc, S, two ? 1 : 0);
     }
     return rc;
 }

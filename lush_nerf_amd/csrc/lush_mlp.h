@@ -17,7 +17,7 @@ enum { NET_MAX_LAYERS = 8 };
 enum { PLANES_F16 = 17 };   // plane code: 1..3 = bf16 planes, 17 = ONE fp16 plane (forward of the NeRF nets)
 // kernel-variant bits of the C ABI (include/lush_march.h LUSH_VARIANT_*): 0 = the product's choice
 enum { LUSH_VARIANT_FWD_HALF = 1, LUSH_VARIANT_FWD_512 = 2, LUSH_VARIANT_BWD_512 = 4, LUSH_VARIANT_HEAD_KERNEL = 8, LUSH_VARIANT_BWD_HALF = 16,
-       LUSH_VARIANT_PE_ROWS = 64, LUSH_VARIANT_DW_SPLIT = 128, LUSH_VARIANT_KERNEL_BITS = 0x1DF };
+       LUSH_VARIANT_PE_ROWS = 64, LUSH_VARIANT_DW_SPLIT = 128, LUSH_VARIANT_DENSE_BWD = 256, LUSH_VARIANT_KERNEL_BITS = 0x3DF };
 
 template <int HW_, int NL_, int SKIP_>
 struct NetT {
@@ -179,6 +179,11 @@ struct MlpFwdArgs {
     long long plane_pe, plane_h, plane_hv;   // plane strides in elements
     int write_stash;
     int stash_planes;              // planes copied to the stash (<= NS): what the backward will use
+    // Live-point launches (round 5; the 64-points-per-wave kernels only): point i of the launch is point live_idx[i] of the
+    // [R][S] grid, the point count is read from *live_cnt on the device (P / n_tiles then are upper bounds: the grid's size),
+    // `raw` is not written (the caller has it from the pass over all points).  Both null: a launch over all the points.
+    const int* live_idx;
+    const int* live_cnt;
 };
 
 struct MlpBwdArgs {
@@ -195,6 +200,8 @@ struct MlpBwdArgs {
     long long plane_h, plane_hv;
     float* dpts;                   // [P][8]: d/dx (3), pad, d/dviewdir (3), pad
     const float* scale;            // fp16 chain only: {loss scale, 1/scale} written by grad_scale_kernel
+    const int* live_idx;           // live-point launches (MlpFwdArgs): draw, mask, dZ, dpts are indexed by the launch's point number
+    const int* live_cnt;
 };
 
 struct DwArgs {
@@ -256,6 +263,8 @@ struct DwGroup {
                                    // proportional to the jobs' cost per point, so every workgroup is busy for the same time and
                                    // drains / flushes / refills ONCE (a walking workgroup does it per job: ten times)
     int first[DW_MAX_JOBS + 1];    // per_job == 2: prefix sums of the jobs' slice counts
+    const int* live_cnt;           // live-point launches: the point count on the device (Ppad / pts_per_split are derived from it
+                                   // in the kernel; the host's values are upper bounds), or null
 };
 
 }  // namespace lush

@@ -1230,10 +1230,16 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
         for (int j = 1; j < G.n; ++j) my_job = (int)blockIdx.x >= G.first[j] ? j : my_job;
         my_slice = (int)blockIdx.x - G.first[my_job];
     }
-    const int pps = G.per_job == 2 ? G.j[my_job].pps : G.pts_per_split;
+    // a live-point launch (DwGroup::live_cnt) reads its point count on the device and slices it as the host would have
+    int Ppad = G.Ppad, pps = G.per_job == 2 ? G.j[my_job].pps : G.pts_per_split;
+    if (G.live_cnt != nullptr) {
+        const int cnt = __builtin_amdgcn_readfirstlane(*G.live_cnt);
+        Ppad = (cnt + 255) / 256 * 256;                  // (the stash arrays of a launch are padded to whole 256-point tiles)
+        pps = ((Ppad + (int)gridDim.x - 1) / (int)gridDim.x + 31) / 32 * 32;
+    }
     const long long p_begin = (long long)my_slice * pps;
     long long p_end = p_begin + pps;
-    if (p_end > G.Ppad) p_end = G.Ppad;
+    if (p_end > Ppad) p_end = Ppad;
     const int n_tiles = (int)((p_end - p_begin) / KT);
     if (n_tiles <= 0) return;
     const float unscale = ZF16 ? G.scale[1] : 1.f;
@@ -1300,7 +1306,7 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
             st.xd = nullptr; st.pe_last = 0; st.pe_row16 = 0; st.pe_dst = 0; st.pe_gch = 0; st.pe_nvalid = 0;
             if (has_x2 && G.xd != nullptr && A.pe_mode != 0) {      // (all waves: each moves its share of the quadruples)
                 st.xd = reinterpret_cast<const char*>(G.xd + p_begin * 8 + (A.pe_mode == 2 ? 4 : 0));
-                st.pe_last = (long long)G.Ppad - 1 - p_begin;
+                st.pe_last = (long long)Ppad - 1 - p_begin;
             }
             if (st.xd != nullptr) {      // every wave: tile rows 4 w .. 4 w + 3, 16 lanes per row, 4 columns (8 bytes) per lane
                 const int row = 4 * w + (lane >> 4);

@@ -441,10 +441,11 @@ struct WdPass {
 // (utils/run_lushnerf_helpers.py:334-361).  With ONE workgroup per CU nothing hides this prologue, so it is built for
 // speed: hardware sin / cos behind an exact range reduction (sincos_rev, lush_mlp_dev.h: 4.2e-7 absolute, 1/500 of the
 // fp16 grid this kernel rounds the result to), and the row leaves as twelve 16-byte LDS writes.
-__device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid, float* xd) {
+__device__ __noinline__ void wd_pe_tile(char* peimg, const float* rays, const float* z, int S, int P, long long tile_pt0, int tid, float* xd,
+                                        const int* live) {
     const long long gpt = tile_pt0 + tid;
     float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-    if (gpt < P) point_of(rays, z, S, gpt, x, d);
+    if (gpt < P) point_of(rays, z, S, live ? (long long)live[gpt] : gpt, x, d);      // (a live-point launch: its i-th point is grid point live[i])
     if (xd != nullptr) {      // what the weight gradients re-encode (dw_pe_write, lush_mlp.hip): 32 bytes instead of the 256-byte row
         float4* o = reinterpret_cast<float4*>(xd + gpt * 8);
         o[0] = make_float4(x[0], x[1], x[2], 0.f);
@@ -552,13 +553,19 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
     rt.srow_off = (unsigned)(((lane >> 3) * HW + (lane & 7) * 8) * 2);
     rt.lane2 = (unsigned)lane * 2u;
     float alpha[2] = {0.f, 0.f};
+    // a live-point launch reads its point count on the device (the host sized the grid for all the points)
+    int P = A.P, n_tiles = A.n_tiles;
+    if (A.live_cnt != nullptr) {
+        P = __builtin_amdgcn_readfirstlane(*A.live_cnt);
+        n_tiles = (P + WD_MT - 1) / WD_MT;
+    }
 
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * WD_MT;
         const long long wpt = pt0 + row0;
         WPROF_T(t_tile);
 #ifndef LUSH_ABL_NOPE
-        wd_pe_tile(peimg, A.rays, A.z, A.S, A.P, pt0, tid, (SPK > 0 && !A.pe_rows) ? A.xd : nullptr);
+        wd_pe_tile(peimg, A.rays, A.z, A.S, P, pt0, tid, (SPK > 0 && !A.pe_rows) ? A.xd : nullptr, A.live_idx);
 #endif
         // my pieces of the tile's first position have landed.  First tile: the prologue issued S positions, S-1 are younger.
         // Later tiles: that DMA left S positions ago, in the views layer's second quarter; younger are the DMAs of S-1
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_fwd_kernel(const MlpFwdArgs A)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const long long gpt = wpt + c * 32 + n;
-                if (gpt < A.P) {
+                if (gpt < P && A.live_idx == nullptr) {      // (a live-point launch re-computes points whose raw output the caller has)
                     float4 o;
                     o.x = accB[c][0][0];
                     o.y = accB[c][0][1];

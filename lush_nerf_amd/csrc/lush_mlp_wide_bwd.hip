@@ -422,6 +422,12 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     const float* w_rgb = wtab;
     const float* w_alpha = wtab + 3 * HV;
     const float gscale = A.scale[0], ginv = A.scale[1];
+    // a live-point launch (MlpBwdArgs::live_idx) reads its point count on the device
+    int P = A.P, n_tiles = A.n_tiles;
+    if (A.live_cnt != nullptr) {
+        P = __builtin_amdgcn_readfirstlane(*A.live_cnt);
+        n_tiles = (P + WD_MT - 1) / WD_MT;
+    }
 
     WdCtx cx;
     cx.ring = ring - w * 1024;      // fragment reads add voff = 16 lane + 1024 w: one per-lane register serves the DMAs and the reads
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             long long gpt = wp + c * 32 + n;
-            if (gpt >= A.P) gpt = A.P - 1;                    // (zeroed when consumed)
+            if (gpt >= P) gpt = P - 1;                        // (zeroed when consumed)
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(drn[c]) : "v"((unsigned)(gpt * 16)), "s"(A.draw) : "memory");
         }
     };
@@ -508,14 +514,14 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
     // tile.  With a vmcnt(0) for the first tile and a vmcnt(32) for the others selected by `tile == blockIdx.x` at the loop
     // head, no path-insensitive reading of the code can tell that the prefetch is always waited for; lush_nerf_amd/isa_check.py
     // rule R5 follows every path and now finds the wait on each of them.)
-    if ((int)blockIdx.x < A.n_tiles) prefetch(blockIdx.x);
+    if ((int)blockIdx.x < n_tiles) prefetch(blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(drn[0]), "+v"(drn[1])::"memory");
 #ifdef LUSH_PROF
     for (int i = 0; i < 16; ++i) cx.prof[i] = 0;
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * WD_MT;
         const long long wpt = pt0 + row0;
         BPROF_T(t_tile);
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         float4 dr[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const bool in = wpt + c * 32 + n < A.P;
+            const bool in = wpt + c * 32 + n < P;
             dr[c].x = in ? drn[c][0] * gscale : 0.f; dr[c].y = in ? drn[c][1] * gscale : 0.f;
             dr[c].z = in ? drn[c][2] * gscale : 0.f; dr[c].w = in ? drn[c][3] * gscale : 0.f;
             rt.dalpha[c] = dr[c].w;
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         // the point this THREAD differentiates the encoding at (point row0 + lane) is loaded in front of the pass: B1 is dead, and
         // the loads have four positions to land
         float px[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
-        if (wpt + lane < A.P) point_of(A.rays, A.z, A.S, wpt + lane, px, pd);
+        if (wpt + lane < P) point_of(A.rays, A.z, A.S, A.live_idx ? (long long)A.live_idx[wpt + lane] : wpt + lane, px, pd);
         rt.mrd = mrd0 + 6 * 128;                           // h_0: parity 0
         WbPass<2, 4, WK_ACT, 12, false, true, 48, 0, false, HW, false>::run(cx, accA, accB, B0, B0, a0, rt);
         BPROF_ADD(4, t_body);      // VA .. layer 0
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
         }
         // (parities 0 / 1 of the decision buffer are free now.  Unconditional -- the last tile fetches its own inputs once more --
         // so that d_raw's registers are re-defined on every path and dead through the tile body, not carried across it)
-        prefetch(tile + (int)gridDim.x < A.n_tiles ? tile + (int)gridDim.x : tile);
+        prefetch(tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile);
         {   // dZ_0 rows: behind the prefetch (the tile start counts them as younger), in front of the encoding (B0's 128 registers are
             // free there: with B0 alive through it the allocator spilled the per-lane DMA offset for the whole kernel)
             const char* rows = wd_uniform(reinterpret_cast<const char*>(A.dz0 + wpt * HW));
@@ -737,7 +743,7 @@ __global__ __launch_bounds__(WD_NT) void mlp_wide_bwd_kernel(const MlpBwdArgs A)
                 gx[i] = sx * ginv;
                 gd[i] = sd * ginv;
             }
-            if (wpt + lane < A.P) {
+            if (wpt + lane < P) {
                 float4* o = reinterpret_cast<float4*>(A.dpts + (wpt + lane) * 8);
                 o[0] = make_float4(gx[0], gx[1], gx[2], 0.f);
                 o[1] = make_float4(gd[0], gd[1], gd[2], 0.f);

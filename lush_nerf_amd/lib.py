@@ -146,7 +146,7 @@ class MarchGout(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("rgb", "depth", "acc", "rgb0", "depth0", "acc0")]
 
 
-VIEW_Z, VIEW_RAW, VIEW_WEIGHTS, VIEW_Z_COARSE, VIEW_STASH_COARSE, VIEW_STASH_FINE = range(6)
+VIEW_Z, VIEW_RAW, VIEW_WEIGHTS, VIEW_Z_COARSE, VIEW_STASH_COARSE, VIEW_STASH_FINE, VIEW_LIVE_COUNTS = range(7)
 
 _p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 _SIGS = {
@@ -194,6 +194,12 @@ _SIGS = {
     "lush_mlp_bwd_chain": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _i, _p], _i),
     "lush_mlp_bwd_weights": ([_i, _i, _i, _i, _i, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(MlpParams), _i, _p], _i),
     "lush_ray_grad_reduce": ([_p, _p, _i, _i, _p, _p], _i),
+    "lush_live_aux_bytes": ([_ll], _sz),
+    "lush_live_compact": ([_p, _i, _i, _p, _p, _p, _p, _p, _p], _i),
+    "lush_mlp_fwd_live": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _i, _p], _i),
+    "lush_mlp_bwd_chain_live": ([_i, _i, _i, _p, _p, _i, _i, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _p, _p, _i, _p], _i),
+    "lush_mlp_bwd_weights_live": ([_i, _i, _i, _i, _i, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(MlpParams), _p, _i, _p], _i),
+    "lush_ray_grad_reduce_live": ([_p, _p, _p, _p, _i, _p, _p], _i),
     "lush_march_workspace_bytes": ([C.POINTER(MarchCfgC)], _sz),
     "lush_march_view": ([C.POINTER(MarchCfgC), _i, C.POINTER(_sz), C.POINTER(_sz)], _i),
     "lush_march_fwd": ([C.POINTER(MarchCfgC), _p, C.POINTER(MlpParams), C.POINTER(MlpParams), C.POINTER(MarchDraws),
@@ -211,10 +217,10 @@ _SIGS = {
     "lush_debug_stash_layout": ([_i, _i, _ll, C.POINTER(_ll)], _i),
 }
 EXPORTS = ["lush_last_error"] + list(_SIGS)
-ABI_VERSION = 9
+ABI_VERSION = 10
 PLANES_F16 = 17          # include/lush_march.h: plane code of ONE fp16 plane (1..3 = bf16 planes)
 # include/lush_march.h: LUSH_VARIANT_* (kernel-variant bits of the MLP entry points; 0 = the product's choice)
-VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS, VARIANT_DW_SPLIT = 1, 2, 4, 8, 16, 64, 128
+VARIANT_FWD_HALF, VARIANT_FWD_512, VARIANT_BWD_512, VARIANT_HEAD_KERNEL, VARIANT_BWD_HALF, VARIANT_PE_ROWS, VARIANT_DW_SPLIT, VARIANT_DENSE_BWD = 1, 2, 4, 8, 16, 64, 128, 256
 # include/lush_march.h: LUSH_FAULT_*
 FAULT_NAMES = {1: "rgb_map", 2: "depth_map", 4: "acc_map", 8: "density_map", 16: "raw", 32: "rgb0", 64: "depth0",
                128: "acc0", 256: "density0", 512: "raw0", 1024: "z_std"}

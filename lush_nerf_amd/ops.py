@@ -108,12 +108,15 @@ class Hooks:
              them: no per-tensor temporaries, zero-fills or `grad += tmp` kernels on the step;
       packed: Trainer.step -- the networks' MFMA fragments, packed once per step by one launch (PackPlan) and valid until the
              optimiser moves the parameters: the marches and the noise MLP of the step take them instead of re-packing per call;
+      live_acc: bench.py -- an int64 [4] device tensor; the backward of a live-point march adds its passes' {live, all} point counts
+             (one small add per march, no synchronisation): the share of points whose backward ran;
       draw_offset: Philox offset of the next lush_draws call (march_draws);
       state: Trainer.step_graph -- the device step state (include/lush_march.h lush_step_state_*): draws then take the
              state's counter plus `draw_delta`, the number of the call inside the step, so a step captured in a HIP graph
              draws fresh numbers on every replay (the same numbers the eager step would have drawn)."""
     timer: Optional[KernelTimer] = None
     keep: Optional[dict] = None
+    live_acc: Optional[torch.Tensor] = None      # int64 [4]: every live-point march adds {live, all} points of its fine and coarse pass (bench.py)
     sink: bool = False
     packed: Optional[dict] = None      # Trainer.step: {(data_ptr of a net's first weight, plane code): packed fragments} of THIS step
     draw_offset: int = 0
@@ -167,7 +170,7 @@ def _packed_for(hooks, tensors, planes):
 
 
 def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: bool, stash_planes: int = 0, variant: int = 0,
-                timer: Optional[KernelTimer] = None):
+                timer: Optional[KernelTimer] = None, group: str = "mlp_fwd"):
     """stash_planes: planes kept for the backward (default: all `planes`)."""
     R, S = z.shape
     sp = nplanes(stash_planes or planes) if want_stash else 0   # 0 = inference: only the gamma-row workspace
@@ -175,7 +178,7 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
     stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, sp, R * S), dtype=torch.uint8,
                         device=rays.device)
     st = lib.mlp_struct(tensors, _NL[net])
-    ev = timer.span("mlp_fwd" if net == NET_NERF else "noise_fwd", R * S) if timer is not None else None
+    ev = timer.span(group if net == NET_NERF else "noise_fwd", R * S) if timer is not None else None
     if ev:
         ev[0].record()
     lib.call("lush_mlp_fwd", net, planes, sp, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st),
@@ -183,6 +186,47 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
     if ev:
         ev[1].record()
     return raw, (stash if want_stash else None)
+
+
+def live_backward(precision: "Precision", hooks: Optional["Hooks"]) -> bool:
+    """The march of this mode runs its backward on the live points only (include/lush_march.h "Live points"; the same rule as
+    csrc/lush_march_abi.hip live_mode): one fp16 plane each way, the product's kernels, and no test hook that wants every
+    point's stash."""
+    older = lib.VARIANT_FWD_HALF | lib.VARIANT_FWD_512 | lib.VARIANT_BWD_HALF | lib.VARIANT_BWD_512 | lib.VARIANT_PE_ROWS | \
+        lib.VARIANT_HEAD_KERNEL | lib.VARIANT_DW_SPLIT | lib.VARIANT_DENSE_BWD
+    return precision.fwd == PLANES_F16 and precision.bwd == PLANES_F16 and not (int(precision.variant) & older) and \
+        (hooks is None or hooks.keep is None)
+
+
+def live_compact(draw: torch.Tensor, R: int, S: int):
+    """lush_live_compact: d_raw [R*S, 4] -> (live_idx int32 [R*S], draw_c [R*S, 4], ray_start int32 [R+1], cnt int32 [2] = {live, R*S})."""
+    dev = draw.device
+    P = R * S
+    lidx = torch.empty(P, dtype=torch.int32, device=dev)
+    draw_c = torch.empty(P, 4, dtype=torch.float32, device=dev)
+    ray_start = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    cnt = torch.empty(2, dtype=torch.int32, device=dev)
+    aux = torch.empty(max(int(lib.load().lush_live_aux_bytes(P)), 4), dtype=torch.uint8, device=dev)
+    lib.call("lush_live_compact", lib.ptr(draw), R, S, lib.ptr(lidx), lib.ptr(draw_c), lib.ptr(ray_start), lib.ptr(cnt), lib.ptr(aux), _stream())
+    return lidx, draw_c, ray_start, cnt
+
+
+def mlp_forward_live(net: int, planes: int, tensors, packed, rays, z, lidx, cnt, stash_planes: int = 0, variant: int = 0,
+                     timer: Optional[KernelTimer] = None):
+    """The forward once more, WITH the stash, on the live points of a pass (lush_mlp_fwd_live): returns the stash.  With a timer the
+    point count is read back (a synchronisation: the bench's kernel-group pass only)."""
+    R, S = z.shape
+    sp = nplanes(stash_planes or planes)
+    stash = torch.empty(lib.load().lush_mlp_stash_bytes(net, planes, sp, R * S), dtype=torch.uint8, device=rays.device)
+    st = lib.mlp_struct(tensors, _NL[net])
+    ev = timer.span("mlp_fwd" if net == NET_NERF else "noise_fwd", int(cnt[0].item())) if timer is not None else None
+    if ev:
+        ev[0].record()
+    lib.call("lush_mlp_fwd_live", net, planes, sp, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed), C.byref(st), lib.ptr(stash),
+             lib.ptr(lidx), lib.ptr(cnt), int(variant), _stream())
+    if ev:
+        ev[1].record()
+    return stash
 
 
 def grad_sink(tensors, hooks: Optional[Hooks]):
@@ -197,9 +241,11 @@ def grad_sink(tensors, hooks: Optional[Hooks]):
 
 
 def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays, z, draw, stash, sink=None, variant: int = 0,
-                 timer: Optional[KernelTimer] = None):
+                 timer: Optional[KernelTimer] = None, live=None):
     """Returns (list of parameter grads in `tensors` order, dpts [P][8]).  With `sink` (a list of fp32
-    buffers, one per tensor) the gradients are ADDED to those buffers and the returned list holds None."""
+    buffers, one per tensor) the gradients are ADDED to those buffers and the returned list holds None.
+    live = (live_idx, cnt) of ops.live_compact: `draw` is the gathered d_raw, `stash` the live points' (mlp_forward_live), dpts
+    comes back in list order (lush_mlp_bwd_chain_live / _weights_live)."""
     R, S = z.shape
     dev = rays.device
     dstash = torch.empty(lib.load().lush_mlp_dstash_bytes(net, planes_b, R * S), dtype=torch.uint8, device=dev)
@@ -213,6 +259,24 @@ def mlp_backward(net: int, planes_f: int, planes_b: int, tensors, packed_b, rays
             o += t.numel()
     dpts = torch.empty(R * S, 8, dtype=torch.float32, device=dev)
     st, gs = lib.mlp_struct(tensors, _NL[net]), lib.mlp_struct(grads, _NL[net])
+    if live is not None:
+        lidx, cnt = live
+        npts = int(cnt[0].item()) if timer is not None else 0
+        ev = timer.span("mlp_bwd_chain", npts) if timer is not None else None
+        if ev:
+            ev[0].record()
+        lib.call("lush_mlp_bwd_chain_live", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b), C.byref(st), lib.ptr(draw),
+                 lib.ptr(stash), lib.ptr(dstash), lib.ptr(dpts), lib.ptr(lidx), lib.ptr(cnt), int(variant), _stream())
+        if ev:
+            ev[1].record()
+        ev = timer.span("mlp_bwd_weights", npts) if timer is not None else None
+        if ev:
+            ev[0].record()
+        lib.call("lush_mlp_bwd_weights_live", net, planes_f, planes_b, R, S, C.byref(st), lib.ptr(draw), lib.ptr(stash), lib.ptr(dstash),
+                 C.byref(gs), lib.ptr(cnt), int(variant), _stream())
+        if ev:
+            ev[1].record()
+        return ([None] * len(tensors) if sink is not None else grads), dpts
     timed = timer is not None and net == NET_NERF
     if not timed:      # chain + weight gradients as ONE call (the loss-scale launch then also zeroes the weight gradients' scratch)
         lib.call("lush_mlp_bwd", net, planes_f, planes_b, lib.ptr(rays), lib.ptr(z), R, S, lib.ptr(packed_b), C.byref(st), lib.ptr(draw),
@@ -403,8 +467,11 @@ class March(torch.autograd.Function):
     @staticmethod
     def _c_cfg(cfg: MarchCfg, R: int, same: bool, need_grad: bool, packed=None):
         pf, pb = cfg.precision.fwd, cfg.precision.bwd
+        variant = int(cfg.precision.variant)
+        if cfg.hooks is not None and cfg.hooks.keep is not None:
+            variant |= lib.VARIANT_DENSE_BWD      # tests read the ReLU decisions of EVERY point from the stash: the forward must keep it
         c = lib.MarchCfgC(R, cfg.N_samples, cfg.N_importance, float(cfg.perturb), float(cfg.raw_noise_std), int(cfg.white_bkgd),
-                          int(cfg.lindisp), float(cfg.near_mask), pf, pb if need_grad else 0, int(cfg.precision.variant), int(same))
+                          int(cfg.lindisp), float(cfg.near_mask), pf, pb if need_grad else 0, variant, int(same))
         if packed is not None:      # packed once per step by the trainer (the tensors stay alive in `packed`, held by the caller)
             p = lambda k: None if packed.get(k) is None else packed[k].data_ptr()
             c.packed_coarse, c.packed_fine = p("coarse"), p("fine")
@@ -424,6 +491,7 @@ class March(torch.autograd.Function):
         Sl = S + Ni
         ctx.packed = March._packed_of(cfg, same, need_grad, coarse, fine)
         c = March._c_cfg(cfg, R, same, need_grad, ctx.packed)
+        ctx.c_variant = int(c.variant)          # (the backward must lay the workspace out as the forward did)
         nbytes = lib.load().lush_march_workspace_bytes(C.byref(c))
         if nbytes == 0:
             raise RuntimeError("lush_march_workspace_bytes: bad configuration")
@@ -458,6 +526,7 @@ class March(torch.autograd.Function):
         (ws,) = saved
         R, fine_on = batch.shape[0], cfg.N_importance > 0
         c = March._c_cfg(cfg, R, ctx.same, True, ctx.packed)      # (the forward's packed buffers, not a second look at the hooks)
+        c.variant = ctx.c_variant
         gp = [_opt(g[0]), _opt(g[1]), _opt(g[2])] + ([_opt(g[7]), _opt(g[8]), _opt(g[9])] if fine_on else [None, None, None])
         go = lib.MarchGout(*(None if t is None else t.data_ptr() for t in gp))
         any_main = any(t is not None for t in gp[:3])
@@ -486,15 +555,30 @@ class March(torch.autograd.Function):
         gf = lib.mlp_struct(buf_f, _NL[NET_NERF]) if buf_f is not None else None
         lib.call("lush_march_bwd", C.byref(c), lib.ptr(batch), C.byref(stc), C.byref(stf), C.byref(dr), C.byref(go), lib.ptr(ws),
                  None if gc is None else C.byref(gc), None if gf is None else C.byref(gf), lib.ptr(drays), _stream())
+        if cfg.hooks.live_acc is not None and (ran_f or ran_c) and not (c.variant & lib.VARIANT_DENSE_BWD) and live_backward(cfg.precision, None):
+            off, nb = C.c_size_t(), C.c_size_t()
+            lib.call("lush_march_view", C.byref(c), lib.VIEW_LIVE_COUNTS, C.byref(off), C.byref(nb))
+            cnt = ws[off.value:off.value + 16].view(torch.int32)
+            if not (ran_f and ran_c) or not fine_on:      # a pass that did not run left its slot untouched
+                cnt = cnt.clone()
+                if not fine_on or not ran_c:
+                    cnt[2:] = 0
+                if fine_on and not ran_f:
+                    cnt[:2] = 0
+            cfg.hooks.live_acc += cnt
         return drays, ret_c, ret_f
 
     # ------------------------------------------------------------------ kernel group by kernel group (bench.py's timing pass)
     @staticmethod
     def _forward_piecewise(ctx, batch, cfg, d, coarse, fine, same, need_grad):
         pf, pb, var, tm = cfg.precision.fwd, cfg.precision.bwd, cfg.precision.variant, cfg.hooks.timer
+        live = need_grad and live_backward(cfg.precision, cfg.hooks)      # the backward re-runs the forward on the live points: no stash here
+        ctx.live = live
+        stash_fwd = need_grad and not live
+        grp = "mlp_fwd_all" if live else "mlp_fwd"
         zc = zgrid(batch, cfg.N_samples, cfg.lindisp, d.get("t_rand"))
         pk_c = mlp_pack(NET_NERF, pf, coarse, var)
-        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, need_grad, stash_code(pf, pb), var, tm)
+        raw_c, stash_c = mlp_forward(NET_NERF, pf, coarse, pk_c, batch, zc, stash_fwd, stash_code(pf, pb), var, tm, grp)
         rgb, depth, acc, weights, density = composite_fwd(raw_c, zc, batch, d.get("noise_c"), cfg,
                                                           lib.FAULT_COARSE_SHIFT if cfg.N_importance > 0 else 0)
         outs = [rgb, depth, acc, density]
@@ -503,7 +587,7 @@ class March(torch.autograd.Function):
         if cfg.N_importance > 0:
             zf, _, z_std = sample_merge(zc, weights, cfg.N_importance, d.get("u"), cfg.flags)
             pk_f = pk_c if same else mlp_pack(NET_NERF, pf, fine, var)
-            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, need_grad, stash_code(pf, pb), var, tm)
+            raw_f, stash_f = mlp_forward(NET_NERF, pf, fine, pk_f, batch, zf, stash_fwd, stash_code(pf, pb), var, tm, grp)
             rgb1, depth1, acc1, weights1, density1 = composite_fwd(raw_f, zf, batch, d.get("noise_f"), cfg)
             outs = [rgb1, depth1, acc1, density1]
             saved += [zf, raw_f, stash_f if stash_f is not None else torch.empty(0, device=batch.device)]
@@ -532,6 +616,13 @@ class March(torch.autograd.Function):
         def run(tensors, z, raw, noise, stash, gg):
             draw = composite_bwd(raw, z, batch, noise, cfg, gg[0], gg[1], gg[2], drays)
             pk = mlp_pack(NET_NERF, pb, tensors, cfg.precision.variant)
+            if getattr(ctx, "live", False):      # (the one-call march does the same inside lush_march_bwd)
+                lidx, draw_c, ray_start, cnt = live_compact(draw, z.shape[0], z.shape[1])
+                st_live = mlp_forward_live(NET_NERF, pf, tensors, pk, batch, z, lidx, cnt, stash_code(pf, pb), cfg.precision.variant, tm)
+                gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw_c, st_live,
+                                        sink=grad_sink(tensors, cfg.hooks), variant=cfg.precision.variant, timer=tm, live=(lidx, cnt))
+                lib.call("lush_ray_grad_reduce_live", lib.ptr(dpts), lib.ptr(z), lib.ptr(lidx), lib.ptr(ray_start), z.shape[0], lib.ptr(drays), _stream())
+                return gr
             gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw, stash,
                                     sink=grad_sink(tensors, cfg.hooks), variant=cfg.precision.variant, timer=tm)
             lib.call("lush_ray_grad_reduce", lib.ptr(dpts), lib.ptr(z), z.shape[0], z.shape[1], lib.ptr(drays), _stream())

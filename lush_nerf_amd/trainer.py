@@ -143,6 +143,18 @@ class Trainer:
         self.allreduce_events = None      # set to a list to collect (start, end) HIP events of every step's all-reduce
         # scratch of the loss kernel's reduction (zero once, left zero by every launch: no zero-fill per step)
         self._loss_work = torch.zeros(2, dtype=torch.float32, device=self.flat.param.device) if self.flat.param.is_cuda else None
+        # live-point backward (include/lush_march.h "Live points"): the share of MLP evaluation points whose d_raw row is non-zero,
+        # counted on the device by every march and followed on the host WITHOUT blocking (snapshots through pinned memory)
+        self.live_policy = "auto"         # "auto": dense backward while the share stays above LIVE_MAX_SHARE; "live" / "dense": always
+        self._live_cum = torch.zeros(4, dtype=torch.int64, device=self.flat.param.device) if self.flat.param.is_cuda else None
+        self._live_ring = torch.zeros(8, 4, dtype=torch.int64).pin_memory() if self.flat.param.is_cuda else None
+        self._live_slot = 0
+        self._live_snaps = []             # [(event, ring row)], oldest first
+        self._live_prev = [0, 0, 0, 0]    # last snapshot read (cumulative counts)
+        self.live_share = None            # share of live points in the most recent step whose counts have arrived
+        self._dense_now = False
+        self._dense_steps = 0
+        self._eager_seen = set()          # backward choices (dense: bool) that have run as an eager step (step_graph captures only those)
         self._pack_plan = None            # ops.PackPlan of the model's networks in the current precision mode
         self._pack_plans = {}             # ... by signature (precision mode, kernel variant, parameter addresses)
         self._graph = None                # step_graph: the captured step (graphs, static batch / loss, device step state + host mirror)
@@ -189,17 +201,84 @@ class Trainer:
     # 77 / 80 / 118 -> 74 / 69 / 115; R = 2 048: 92 / 96 / 189 -> 110 / 109 / 160 (the big tiles win from there).
     SMALL_LAUNCH_POINTS = 32768
 
-    def _step_precision(self, n_rays: int, force_naive: bool, coarse_only: bool = False):
-        """The precision mode this step's kernels run in: the model's, with the small-launch kernel variant when the step's
-        largest MLP launch is small (headline mode only; an explicit variant is left alone)."""
-        pr = self.model.precision
-        if pr.variant != 0 or pr.fwd != ops.PLANES_F16 or pr.bwd != ops.PLANES_F16:
-            return pr
+    # The live-point march costs one forward over all the points more than the dense one and saves (1 - share) of the stash-
+    # writing forward, the chain and the weight gradients: measured on BASELINE config 2, 5.2 + 15.7 x share ms against 16.2 ms,
+    # break-even at a share of 0.70.  Above LIVE_MAX_SHARE the trainer runs the dense backward and looks again (one live step)
+    # every LIVE_PROBE_EVERY steps; it returns to the live march below LIVE_MIN_SHARE.
+    LIVE_MAX_SHARE, LIVE_MIN_SHARE, LIVE_PROBE_EVERY = 0.65, 0.60, 32
+
+    def _live_poll(self):
+        """Read the count snapshots that have arrived (never blocks): updates live_share."""
+        while self._live_snaps and self._live_snaps[0][0].query():
+            _, row = self._live_snaps.pop(0)
+            cur = [int(x) for x in self._live_ring[row].tolist()]
+            d_live = (cur[0] - self._live_prev[0]) + (cur[2] - self._live_prev[2])
+            d_all = (cur[1] - self._live_prev[1]) + (cur[3] - self._live_prev[3])
+            if d_all > 0:
+                self.live_share = d_live / d_all
+            self._live_prev = cur
+
+    def _live_snapshot(self):
+        """Enqueue a copy of the cumulative counts into the next row of the pinned ring (no allocation, nothing blocks)."""
+        if self._live_cum is None or len(self._live_snaps) >= self._live_ring.shape[0]:
+            return                         # (the host ran a ring ahead of the device: this step's delta folds into the next snapshot)
+        row = self._live_slot
+        self._live_slot = (row + 1) % self._live_ring.shape[0]
+        self._live_ring[row].copy_(self._live_cum, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._live_snaps.append((ev, row))
+
+    def live_counts(self):
+        """Cumulative {live, all} point counts of the fine and the coarse passes of every live-point march so far (a
+        synchronisation; bench.py reads it around its timed region)."""
+        return [0, 0, 0, 0] if self._live_cum is None else [int(x) for x in self._live_cum.tolist()]
+
+    def _dense_backward_now(self) -> bool:
+        """The policy's choice for the step that starts now."""
+        if self.live_policy == "dense":
+            return True
+        if self.live_policy == "live" or self.live_share is None:
+            return False
+        if self._dense_now:
+            self._dense_steps += 1
+            if self._dense_steps % self.LIVE_PROBE_EVERY == 0:
+                return False                                   # one live step: look at the share again
+            if self.live_share < self.LIVE_MIN_SHARE:
+                self._dense_now = False
+        elif self.live_share > self.LIVE_MAX_SHARE:
+            self._dense_now, self._dense_steps = True, 0
+        return self._dense_now
+
+    def _largest_launch(self, n_rays: int, force_naive: bool, coarse_only: bool = False) -> int:
         M = 1 if (force_naive or coarse_only or self.model.blur_kernel_net is None) else self.model.mlp_rbk.num_motion + 1
         Ni = 0 if coarse_only else int(self.kw["N_importance"])
-        pts = int(n_rays) * M * (int(self.kw["N_samples"]) + Ni)
-        if pts <= self.SMALL_LAUNCH_POINTS:
+        return int(n_rays) * M * (int(self.kw["N_samples"]) + Ni)
+
+    def _headline_default(self) -> bool:
+        pr = self.model.precision
+        return pr.variant == 0 and pr.fwd == ops.PLANES_F16 and pr.bwd == ops.PLANES_F16
+
+    def _backward_choice(self, n_rays: int, force_naive: bool) -> bool:
+        """True: the step that starts now runs the dense backward.  Decided on the host from the counts that have arrived, OUTSIDE
+        any graph capture (step_graph keeps one captured step per answer)."""
+        if not self._headline_default() or self._largest_launch(n_rays, force_naive) <= self.SMALL_LAUNCH_POINTS \
+                or self._live_cum is None:
+            return False
+        self._live_poll()
+        return self._dense_backward_now()
+
+    def _step_precision(self, n_rays: int, force_naive: bool, coarse_only: bool = False, dense: bool = False):
+        """The precision mode this step's kernels run in: the model's, with the small-launch kernel variant when the step's
+        largest MLP launch is small, or with the dense backward when _backward_choice said so (headline mode only; an explicit
+        variant is left alone)."""
+        pr = self.model.precision
+        if not self._headline_default():
+            return pr
+        if self._largest_launch(n_rays, force_naive, coarse_only) <= self.SMALL_LAUNCH_POINTS:
             return ops.Precision(pr.fwd, pr.bwd, ops.lib.VARIANT_FWD_HALF | ops.lib.VARIANT_BWD_HALF)
+        if dense:
+            return ops.Precision(pr.fwd, pr.bwd, ops.lib.VARIANT_DENSE_BWD)
         return pr
 
     class _PrecisionFor:
@@ -282,18 +361,23 @@ class Trainer:
             (loss_rgb * weight).backward()
         return loss_rgb.detach()
 
-    def step(self, batch: Dict[str, torch.Tensor], i: int, draws=None, consist: Optional[dict] = None):
+    def step(self, batch: Dict[str, torch.Tensor], i: int, draws=None, consist: Optional[dict] = None, _dense: Optional[bool] = None):
         """One optimisation step on a batch {rays [N,3,2] (or c2w/view/px/py for device-side ray generation),
         images_idx [N,1], target [N,3], fq_mask [N]}."""
         self.model.train()
         force_naive = i < self.kernel_start_iter
         N = batch["target"].shape[0]
         mb = self.micro_batch if 0 < self.micro_batch < N else N
+        dense = self._backward_choice(mb, force_naive) if _dense is None else _dense
+        self._eager_seen.add(dense)
         loss = None
         hooks = self.model.hooks
         sink_before, hooks.sink = hooks.sink, True
+        acc_before = hooks.live_acc
+        if hooks.live_acc is None:
+            hooks.live_acc = self._live_cum
         try:      # dW kernels add straight into the flat gradient (p.grad are views of it)
-            step_prec = self._step_precision(mb, force_naive)
+            step_prec = self._step_precision(mb, force_naive, dense=dense)
             with self._PrecisionFor(self.model, step_prec):
                 self._pack_weights(zero_grad=True)
                 for a in range(0, N, mb):
@@ -307,7 +391,9 @@ class Trainer:
                     self._pack_weights()      # (the aligned-pixel march runs in the model's own kernel variant: other fragment copies)
                 loss = loss + w * self._consistency(consist, w)
         finally:
-            hooks.sink, hooks.packed = sink_before, None
+            hooks.sink, hooks.packed, hooks.live_acc = sink_before, None, acc_before
+        if acc_before is None and not dense:
+            self._live_snapshot()
         if self.distributed:
             self._all_reduce()          # RCCL sum over xGMI; the 1/world mean is folded into Adam
         lr = self.lr() if self._lr_next is None else self._lr_next
@@ -406,7 +492,7 @@ class Trainer:
             ev[1].record()
             self.allreduce_events.append(ev)
 
-    def _body_grads(self, batch, i, force_naive, state):
+    def _body_grads(self, batch, i, force_naive, state, dense=False):
         """First half of what step() enqueues -- zero the flat gradient, forward + backward of every micro-batch -- with the
         Philox draw counter taken from the device step state."""
         N = batch["target"].shape[0]
@@ -416,7 +502,7 @@ class Trainer:
         sink_before, hooks.sink = hooks.sink, True
         hooks.state, hooks.draw_delta = state, 0
         try:
-            with self._PrecisionFor(self.model, self._step_precision(mb, force_naive)):
+            with self._PrecisionFor(self.model, self._step_precision(mb, force_naive, dense=dense)):
                 self._pack_weights(zero_grad=True)
                 for a in range(0, N, mb):
                     b = min(a + mb, N)
@@ -484,30 +570,42 @@ class Trainer:
             self._graph_eager_left = max(self._graph_eager_left - 1, 0)
             return self.step(batch, i, consist=consist)      # (the consistency branch draws its anchor / pixels on the host: eager)
         hooks = self.model.hooks
-        if self._graph is None:
+        N = batch["target"].shape[0]
+        dense = self._backward_choice(self.micro_batch if 0 < self.micro_batch < N else N, force_naive)
+        if dense not in self._eager_seen:             # (each backward's first step is a real, eager one: its lazy initialisation)
+            return self.step(batch, i, _dense=dense)
+        if self._graph is None or dense not in self._graph["sub"]:
             self.model.train()
             dev = self.flat.param.device
-            state = torch.zeros(ops.lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
-            mirror = self._state_init(state)
-            static = batch.clone_static() if isinstance(batch, BlobBatch) else {k: v.clone() for k, v in batch.items()}
+            if self._graph is None:
+                state = torch.zeros(ops.lib.load().lush_step_state_bytes(), dtype=torch.uint8, device=dev)
+                mirror = self._state_init(state)
+                static = batch.clone_static() if isinstance(batch, BlobBatch) else {k: v.clone() for k, v in batch.items()}
+                self._graph = dict(key=key, static=static, state=state, mirror=mirror, sub={}, pool=None)
+            G = self._graph
+            state, static = G["state"], G["static"]
             g1 = torch.cuda.CUDAGraph()
             g2 = None
+            pool = {} if G["pool"] is None else dict(pool=G["pool"])      # (the two captured steps never run at once: one pool)
             distributed, self.distributed = self.distributed, False      # (the captured body never calls the collective itself)
+            acc_before, hooks.live_acc = hooks.live_acc, (self._live_cum if hooks.live_acc is None else hooks.live_acc)
             try:
                 if not split:
-                    with torch.cuda.graph(g1):
-                        loss, calls = self._body_grads(static, i, force_naive, state)
+                    with torch.cuda.graph(g1, **pool):
+                        loss, calls = self._body_grads(static, i, force_naive, state, dense)
                         mask = self._body_update(force_naive, state, calls)
                 else:
-                    with torch.cuda.graph(g1):
-                        loss, calls = self._body_grads(static, i, force_naive, state)
+                    with torch.cuda.graph(g1, **pool):
+                        loss, calls = self._body_grads(static, i, force_naive, state, dense)
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, pool=g1.pool()):
                         mask = self._body_update(force_naive, state, calls)
             finally:
-                self.distributed = distributed
-            self._graph = dict(key=key, g1=g1, g2=g2, static=static, loss=loss, calls=calls, mask=mask, state=state, mirror=mirror)
+                self.distributed, hooks.live_acc = distributed, acc_before
+            G["pool"] = g1.pool()
+            G["sub"][dense] = dict(g1=g1, g2=g2, loss=loss, calls=calls, mask=mask)
         G = self._graph
+        sub = G["sub"][dense]
         if G["mirror"] != (int(hooks.draw_offset), int(self.global_step), tuple(self.steps)):
             G["mirror"] = self._state_init(G["state"])
         if isinstance(batch, BlobBatch) and isinstance(G["static"], BlobBatch):
@@ -515,18 +613,20 @@ class Trainer:
         else:
             for k, v in batch.items():
                 G["static"][k].copy_(v, non_blocking=True)
-        G["g1"].replay()
-        if G["g2"] is not None:
+        sub["g1"].replay()
+        if sub["g2"] is not None:
             if self.distributed:
                 self._all_reduce()
-            G["g2"].replay()
+            sub["g2"].replay()
+        if not dense:
+            self._live_snapshot()                    # (the captured live-point march adds its counts on the device)
         for s in range(3):
-            if (G["mask"] >> s) & 1:
+            if (sub["mask"] >> s) & 1:
                 self.steps[s] += 1
         self.global_step += 1
-        hooks.draw_offset += G["calls"]
+        hooks.draw_offset += sub["calls"]
         G["mirror"] = (int(hooks.draw_offset), int(self.global_step), tuple(self.steps))
-        return G["loss"]
+        return sub["loss"]
 
     def faults(self) -> int:
         """Numerical-fault word of the model's render calls since the last read (one device sync; the reference

@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --also= --extra= --no-traffic --sustained 0"
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --also= --extra= --no-traffic --sustained 0 --no-dense"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py $ARGS > $OUT/bench_$c.json 2> $OUT/pmc_$c.err

@@ -887,6 +887,27 @@ def _gpu_masks(keep, precision):
     return out
 
 
+def live_vs_dense(tag, net, rays, dense, dense_rays):
+    """The product's live-point backward against the dense one on the same forward: every tensor to the order of the fp32 sums.
+    Both add the same non-zero terms (a dead point's row is exact zeros) but group them differently -- 32 live points per
+    weight-gradient stage instead of ~16 live + ~16 dead -- so a tensor that is a cancelling sum (the alpha bias, the RBK heads:
+    the tensors on which the fp32 oracle itself is off by 1e-4 .. 1e-3 against float64) moves by its condition number times 2^-24
+    per partial sum; gates: all gradients together 1e-5 of their norm, no tensor beyond 2e-3 of its largest entry."""
+    num = den = 0.0
+    worst, wk = 0.0, ""
+    items = [(k, v.grad, dense[k]) for k, v in net.named_parameters() if v.grad is not None] + [("d rays", rays.grad, dense_rays)]
+    for k, a, b in items:
+        e = util.relerr(a, b)
+        if e > worst:
+            worst, wk = e, k
+        num += float((a.double() - b.double()).pow(2).sum())
+        den += float(b.double().pow(2).sum())
+    l2 = (num / max(den, 1e-300)) ** 0.5
+    RESULTS.append((f"{tag} live-point backward = dense backward (all gradients, L2)", l2, 1e-5, bool(l2 <= 1e-5)))
+    RESULTS.append((f"{tag} live-point backward = dense backward (worst tensor [{wk}])", worst, 2e-3, bool(worst <= 2e-3)))
+    print(f"{'ok  ' if l2 <= 1e-5 and worst <= 2e-3 else 'FAIL'} {tag}: live-point backward against the dense one: L2 {l2:.1e}, worst tensor {wk} {worst:.1e}", flush=True)
+
+
 def t_train_e2e():
     from lush_nerf_amd import model as M
     import argparse
@@ -918,6 +939,24 @@ def t_train_e2e():
             net.hooks.keep = None
         loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
         loss.backward()
+        if ops.live_backward(prec, None):
+            # the PRODUCT's march keeps no stash and runs its backward on the live points only (include/lush_march.h "Live points");
+            # the run above kept every point's stash for the ReLU decisions (hooks.keep).  Same forward, product backward: the
+            # outputs must be the same bit for bit, the gradients equal up to the order of the fp32 atomics -- and THESE are the
+            # gradients the oracle checks below see.
+            dense = {k: (None if v.grad is None else v.grad.clone()) for k, v in net.named_parameters()}
+            dense_rays, dense_out = rays.grad.clone(), [o.detach().clone() for o in (out[0], out[1], out[3])]
+            net.zero_grad(set_to_none=True)
+            rays.grad = None
+            out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": gpu(b["images_idx"])}, retraw=True,
+                      force_naive=bool(naive), allkernel=bool(allk), kernel_pixel=gpu(b["fq_mask"]), perturb=1.,
+                      N_importance=Ni, N_samples=Ns, use_viewdirs=True, white_bkgd=False, raw_noise_std=1.,
+                      inference=False, near=0., far=1., draws=draws)
+            loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
+            loss.backward()
+            same = all(torch.equal(a, o.detach()) for a, o in zip(dense_out, (out[0], out[1], out[3])))
+            RESULTS.append((f"train {name} live-point march: outputs bit-identical to the dense march", 0. if same else 1., 0, same))
+            live_vs_dense(f"train {name}", net, rays, dense, dense_rays)
         rep(f"train {name} rgb_blur", out[0], g["rgb_blur"], 1e-4)
         rep(f"train {name} rgb0_blur", out[1], g["rgb0_blur"], 1e-4)
         rep(f"train {name} noise", out[3], g["noise"], 1e-4)
@@ -987,6 +1026,20 @@ def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
         net.hooks.keep = None
     loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
     loss.backward()
+    live_frac = None
+    if ops.live_backward(prec, None):      # the product's march: backward on the live points only (see t_train_e2e); ITS gradients go to the oracle
+        dense = {k: (None if v.grad is None else v.grad.clone()) for k, v in net.named_parameters()}
+        dense_rays, dense_out = rays.grad.clone(), [o.detach().clone() for o in (out[0], out[1], out[3], out[5])]
+        net.zero_grad(set_to_none=True)
+        rays.grad = None
+        out = net(H, W, K, chunk=1 << 20, rays=rays, rays_info={"images_idx": gpu(b["images_idx"])}, retraw=True,
+                  force_naive=False, allkernel=True, kernel_pixel=gpu(b["fq_mask"]), perturb=1., N_importance=Ni, N_samples=Ns,
+                  use_viewdirs=True, white_bkgd=False, raw_noise_std=1., inference=False, near=0., far=1., draws=draws)
+        loss = ops.TrainLoss.apply(out[0], out[1], gpu(b["target"]))
+        loss.backward()
+        same = all(torch.equal(a, o.detach()) for a, o in zip(dense_out, (out[0], out[1], out[3], out[5])))
+        RESULTS.append(("bench regime live-point march: outputs bit-identical to the dense march", 0. if same else 1., 0, same))
+        live_vs_dense("bench regime", net, rays, dense, dense_rays)
     fw = net.read_faults()
     RESULTS.append(("bench regime fault word", float(fw), 0, fw == 0))
     tiles = keep["P_f"] // 128

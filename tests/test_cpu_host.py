@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     assert set(lib.EXPORTS) <= declared | {"lush_last_error"}
     l = lib.load()
-    assert l.lush_abi_version() == lib.ABI_VERSION == 9
+    assert l.lush_abi_version() == lib.ABI_VERSION == 10
     # pure host queries (no device work)
     p1, p3 = l.lush_mlp_packed_bytes(0, 1), l.lush_mlp_packed_bytes(0, 3)
     assert p1 > 2 * 593408 * 2 and 2.9 * p1 < p3 < 3 * p1      # fragments scale with planes, the fp32 bias block does not
@@ -462,7 +462,7 @@ def test_bench_traffic_child_profiles_the_same_workload():
     val = lambda k: t[t.index(k) + 1]
     assert (val("--n-rand"), val("--n-samples"), val("--n-importance"), val("--micro-batch")) == ("2048", "128", "128", "1024")
     assert val("--planes") == "h,h" and val("--variant") == "64" and val("--so") == "/x/y.so" and val("--steps") == "2"
-    assert "--no-traffic" in t and "--no-kernel-pass" in t and "--no-cpu-baseline" in t and val("--sustained") == "0"      # no recursion, nothing else timed
+    assert "--no-traffic" in t and "--no-kernel-pass" in t and "--no-cpu-baseline" in t and "--no-dense" in t and val("--sustained") == "0"      # no recursion, nothing else timed
     # and the parser accepts exactly that tail
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *[x for x in t if x != "/x/y.so" and x != "--so"], "--gpus", "0"],
                        capture_output=True, text=True, timeout=300)

@@ -683,7 +683,7 @@ def test_step_graph_resynchronises_with_the_host(diag, mode, tmp_path):
                 lb.append(float(B.step(b, s)))
             else:
                 lb.append(float(B.step_graph(b, s, split=(mode == "split"))))
-        assert B._graph is not None and (B._graph["g2"] is not None) == (mode == "split")
+        assert B._graph is not None and all((g["g2"] is not None) == (mode == "split") for g in B._graph["sub"].values())
         assert A.steps == B.steps and A.global_step == B.global_step and A.model.hooks.draw_offset == B.model.hooks.draw_offset
         worst = max(abs(x - y) / abs(x) for x, y in zip(la, lb))
         assert worst < 2e-5, (mode, worst, la, lb)
@@ -1020,6 +1020,131 @@ def test_weight_gradient_split_agrees_with_the_walk(tmp_path):
         worst = max(worst, err)
         assert np.isfinite(a[k]).all() and err < 2e-5, (k, err)
     print(f"one job per workgroup against the walk: parameter gradients within {worst:.1e}")
+
+
+def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=False, seed=17, sharp=False):
+    """One kernel-on training forward + backward of the (h,h) model in the given kernel variant: (outputs, gradients, live counts)."""
+    from lush_nerf_amd import ops, synth
+    dev = torch.device("cuda:0")
+    net = diag._nerf_all(64, seed, sharp=sharp, precision=ops.Precision(ops.PLANES_F16, ops.PLANES_F16, variant), rbk_scale=2.0e4)
+    if alpha_bias is not None:
+        with torch.no_grad():
+            net.mlp_coarse.alpha_linear.bias.fill_(alpha_bias)
+            net.mlp_fine.alpha_linear.bias.fill_(alpha_bias)
+    b = diag.batch_of(n, seed)
+    draws = {k: v.to(dev) for k, v in diag.util.tdraws(n * 5, 64, 64, seed).items()}
+    rays = diag.gpu(b["rays"]).requires_grad_(True)
+    net.hooks.live_acc = torch.zeros(4, dtype=torch.int64, device=dev)
+    out = net(diag.H, diag.W, [[diag.F, 0, diag.W / 2], [0, diag.F, diag.H / 2], [0, 0, 1]], chunk=1 << 20, rays=rays,
+              rays_info={"images_idx": diag.gpu(b["images_idx"])}, retraw=True, force_naive=False, allkernel=True,
+              kernel_pixel=diag.gpu(b["fq_mask"]), perturb=1., N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False,
+              raw_noise_std=noise, inference=False, near=0., far=1., draws=draws)
+    loss = ops.TrainLoss.apply(out[0], out[1], diag.gpu(b["target"]))
+    (loss * 0.0 if zero_upstream else loss).backward()
+    assert net.read_faults() == 0
+    grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in net.named_parameters()}
+    grads["d rays"] = rays.grad.clone()
+    return [o.detach().clone() for o in (out[0], out[1], out[3], out[5])], grads, [int(x) for x in net.hooks.live_acc.tolist()]
+
+
+@pytest.mark.parametrize("case", ["default-init", "all-live", "all-dead", "sharp"])
+def test_live_point_march_equals_the_dense_march(diag, case):
+    """Round 5: the headline mode's march keeps no stash in its forward; its backward lists the points whose d_raw row is non-zero
+    (a sample whose density pre-activation the ReLU of raw2outputs clamps has alpha = 0, weight = 0, d alpha / d raw = 0:
+    models/lushnerf.py:313-327), re-runs the forward with the stash on that list and chains / forms the weight gradients there.
+    Against LUSH_VARIANT_DENSE_BWD (every point stashed and chained, rounds 1-4): outputs bit for bit, every gradient to the order of
+    the fp32 sums.  Cases: the bench's regime (default init, raw_noise_std 1: about half the points live), every point live
+    (density bias +5, no noise), no point live (zero upstream gradient: empty list), a sharp net."""
+    from lush_nerf_amd import lib
+    kw = {"default-init": dict(n=96), "all-live": dict(n=48, alpha_bias=5.0, noise=0.), "all-dead": dict(n=48, zero_upstream=True),
+          "sharp": dict(n=48, sharp=True)}[case]
+    out_l, g_l, cnt = _march_grads(diag, 0, **kw)
+    out_d, g_d, cnt_d = _march_grads(diag, lib.VARIANT_DENSE_BWD, **kw)
+    assert cnt_d == [0, 0, 0, 0]                               # the dense march lists nothing
+    assert all(torch.equal(a, b) for a, b in zip(out_l, out_d))
+    share = (cnt[0] + cnt[2]) / max(cnt[1] + cnt[3], 1)
+    assert cnt[1] == kw["n"] * 5 * 128 and cnt[3] == kw["n"] * 5 * 64, cnt
+    if case == "default-init":
+        assert 0.3 < share < 0.7, share
+    elif case == "all-live":
+        assert share > 0.999, share
+    elif case == "all-dead":
+        assert share == 0.0, share
+    num = den = 0.0
+    worst, wk = 0.0, ""
+    for k, a in g_l.items():
+        b = g_d[k]
+        assert (a is None) == (b is None), k
+        if a is None:
+            continue
+        assert torch.isfinite(a).all(), k
+        if case == "all-dead":
+            assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0, k
+            continue
+        e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        if e > worst:
+            worst, wk = e, k
+        num += float((a.double() - b.double()).pow(2).sum())
+        den += float(b.double().pow(2).sum())
+    if case != "all-dead":
+        l2 = (num / den) ** 0.5
+        print(f"live-point march [{case}]: {share:.3f} of the points live; gradients against the dense march: L2 {l2:.1e}, worst tensor {wk} {worst:.1e}")
+        assert l2 < 1e-5 and worst < 2e-3, (l2, wk, worst)
+
+
+def test_trainer_falls_back_to_the_dense_backward_when_most_points_are_live(diag):
+    """The live-point march costs one forward over all the points more than the dense one: while more than Trainer.LIVE_MAX_SHARE
+    of the points are live the trainer runs the dense backward (and looks again every LIVE_PROBE_EVERY steps); the share arrives
+    through pinned snapshots, nothing blocks."""
+    from lush_nerf_amd import ops, synth
+    from lush_nerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    net = diag._nerf_all(64, 5, sharp=False, precision=ops.Precision(ops.PLANES_F16, ops.PLANES_F16, 0), rbk_scale=2.0e4)
+    with torch.no_grad():
+        net.mlp_coarse.alpha_linear.bias.fill_(6.0)
+        net.mlp_fine.alpha_linear.bias.fill_(6.0)
+    tr = Trainer(net, diag.H, diag.W, diag.F, 64, 64, kernel_start_iter=0, allkernel_start_iter=0, lrate=0.0)
+    tr.LIVE_PROBE_EVERY = 4
+    b = {k: diag.gpu(v) for k, v in diag.batch_of(512, 5).items()}
+    modes = []
+    for i in range(12):
+        before = tr.live_counts()
+        tr.step(b, i)
+        torch.cuda.synchronize()
+        after = tr.live_counts()
+        modes.append("live" if after[1] > before[1] else "dense")
+    assert tr.live_share is not None and tr.live_share > 0.95, tr.live_share
+    assert modes[0] == "live" and "dense" in modes[1:4], modes           # switched as soon as the first share arrived
+    assert modes.count("live") >= 3 and modes.count("dense") >= 6, modes  # ... and probes every fourth step
+    tr.live_policy = "live"
+    before = tr.live_counts()
+    tr.step(b, 12)
+    assert tr.live_counts()[1] > before[1]
+
+    # the same under step_graph: one captured step per backward choice, the choice made on the host outside the capture
+    def make():
+        n2 = diag._nerf_all(64, 5, sharp=False, precision=ops.Precision(ops.PLANES_F16, ops.PLANES_F16, 0), rbk_scale=2.0e4)
+        with torch.no_grad():
+            n2.mlp_coarse.alpha_linear.bias.fill_(6.0)
+            n2.mlp_fine.alpha_linear.bias.fill_(6.0)
+        t = Trainer(n2, diag.H, diag.W, diag.F, 64, 64, kernel_start_iter=0, allkernel_start_iter=0)
+        t.LIVE_PROBE_EVERY = 4
+        return t
+    A, B = make(), make()
+    la, lb, mb = [], [], []
+    for i in range(16):
+        la.append(float(A.step(b, i)))
+        torch.cuda.synchronize()
+        before = B.live_counts()
+        lb.append(float(B.step_graph(b, i)))
+        torch.cuda.synchronize()
+        mb.append("live" if B.live_counts()[1] > before[1] else "dense")
+    assert B._graph is not None and set(B._graph["sub"]) == {False, True}, (B._graph and list(B._graph["sub"]), mb)
+    assert mb.count("live") >= 3 and mb.count("dense") >= 8, mb
+    assert A.steps == B.steps and A.global_step == B.global_step and A.model.hooks.draw_offset == B.model.hooks.draw_offset
+    worst = max(abs(x - y) / abs(x) for x, y in zip(la, lb))
+    print(f"step_graph under the live / dense policy ({' '.join(m[0] for m in mb)}): losses within {worst:.1e} of sixteen eager steps")
+    assert worst < 5e-5, (worst, la, lb)
 
 
 def test_march_through_the_c_abi_alone(diag):
