@@ -19,7 +19,10 @@ planes = ("h" if _pf.startswith("fp16") else _pf.replace("bf16x", "")) + "," + (
 steps = bench.get("steps", 4) * (2 if "kernel_timing" in bench else 1) + bench.get("warmup", 2)
 steps += (bench.get("sustained") or {}).get("steps", 0)      # round 5: the >= 3 s of steps behind the timed region (collect.sh passes --sustained 0)
 
-GROUP = {"mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
+# (checked in this order: the round-5 march runs the wide forward twice -- over all the points without a stash, then with the stash
+#  on the live points; the last template argument tells them apart)
+GROUP = {"mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 0>": "mlp_fwd_all", "mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 1>": "mlp_fwd",
+         "mlp_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_chain_fwd_half_kernel<lush::NetT<256": "mlp_fwd", "mlp_chain_bwd_half_kernel<lush::NetT<256": "mlp_bwd_chain",
          "mlp_wide_fwd_kernel<lush::NetT<256": "mlp_fwd", "mlp_wide_bwd_kernel<lush::NetT<256": "mlp_bwd_chain",
@@ -85,12 +88,21 @@ if per:
     alg = {"mlp_fwd": evals * (sp * xs(sp) + 16), "mlp_bwd_chain": evals * (pb * zs(pb) + 336),
            "mlp_bwd_weights": evals * pb * (xs(pb) + zs(pb))}
     lps = {k: v["launches_per_step"] for k, v in bench.get("kernels", {}).items()}
-    for g in ("mlp_fwd", "mlp_bwd_chain", "mlp_bwd_weights"):
+    names = ("mlp_fwd", "mlp_bwd_chain", "mlp_bwd_weights")
+    if "mlp_fwd_all" in bench.get("kernels", {}):
+        # live-point march: the stash-side kernels run on the live points of each step only -- the algorithmic bytes are the bench
+        # line's own (bytes per point of this design x the points each launch processed, from its kernel-group pass)
+        names = ("mlp_fwd_all",) + names
+        alg = {k: v["hbm_gbs_algorithmic"] * 1e9 * v["avg_ms"] * 1e-3 * v["launches_per_step"] for k, v in bench["kernels"].items()}
+    for g in names:
         fe, wr = per.get("FETCH_SIZE", {}).get(g, 0.0) / steps, per.get("WRITE_SIZE", {}).get(g, 0.0) / steps
         lines.append(f"| {g} | {fe / 1e9:.2f} | {wr / 1e9:.2f} | {(fe + wr) / 1e9:.2f} | {alg[g] / 1e9:.2f} |")
         traffic[f"{g}:{planes}"] = {"hbm_bytes_per_launch_group": round((fe + wr) / max(lps.get(g, 2.0), 1e-9)),
-                                    "hbm_bytes_per_step": round(fe + wr), "algorithmic_bytes_per_step": alg[g],
+                                    "hbm_bytes_per_step": round(fe + wr), "algorithmic_bytes_per_step": round(alg[g]),
                                     "source": f"profiles/{tag}_summary.md"}
+    if bench.get("live_points"):
+        lines.append(f"\n(Live-point march: {bench['live_points']['share']:.3f} of the points were live in the timed steps; the counters are totals over "
+                     f"all {steps} steps of the process, the algorithmic column is the kernel-group pass's points.)")
     json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 if bench:
     json.dump(bench, open(os.path.join(root, "profiles", f"{tag}_bench_line.json"), "w"), indent=1)

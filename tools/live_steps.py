@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool (needs a GPU): per-step GPU time (HIP events, no synchronisation inside the loop) and live share of bench.py's
-headline configuration, to see what a fresh box does to the first steps."""
+"""Developer tool (needs a GPU): per-step GPU time (HIP events, no synchronisation inside the loop) and share of live points of
+bench.py's headline configuration over STEPS steps of training on the synthetic targets (profiles/r05_live_points.md).
+VARIANT=256 (LUSH_VARIANT_DENSE_BWD): the same steps with the backward over all the points.  POLICY=auto|live|dense."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,6 +39,16 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(N)]
 sh = [(a[0] + a[2]).item() / max((a[1] + a[3]).item(), 1) for a in accs]
-print(f"variant {variant}: wall {wall / N * 1e3:.2f} ms/step; first 20 steps {sum(ms[:20]) / 20:.2f} ms")
-print(" ".join(f"{m:.1f}({s:.2f})" for m, s in zip(ms, sh)))
+import numpy as np
+print(f"variant {variant}, policy {tr.live_policy}: wall {wall / N * 1e3:.3f} ms/step over {N} steps; first 20 steps {sum(ms[:20]) / 20:.3f} ms/step "
+      f"(live share {sum(sh[:20]) / 20:.3f})")
+if any(sh):
+    A = np.stack([np.ones(N), np.array(sh)], 1)
+    (a, b), *_ = np.linalg.lstsq(A, np.array(ms), rcond=None)
+    print(f"least squares over the {N} steps: ms/step = {a:.2f} + {b:.2f} x share (residual rms {float(np.sqrt(np.mean((A @ [a, b] - np.array(ms)) ** 2))):.3f} ms)")
+print("| steps | ms/step (mean) | live share (mean) | min .. max share |\n|---|---|---|---|")
+B = max(N // 20, 1)
+for k in range(0, N, B):
+    m, q = ms[k:k + B], sh[k:k + B]
+    print(f"| {5 + k} .. {5 + k + len(m) - 1} | {sum(m) / len(m):.3f} | {sum(q) / len(q):.3f} | {min(q):.3f} .. {max(q):.3f} |")
 dist.destroy_process_group()

@@ -56,16 +56,22 @@ def blocks():
                  f"whole step {frac:.2f} of the dense bf16 MFMA peak; dominant kernel `{drv['roofline']['kernel']}` at {drv['roofline']['frac']:.2f} of "
                  f"the {drv['roofline']['bound'].upper()} roof; CPU oracle on the box's {cpu.get('cores', '?')} host threads {cpu.get('value', 0):.1f} rays/s).")
     if line:
+        lp = line.get("live_points")
         s.append(f"This round's profiled run (`profiles/{tag}_bench_line.json`, another box, inside `rocprofv3`): {line['value']:,.0f} rays/s, "
-                 f"{line['ms_per_step']:.3f} ms/step; un-profiled runs of the same tree on this round's boxes: DESIGN.md section 5.")
+                 f"{line['ms_per_step']:.3f} ms/step" + (f" with the live-point backward ({lp['share']:.2f} of the points live in its timed steps; the driver's "
+                 f"file above predates it)" if lp else "") + "; un-profiled runs of the same tree on this round's boxes: DESIGN.md section 5.")
     out["status"] = "\n".join(s)
     # ---- kernel table
     if line:
         rows = ["| group | launches / step | avg launch ms (HIP events) | algorithmic TFLOP/s (of 2.5 PF) | algorithmic HBM GB/s (of 8 TB/s) | PMC HBM GB / step (algorithmic) |",
                 "|---|---|---|---|---|---|"]
         tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json")) else {}
-        label = {"mlp_bwd_weights": "dW (`dw_group_kernel`)", "mlp_fwd": "forward (`mlp_wide_fwd_kernel`)", "mlp_bwd_chain": "dX chain (`mlp_wide_bwd_kernel`)"}
-        for g in ("mlp_bwd_weights", "mlp_fwd", "mlp_bwd_chain"):
+        live = "mlp_fwd_all" in line["kernels"]
+        label = {"mlp_bwd_weights": "dW (`dw_group_kernel`)" + (", live points" if live else ""),
+                 "mlp_fwd": "forward with the stash (`mlp_wide_fwd_kernel<.., 1>`)" + (", live points" if live else ""),
+                 "mlp_fwd_all": "forward, all points, no stash (`mlp_wide_fwd_kernel<.., 0>`)",
+                 "mlp_bwd_chain": "dX chain (`mlp_wide_bwd_kernel`)" + (", live points" if live else "")}
+        for g in sorted(line["kernels"], key=lambda g: -line["kernels"][g]["ms_per_step"]):
             k = line["kernels"][g]
             t = tr.get(f"{g}:h,h", {})
             rows.append(f"| {label[g]} | {k['launches_per_step']:.0f} | {k['avg_ms']:.3f} | {k['tflops_algorithmic']:.0f} ({k['frac_mfma']:.2f}) | "
@@ -75,25 +81,29 @@ def blocks():
             avg = {r["kernel"]: float(r["avg_ms"]) for r in csv.DictReader(open(stats))}
             pick = lambda key: next((v for k, v in avg.items() if key in k), None)
             rows.append("")
+            fw = (f"`mlp_wide_fwd_kernel<.., 0>` {pick('mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 0>'):.3f} ms, `mlp_wide_fwd_kernel<.., 1>` "
+                  f"{pick('mlp_wide_fwd_kernel<lush::NetT<256, 8, 5>, 1>'):.3f} ms") if live else f"`mlp_wide_fwd_kernel` {pick('mlp_wide_fwd_kernel'):.3f} ms"
             rows.append(f"`rocprofv3 --kernel-trace --stats` of the same run (`profiles/{tag}_bench_kernel_stats.csv`), average launch: "
-                        f"`dw_group_kernel<true,true,1>` {pick('dw_group_kernel<true'):.3f} ms, `mlp_wide_fwd_kernel` {pick('mlp_wide_fwd_kernel'):.3f} ms, "
+                        f"`dw_group_kernel<true,true,1>` {pick('dw_group_kernel<true'):.3f} ms, {fw}, "
                         f"`mlp_wide_bwd_kernel` {pick('mlp_wide_bwd_kernel'):.3f} ms.")
         k = line["kernels"]
         big = sum(v["ms_per_step"] for v in k.values())
-        rows.append(f"Whole step: {line['step_tflops_algorithmic']:.0f} TFLOP/s algorithmic = {line['step_frac_mfma']:.2f} of the dense bf16 MFMA peak; "
-                    f"the three groups sum to {big:.2f} of the step's {line['ms_per_step']:.2f} ms.")
+        ex = f" ({line['step_tflops_executed']:.0f} TFLOP/s executed = {line['step_frac_mfma_executed']:.2f}: a skipped dead point earns nothing there)" if "step_frac_mfma_executed" in line else ""
+        rows.append(f"Whole step: {line['step_tflops_algorithmic']:.0f} TFLOP/s algorithmic = {line['step_frac_mfma']:.2f} of the dense bf16 MFMA peak{ex}; "
+                    f"the {len(k)} groups sum to {big:.2f} of the step's {line['ms_per_step']:.2f} ms (kernel-group pass and timed region see "
+                    f"different live shares).")
         out["kernels"] = "\n".join(rows)
     # ---- SQ counters
     sq = os.path.join(ROOT, "profiles", f"{tag}_sq_counters.md") if tag else None
     if sq and os.path.exists(sq):
         txt = open(sq).read()
         rows = ["| kernel | non-MFMA instructions per MFMA | matrix pipe busy / wave cycles | issuing | issue-stalled | parked in waits | LDS conflict share |", "|---|---|---|---|---|---|---|"]
-        for m in re.finditer(r"## (\S+)[^\n]*\n(?:.*\n)*?Derived: ([^\n]*)", txt):
-            d = m.group(2)
+        for m in re.finditer(r"## (\S+)([^\n]*)\n(?:.*\n)*?Derived: ([^\n]*)", txt):
+            d = m.group(3)
             g = lambda pat: (re.search(pat, d) or [None, "?"])[1]
             cols = [g(r"per MFMA ([\d.]+)"), g(r"wave cycles = ([\d.]+)"), g(r"issuing (\d+%)"), g(r"issue-stalled (\d+%)"),
                     g(r"s_barrier (\d+%)"), g(r"active cycles ([\d.]+%)")]
-            rows.append("| `" + m.group(1) + "` | " + " | ".join(cols) + " |")
+            rows.append("| `" + m.group(1) + "`" + (", no stash (the pass over all the points)" if "no stash" in m.group(2) else ", stash on" if "stash on" in m.group(2) else "") + " | " + " | ".join(cols) + " |")
         rows.append(f"\n(`profiles/{tag}_sq_counters.md`, `profiles/summarize_sq.py`; per-launch counter values, fine-pass shape.)")
         out["sq"] = "\n".join(rows)
     # ---- launches of one timed step
