@@ -220,7 +220,7 @@ def self_launch(a):
     import socket
     import subprocess
     n_dev = torch.cuda.device_count()
-    if n_dev < a.gpus:
+    if n_dev < a.gpus and not getattr(a, "rehearse_on_one_gpu", False):
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -257,6 +257,9 @@ def main():
     ap.add_argument("--sustained", type=float, default=3.0, help="seconds of back-to-back headline steps behind the timed region, reported "
                     "under `sustained` (0 to skip)")
     ap.add_argument("--no-dense", action="store_true", help="skip the comparison run with the backward over all the points (dense_backward)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="developer: run the N ranks of --gpus N on the GPUs that exist "
+                    "(rank r on device r mod count), collectives over gloo -- a rehearsal of the multi-rank control flow on a one-GPU box; "
+                    "the line says so under `rehearsal` and is not a measurement")
     ap.add_argument("--cpu-n-rand", type=int, default=512, help="input rays of the CPU baseline's kernel-on step (SURVEY 8d: 512)")
     ap.add_argument("--config", type=str, default="C2", choices=["C2", "C3", "C5"],
                     help="BASELINE config timed as the headline workload (C2 = the one the metric is quoted on)")
@@ -277,6 +280,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the reported n_gpus must be the RCCL world size")
+    if a.rehearse_on_one_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py needs an MI355X per rank (no CPU fallback of the product path): rank {rank} has no device")
     torch.cuda.set_device(local_rank)
@@ -284,7 +289,10 @@ def main():
     # the RCCL group exists at every N (at N = 1 the all-reduce is a one-rank collective): the timed path is the same code
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.rehearse_on_one_gpu:      # RCCL refuses two ranks on one device: the rehearsal's collectives run over gloo
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if dist.get_world_size() != a.gpus:
         raise SystemExit(f"RCCL world size {dist.get_world_size()} != --gpus {a.gpus}")
 
@@ -374,7 +382,9 @@ def main():
             net.hooks.timer = None
         sustained = None
         if sustained_s > 0:
-            cycles = max(1, int(sustained_s / max(dt, 1e-6)) + 1)
+            cdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(cdt, op=dist.ReduceOp.MAX)      # (every rank runs the same number of cycles: each step holds a collective)
+            cycles = max(1, int(sustained_s / max(float(cdt.item()), 1e-6)) + 1)
             live1 = tr.live_counts()
             sync()
             t1 = time.perf_counter()
@@ -636,6 +646,9 @@ def main():
                         "more ReLU kinks), backward plain bf16 -- optional faster mode, not the headline"}
         if a.so:
             out["library"] = os.path.abspath(a.so)
+        if a.rehearse_on_one_gpu:
+            out["rehearsal"] = (f"{world} ranks time-sharing {torch.cuda.device_count()} GPU(s), collectives over gloo: the multi-rank control "
+                                "flow of this script, NOT a measurement")
         if others:
             out["modes"] = {m: {"value": round(a.n_rand * world * osteps / odt, 1),
                                 "ms_per_step": round(odt / osteps * 1e3, 3),

@@ -534,8 +534,13 @@ _TWO_RANK = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
 import torch, torch.distributed as dist
-rank = int(os.environ["RANK"]); torch.cuda.set_device(rank); dev = torch.device("cuda", rank)
-dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+rank = int(os.environ["RANK"])
+ndev = torch.cuda.device_count()
+idx = rank % ndev; torch.cuda.set_device(idx); dev = torch.device("cuda", idx)
+if ndev >= 2:
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+else:      # one-GPU box: both ranks share the card (RCCL refuses two ranks on one device), the collective runs over gloo
+    dist.init_process_group("gloo", rank=rank, world_size=2)
 from lush_nerf_amd import lib, ops, synth
 from lush_nerf_amd.trainer import Trainer
 import bench
@@ -568,11 +573,11 @@ open(os.path.join(sys.argv[2], f"r{rank}.ok"), "w").write("ok")
 '''
 
 
-def test_trainer_over_rccl_two_ranks(diag, tmp_path):
-    """Two ranks over RCCL (skipped on a one-GPU box; the driver's scaling run exercises N = 2, 4, 8)."""
+def test_trainer_two_ranks(diag, tmp_path):
+    """Two ranks, one process each: over RCCL with two GPUs; on a one-GPU box both ranks run their HIP kernels on the one card
+    and the flat gradient's all-reduce goes over gloo -- the same Trainer code (broadcast at construction, one all-reduce per
+    step, 1 / world folded into Adam), the reference's DataParallel semantics checked against one rank on the concatenated batch."""
     import os, subprocess, sys, socket
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "two.py"
     script.write_text(_TWO_RANK)
@@ -582,6 +587,30 @@ def test_trainer_over_rccl_two_ranks(diag, tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", port, str(script), root, str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_two_ranks_rehearsal(diag, tmp_path):
+    """bench.py's multi-rank control flow with real kernels on the box we have: `--gpus 2` starts two ranks itself; with
+    `--rehearse-on-one-gpu` both use the one card and the collectives go over gloo.  What it pins: no rank-dependent loop count
+    in front of a collective (every step of every pass holds one: warm-up, timed region, kernel-group pass, sustained cycles,
+    the dense-backward comparison, the other modes), ONE JSON line from rank 0 with n_gpus = 2 and the whole-job value, the
+    `n1_only` and `rehearsal` notes.  Not a measurement."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "2",
+                        "--n-rand", "1024", "--no-cpu-baseline", "--also=2,2", "--sustained", "0.3"], capture_output=True, text=True,
+                       timeout=420, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "rehearsal" in d and "n1_only" in d
+    assert d["config"]["parallelism"] == "dp2" and d["live_points"]["share"] > 0.2
+    assert d["dense_backward"]["ms_per_step"] > 0 and d["sustained"]["steps"] % 3 == 0 and "2,2" in d["modes"]
+    print(f"bench.py --gpus 2 rehearsed on one GPU: {d['ms_per_step']} ms/step of two time-shared ranks, all-reduce {d['allreduce_ms']} ms over gloo")
 
 
 @pytest.mark.parametrize("kernel_on", [True, False])
