@@ -621,18 +621,13 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         // fill the chip once -- one round of atomics in all, 1 / slices of the contenders per address (the same pass: 0.15 ms;
         // 4 096 points 0.107 -> 0.064 ms).  Above it a job's streaming time hides its atomics and every workgroup takes every job of
         // its slice in turn, which balances the narrow jobs.
-#ifndef LUSH_DW_PERJOB_MAX_PTS
-#define LUSH_DW_PERJOB_MAX_PTS 262144
-#endif
-#ifndef LUSH_DW_PERJOB_MIN_PTS
-#define LUSH_DW_PERJOB_MIN_PTS 512      // points per slice at least (4 096 points, 11 jobs: 256 -> 70 us, 512 -> 64 us, 1024 -> 88 us)
-#endif
+        // (LUSH_DW_PERJOB_MAX_PTS / _MIN_PTS: lush_mlp.h; a live-point launch makes the same choice on the device)
         int splits = dw_splits(L.Ppad);
         G.per_job = 0;
         G.live_cnt = live_cnt;
         int dev = 0, cus = 256;
         if (current_device_cus(dev, cus) != 0) cus = 256;
-        if (L.Ppad <= LUSH_DW_PERJOB_MAX_PTS && !live_cnt) {      // (a live-point launch walks: its size is known on the device only)
+        if (L.Ppad <= LUSH_DW_PERJOB_MAX_PTS && !live_cnt) {      // (a live-point launch decides in the kernel: its size is known on the device only)
             long long sp = cus / G.n, most = L.Ppad / LUSH_DW_PERJOB_MIN_PTS;
             if (sp > most) sp = most;
             splits = sp < 1 ? 1 : (int)sp;

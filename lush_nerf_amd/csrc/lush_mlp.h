@@ -231,6 +231,14 @@ struct DwJob {
     int pps;                                                // DwGroup::per_job == 2: points per slice of THIS job (multiple of 32)
 };
 enum { DW_MAX_JOBS = 12 };
+// Passes of at most LUSH_DW_PERJOB_MAX_PTS points run ONE job per workgroup with slices of at least LUSH_DW_PERJOB_MIN_PTS points
+// (4 096 points, 11 jobs: 256 -> 70 us, 512 -> 64 us, 1024 -> 88 us); see lush_abi.hip (host's choice) and dw_group_kernel (live launches).
+#ifndef LUSH_DW_PERJOB_MAX_PTS
+#define LUSH_DW_PERJOB_MAX_PTS 262144
+#endif
+#ifndef LUSH_DW_PERJOB_MIN_PTS
+#define LUSH_DW_PERJOB_MIN_PTS 512
+#endif
 // A one-plane dZv row carries 8 more columns: the head gradients [d_r d_g d_b d_alpha] as a hi and a lo 16-bit plane
 // (hi = round16(x), lo = round16(x - hi): 16 / 22 bits for bf16 / fp16), scaled like dZ.  The grouped weight-gradient
 // launch then gets the K<=3 heads as 8 more GEMM rows of the feature job (row HV+3 + row HV+7 = d_alpha^T h_{NL-1}) and

@@ -1232,10 +1232,27 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
     }
     // a live-point launch (DwGroup::live_cnt) reads its point count on the device and slices it as the host would have
     int Ppad = G.Ppad, pps = G.per_job == 2 ? G.j[my_job].pps : G.pts_per_split;
+    int per_job = G.per_job;
     if (G.live_cnt != nullptr) {
         const int cnt = __builtin_amdgcn_readfirstlane(*G.live_cnt);
         Ppad = (cnt + 255) / 256 * 256;                  // (the stash arrays of a launch are padded to whole 256-point tiles)
-        pps = ((Ppad + (int)gridDim.x - 1) / (int)gridDim.x + 31) / 32 * 32;
+        if (Ppad <= LUSH_DW_PERJOB_MAX_PTS && per_job == 0 && (int)gridDim.x >= G.n) {
+            // few live points (a trained scene's empty space is dead): ONE job per workgroup on the 1-D grid, as the host chooses
+            // for a small pass it knows the size of (lush_abi.hip) -- workgroup b = (slice b / n, job b mod n), just enough slices
+            // to fill the chip once.  The walk's 256 slices x 10 jobs of fp32 atomics (0.6 GB at the chip's 1.3 TB/s: 0.45 ms
+            // whatever the point count) become slices x 2.3 MB.
+            int sp = (int)gridDim.x / G.n;
+            const int most = Ppad / LUSH_DW_PERJOB_MIN_PTS;
+            sp = sp > most ? most : sp;
+            sp = sp < 1 ? 1 : sp;
+            if ((int)blockIdx.x >= sp * G.n) return;
+            per_job = 1;
+            my_slice = (int)blockIdx.x / G.n;
+            my_job = (int)blockIdx.x % G.n;
+            pps = ((Ppad + sp - 1) / sp + 31) / 32 * 32;
+        } else {
+            pps = ((Ppad + (int)gridDim.x - 1) / (int)gridDim.x + 31) / 32 * 32;
+        }
     }
     const long long p_begin = (long long)my_slice * pps;
     long long p_end = p_begin + pps;
@@ -1255,9 +1272,9 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
 
     // (a small launch -- the 4 096-point noise net, configuration 1 -- has fewer slices than the chip has CUs and spent its time
     // walking 7-19 jobs in series, each a ring refill + a few tiles + 64 K atomics: 69 us for 0.4 GFLOP; one job per workgroup then)
-    const int j_begin = G.per_job ? my_job : 0, j_end = G.per_job ? my_job + 1 : G.n;
+    const int j_begin = per_job ? my_job : 0, j_end = per_job ? my_job + 1 : G.n;
     for (int jj = j_begin; jj < j_end; ++jj) {
-        int jsel = G.per_job ? jj : (int)((blockIdx.x + (unsigned)jj) % (unsigned)G.n);
+        int jsel = per_job ? jj : (int)((blockIdx.x + (unsigned)jj) % (unsigned)G.n);
         jsel = __builtin_amdgcn_readfirstlane(jsel);
         const DwJob A = G.j[jsel];                      // one scalar load of the whole record per job
         const bool has_x2 = A.X2 != nullptr;
@@ -1328,6 +1345,10 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
         else if (nv2 == 1) grp_stream<XF16, ZF16, 1, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
         else grp_stream<XF16, ZF16, 2, NS>(st, tiles, lds0, n_tiles, w, lane, wave_live, row_live, x2_wave, a_off, b_off, sel_off, x2_off, acc, accs);
         DPROF_T(t_flush);
+#ifdef LUSH_ABL_NOFLUSH      // timing ablation only (wrong results): the accumulators are kept alive, nothing is added
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[3][0]), "v"(acc[3][1]), "v"(accs[0]), "v"(accs[1]));
+        if (false)
+#endif
         if (row_live) {
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
@@ -1344,6 +1365,9 @@ __global__ __launch_bounds__(DW_THREADS2) void dw_group_kernel(const DwGroup G) 
                 }
             }
         }
+#ifdef LUSH_ABL_NOFLUSH
+        if (false)
+#endif
         if (wave_live) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)

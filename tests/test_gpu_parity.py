@@ -1076,16 +1076,16 @@ def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=Fals
     return [o.detach().clone() for o in (out[0], out[1], out[3], out[5])], grads, [int(x) for x in net.hooks.live_acc.tolist()]
 
 
-@pytest.mark.parametrize("case", ["default-init", "all-live", "all-dead", "sharp"])
+@pytest.mark.parametrize("case", ["default-init", "default-init-large", "all-live", "all-dead", "sharp"])
 def test_live_point_march_equals_the_dense_march(diag, case):
     """Round 5: the headline mode's march keeps no stash in its forward; its backward lists the points whose d_raw row is non-zero
     (a sample whose density pre-activation the ReLU of raw2outputs clamps has alpha = 0, weight = 0, d alpha / d raw = 0:
     models/lushnerf.py:313-327), re-runs the forward with the stash on that list and chains / forms the weight gradients there.
     Against LUSH_VARIANT_DENSE_BWD (every point stashed and chained, rounds 1-4): outputs bit for bit, every gradient to the order of
-    the fp32 sums.  Cases: the bench's regime (default init, raw_noise_std 1: about half the points live), every point live
+    the fp32 sums.  Cases: the bench's regime (default init, raw_noise_std 1: about half the points live) at two sizes, every point live
     (density bias +5, no noise), no point live (zero upstream gradient: empty list), a sharp net."""
     from lush_nerf_amd import lib
-    kw = {"default-init": dict(n=96), "all-live": dict(n=48, alpha_bias=5.0, noise=0.), "all-dead": dict(n=48, zero_upstream=True),
+    kw = {"default-init": dict(n=96), "default-init-large": dict(n=1536), "all-live": dict(n=48, alpha_bias=5.0, noise=0.), "all-dead": dict(n=48, zero_upstream=True),
           "sharp": dict(n=48, sharp=True)}[case]
     out_l, g_l, cnt = _march_grads(diag, 0, **kw)
     out_d, g_d, cnt_d = _march_grads(diag, lib.VARIANT_DENSE_BWD, **kw)
@@ -1093,8 +1093,11 @@ def test_live_point_march_equals_the_dense_march(diag, case):
     assert all(torch.equal(a, b) for a, b in zip(out_l, out_d))
     share = (cnt[0] + cnt[2]) / max(cnt[1] + cnt[3], 1)
     assert cnt[1] == kw["n"] * 5 * 128 and cnt[3] == kw["n"] * 5 * 64, cnt
-    if case == "default-init":
+    if case.startswith("default-init"):
+        # (96 rays: both passes list fewer than 2^18 points -- the weight-gradient launch takes ONE job per workgroup, chosen in the
+        #  kernel; 1 536 rays: the fine pass lists more -- every workgroup walks the jobs of its slice)
         assert 0.3 < share < 0.7, share
+        assert (cnt[0] > 262144) == (case == "default-init-large"), cnt
     elif case == "all-live":
         assert share > 0.999, share
     elif case == "all-dead":
