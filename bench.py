@@ -652,11 +652,13 @@ def main():
         if others:
             out["modes"] = {m: {"value": round(a.n_rand * world * osteps / odt, 1),
                                 "ms_per_step": round(odt / osteps * 1e3, 3),
+                                "live_points": ogroups.get("_live"),
                                 "kernels": kernel_table(ogroups, qf, qb, osteps), "note": notes.get(m, "")}
                             for m, qf, qb, odt, ogroups, osteps in others}
             if "2,2" in out["modes"]:     # the strict figure sits next to `value`, not only under modes
                 out["value_strict_2_2"] = out["modes"]["2,2"]["value"]
                 out["ms_per_step_strict_2_2"] = out["modes"]["2,2"]["ms_per_step"]
+                out["live_points_strict_2_2"] = out["modes"]["2,2"]["live_points"]      # (the live-point backward runs in every one- / two-plane mode)
         if extras:
             out["extra_configs"] = extras
         if world > 1:      # a SCALE line explains what it leaves out

@@ -30,7 +30,7 @@ typedef void* lush_stream_t;
 const char* lush_last_error(void);
 int lush_abi_version(void);   /* 10 (round 5; 9: lush_rbk_mlp_bwd consumes its d_rvw rows; 10: the live-point entry points lush_live_compact /
                              * lush_mlp_fwd_live / lush_mlp_bwd_*_live / lush_ray_grad_reduce_live, LUSH_VARIANT_DENSE_BWD,
-                             * LUSH_VIEW_LIVE_COUNTS; the march's one-fp16-plane backward runs on the live points).  Earlier: 8 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
+                             * LUSH_VIEW_LIVE_COUNTS; the march's one- and two-plane backward runs on the live points).  Earlier: 8 (round 3: explicit kernel-variant argument instead of environment switches; 6: the blur-mix / tone-map
                              * backward entry points write their outputs instead of accumulating; 7, round 4: the fused ray-level
                              * entry points lush_rbk_warp_ndc_* and lush_blur_mix_*, an explicit d_rvw row stride, and no second
                              * stream inside lush_march_bwd; 8: lush_pack_plan_run takes a buffer to clear, lush_adam_multi /
@@ -344,8 +344,8 @@ int lush_ray_grad_reduce(const float* dpts, const float* z, int R, int S, float*
 
 /* Live points (round 5).  A sample whose density pre-activation the ReLU of raw2outputs clamps (models/lushnerf.py:313:
  * relu(raw[..., 3] + noise)) has alpha = 0, weight = 0 and d alpha / d raw = 0: its d_raw row is exactly zero and nothing flows
- * back through its MLP evaluation -- with raw_noise_std = 1 and a density near zero, half of all the points.  The one-fp16-plane
- * backward of the 8x256 net runs on the live points only: lush_live_compact lists them in grid order (live_idx [R*S] int32, the
+ * back through its MLP evaluation -- with raw_noise_std = 1 and a density near zero, half of all the points.  The one- and two-plane
+ * backward of the 8x256 net (plane codes 1, 2, 17 each way) runs on the live points only: lush_live_compact lists them in grid order (live_idx [R*S] int32, the
  * first cnt[0] entries valid), gathers their d_raw rows (draw_c [R*S][4], rows behind the list zeroed) and gives ray r the range
  * [ray_start[r], ray_start[r+1]) of the list (ray_start [R+1]); cnt [2] int32 = {live points, R*S}; aux: lush_live_aux_bytes(R*S).
  * lush_mlp_fwd_live re-runs the forward with the stash on the list (its i-th point = grid point live_idx[i]; no raw output),

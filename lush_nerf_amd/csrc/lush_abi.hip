@@ -412,11 +412,13 @@ int lush_debug_stash_layout(int net, int planes, long long P, long long* o) {
     return 0;
 }
 
-// a live-point launch is the 64-points-per-wave kernels' (one fp16 plane on the 8x256 net, no older-kernel variant bit)
+// a live-point launch: the 8x256 net's one- and two-plane kernels (the 64-points-per-wave kernels of the one-fp16-plane mode and the
+// 128-point-tile chain kernels of the bf16-plane modes, with the grouped weight gradients), no older-kernel variant bit; the
+// three-plane reference mode keeps its tiled kernels and the backward over all the points
+static const int LIVE_OLDER_VARIANTS = LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_BWD_HALF | LUSH_VARIANT_BWD_512 | LUSH_VARIANT_PE_ROWS |
+                                       LUSH_VARIANT_HEAD_KERNEL | LUSH_VARIANT_DW_SPLIT;
 static bool live_kernels(int net, int planes_f, int planes_b, int variant) {
-    const int older = LUSH_VARIANT_FWD_HALF | LUSH_VARIANT_FWD_512 | LUSH_VARIANT_BWD_HALF | LUSH_VARIANT_BWD_512 | LUSH_VARIANT_PE_ROWS |
-                      LUSH_VARIANT_HEAD_KERNEL | LUSH_VARIANT_DW_SPLIT;
-    return net == 0 && planes_f == PLANES_F16 && planes_b == PLANES_F16 && !(variant & older);
+    return net == 0 && mlp_fwd_chain_enabled(planes_f) && mlp_bwd_chain_enabled(planes_b) && !(variant & LIVE_OLDER_VARIANTS);
 }
 
 static int mlp_fwd_impl(int net, int planes, int stash_planes, const float* rays, const float* z, int R, int S,
@@ -459,7 +461,7 @@ static int mlp_fwd_impl(int net, int planes, int stash_planes, const float* rays
     a.live_idx = live_idx; a.live_cnt = live_cnt;
     if (live_idx || live_cnt) {
         if (!live_idx || !live_cnt) return set_error("lush_mlp_fwd_live: the list and its count come together");
-        if (!live_kernels(net, planes, stash_planes == 1 ? PLANES_F16 : 0, variant) || !chain) return set_error("lush_mlp_fwd_live: one fp16 plane with the stash, 8x256 net, the product's kernels only");
+        if (net != 0 || !chain || (variant & LIVE_OLDER_VARIANTS) || stash_planes < 1) return set_error("lush_mlp_fwd_live: the 8x256 net's one- or two-plane kernels with the stash, no older-kernel variant");
     }
     if (chain) return launch_mlp_chain_fwd(net, planes, a, variant, (hipStream_t)stream);
     const int grid = a.n_tiles < 1024 ? a.n_tiles : 1024;
@@ -484,7 +486,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
                         int do_weights, int prepared = 0, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
     NetInfo n;
     if (!net_info(net, n)) return set_error("lush_mlp_bwd: bad net");
-    if (live_cnt && !live_kernels(net, planes_f, planes_b, variant)) return set_error("lush_mlp_bwd (live points): one fp16 plane each way, 8x256 net, the product's kernels only");
+    if (live_cnt && !live_kernels(net, planes_f, planes_b, variant)) return set_error("lush_mlp_bwd (live points): the 8x256 net's one- or two-plane kernels, no older-kernel variant");
     const bool x_f16 = planes_f == PLANES_F16;     // the stash was written by the fp16 forward
     if (x_f16) planes_f = 1;
     const bool z_f16 = planes_b == PLANES_F16;     // loss-scaled fp16 gradient chain (one plane)
@@ -705,7 +707,7 @@ static int mlp_bwd_impl(int net, int planes_f, int planes_b, const float* rays, 
         rc = launch_feat_factor(F, st);
         if (rc || fold) return rc;
         return launch_head_dw(planes_b, x_f16, draw, P, hv, plane_hv, n.HV, H(n.NL - 1), plane_h, n.HW, g->w_rgb, g->b_rgb,
-                              net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st);
+                              net == 0 ? g->w_alpha : nullptr, net == 0 ? g->b_alpha : nullptr, st, live_cnt);
     }
     // three planes (test reference): one launch per layer
     for (int l = 0; l < n.NL && !rc; ++l) {

@@ -79,6 +79,6 @@ int launch_feat_factor(const FeatFactorArgs& a, hipStream_t s);
 int launch_grad_scale(const float* draw, long long n, float* scale, float* zero_buf, long long zero_n, hipStream_t s);
 int launch_head_dw(int ns, bool x_f16, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
-                   float* db_alpha, hipStream_t s);
+                   float* db_alpha, hipStream_t s, const int* live_cnt = nullptr);
 
 }  // namespace lush

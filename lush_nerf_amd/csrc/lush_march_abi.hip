@@ -29,7 +29,8 @@ struct Layout {
     bool live;                                   // the backward re-runs the forward on the live points (the forward call keeps no stash)
 };
 
-// The headline mode's march (one fp16 plane each way, the 64-points-per-wave kernels) keeps NO stash in its forward: the
+// The march of every one- / two-plane mode (the 64-points-per-wave kernels of (h,h), the 128-point chain kernels of the bf16-plane
+// modes) keeps NO stash in its forward: the
 // backward lists the points whose d_raw row is non-zero, re-runs the forward with the stash on that list and chains / forms the
 // weight gradients on it (include/lush_march.h "Live points").  LUSH_VARIANT_DENSE_BWD keeps the rounds 1-4 form.
 inline bool live_mode(const lush_march_cfg* c) {

@@ -179,7 +179,7 @@ struct MlpFwdArgs {
     long long plane_pe, plane_h, plane_hv;   // plane strides in elements
     int write_stash;
     int stash_planes;              // planes copied to the stash (<= NS): what the backward will use
-    // Live-point launches (round 5; the 64-points-per-wave kernels only): point i of the launch is point live_idx[i] of the
+    // Live-point launches (round 5; the 64-points-per-wave and the 128-point chain kernels of the 8x256 net): point i of the launch is point live_idx[i] of the
     // [R][S] grid, the point count is read from *live_cnt on the device (P / n_tiles then are upper bounds: the grid's size),
     // `raw` is not written (the caller has it from the pass over all points).  Both null: a launch over all the points.
     const int* live_idx;

@@ -1449,7 +1449,8 @@ __global__ __launch_bounds__(DW_THREADS) void head_dw_kernel(const float* __rest
                                                             const __bf16* __restrict__ hl, long long plane_h, int HW,
                                                             int pts_per_block, float* __restrict__ dw_rgb,
                                                             float* __restrict__ db_rgb, float* __restrict__ dw_alpha,
-                                                            float* __restrict__ db_alpha) {
+                                                            float* __restrict__ db_alpha, const int* __restrict__ live_cnt) {
+    if (live_cnt != nullptr) P = *live_cnt;      // (a live-point launch: the rows behind the list hold whatever an earlier launch left)
     const int nchv = HV / 8, nch = nchv + (dw_alpha ? HW / 8 : 0);
     const int rows = DW_THREADS / nch;
     const int c = threadIdx.x % nch, rr = threadIdx.x / nch;
@@ -1786,13 +1787,13 @@ int launch_grad_scale(const float* draw, long long n, float* scale /* {scale, 1/
 
 int launch_head_dw(int ns, bool x_f16, const float* draw, long long P, const __bf16* hv, long long plane_hv, int HV,
                    const __bf16* hl, long long plane_h, int HW, float* dw_rgb, float* db_rgb, float* dw_alpha,
-                   float* db_alpha, hipStream_t s) {
+                   float* db_alpha, hipStream_t s, const int* live_cnt) {
     const int ppb = 1024;     // measured on the fine pass (2.6 M points): 128 -> 661 us, 512 / 1024 -> 503, 2048 -> 617, 8192 -> 1097
     const int blocks = (int)((P + ppb - 1) / ppb);
-    if (x_f16) hipLaunchKernelGGL((head_dw_kernel<1, true>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else if (ns == 1) hipLaunchKernelGGL((head_dw_kernel<1, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else if (ns == 2) hipLaunchKernelGGL((head_dw_kernel<2, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
-    else hipLaunchKernelGGL((head_dw_kernel<3, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha);
+    if (x_f16) hipLaunchKernelGGL((head_dw_kernel<1, true>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha, live_cnt);
+    else if (ns == 1) hipLaunchKernelGGL((head_dw_kernel<1, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha, live_cnt);
+    else if (ns == 2) hipLaunchKernelGGL((head_dw_kernel<2, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha, live_cnt);
+    else hipLaunchKernelGGL((head_dw_kernel<3, false>), dim3(blocks), dim3(DW_THREADS), 0, s, draw, P, hv, plane_hv, HV, hl, plane_h, HW, ppb, dw_rgb, db_rgb, dw_alpha, db_alpha, live_cnt);
     LUSH_HIP(hipGetLastError());
     return 0;
 }

@@ -517,6 +517,12 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     char* stage = reinterpret_cast<char*>(biasl + NBIAS);   // [4 waves][4 KiB] stash transposition tiles (SPK > 0)
 
     const int tid = threadIdx.x, lane = tid & 63;
+    // (a live-point launch reads its point count on the device: include/lush_march.h "Live points")
+    int P = A.P, n_tiles = A.n_tiles;
+    if (A.live_cnt != nullptr) {
+        P = __builtin_amdgcn_readfirstlane(*A.live_cnt);
+        n_tiles = (P + 255) / 256 * 256 / CH_MT;      // (whole 256-point blocks, as the host pads a launch: the weight gradients read them)
+    }
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const char* wbase = reinterpret_cast<const char*>(A.wpk);
@@ -546,13 +552,13 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * CH_MT;
         const long long gpt = pt0 + row;
         PROF_T(t_pe);
         const long long wpt = pt0 + w * 32;            // this wave's first point
 #ifndef LUSH_ABL_NOPE    // timing ablation only (wrong results)
-        pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
+        pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, P, pt0, tid, A.live_idx);
 #endif
         wait_vm<0>();      // first tile: the prologue DMAs; later tiles: already published by the last mid-step
         lds_barrier();
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_fwd_kernel(const MlpFwdArgs A
         ch_bias<1>(ar, biasl + N::f32_b_rgb, h);
         if constexpr (SPK > 0) ch_stash_all<NS, SPK, N::KKV, KKH, HV>(xin, tile_w, A.hv + wpt * HV, A.plane_hv, lane);
         ch_phase<N, NS, DT, HAS_ALPHA, 1, SC::G_R, SC::NP_R, B_REG, false, SC::T_R, KKH>(cx, ar, xin, peimg, row);
-        if (h == 0 && gpt < A.P) {
+        if (h == 0 && gpt < P && A.live_idx == nullptr) {      // (a live-point launch re-runs the forward for its stash only)
             float4 o;
             o.x = ar[0][0];
             o.y = ar[0][1];
@@ -715,6 +721,12 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
     char* stage = peimg + PE_PLANE;                     // [4 waves][4 KiB] stash transposition tiles
 
     const int tid = threadIdx.x, lane = tid & 63;
+    // (a live-point launch reads its point count on the device: include/lush_march.h "Live points")
+    int P = A.P, n_tiles = A.n_tiles;
+    if (A.live_cnt != nullptr) {
+        P = __builtin_amdgcn_readfirstlane(*A.live_cnt);
+        n_tiles = (P + 255) / 256 * 256 / CH_MT;      // (whole 256-point blocks, as the host pads a launch: the weight gradients read them)
+    }
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const char* wbase = reinterpret_cast<const char*>(A.wpk);
@@ -747,12 +759,12 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
     }
     const float* const bias = SPK == 0 ? reinterpret_cast<const float*>(stage) : f32b;
 
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * CH_MT;
         const long long gpt = pt0 + row;
         const long long wpt = pt0 + w * 32;
 #ifndef LUSH_ABL_NOPE    // timing ablation only (wrong results)
-        pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, A.P, pt0, tid);
+        pe_tile<NS, CH_MT, CH_NT, DT>(peimg, PE_PLANE, PE_ROW * 2, A.rays, A.z, A.S, P, pt0, tid, A.live_idx);
 #endif
         wait_vm<0>();      // first tile: the prologue DMAs; later tiles: already published by the last mid-step
         lds_barrier();
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_fwd_half_kernel(const MlpF
         ch_bias_g<1>(ar, bias + N::f32_b_rgb, h);
         if constexpr (SPK > 0) ch_stash_all<NS, SPK, N::KKV, KKH, HV>(xin, tile_w, A.hv + wpt * HV, A.plane_hv, lane);
         ChPhase<SC, NS, DT, 1, SC::G_R, SC::NP_R, B_REG, true, 0, KKH, 0, 1>::run(cx, ar, xin, peimg, row, nullptr, nullptr, 0);
-        if (h == 0 && gpt < A.P) {
+        if (h == 0 && gpt < P && A.live_idx == nullptr) {      // (a live-point launch re-runs the forward for its stash only)
             float4 o;
             o.x = ar[0][0];
             o.y = ar[0][1];
@@ -975,6 +987,12 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
     float* wtab = dxbuf + PARTS * CH_MT * 6;                        // w_rgb [3][HV] | w_alpha [HW]
 
     const int tid = threadIdx.x, lane = tid & 63;
+    // (a live-point launch reads its point count on the device: include/lush_march.h "Live points")
+    int P = A.P, n_tiles = A.n_tiles;
+    if (A.live_cnt != nullptr) {
+        P = __builtin_amdgcn_readfirstlane(*A.live_cnt);
+        n_tiles = (P + 255) / 256 * 256 / CH_MT;      // (whole 256-point blocks, as the host pads a launch: the weight gradients read them)
+    }
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const char* wbase = reinterpret_cast<const char*>(A.wpk);
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * CH_MT;
         const long long gpt = pt0 + row;
         const long long wpt = pt0 + w * 32;
@@ -1029,7 +1047,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
             for (int rb = 0; rb < NRB; ++rb) mw[rb] = rb < nb ? (unsigned)m[rb * 64] : 0u;
         };
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gpt < A.P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
+        if (gpt < P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
         if constexpr (DT == DT_F16) { dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale; }
         wait_vm<0>();          // first tile: the prologue DMAs (later tiles: published by the last mid-step)
         lds_barrier();         // also orders wtab and the previous tile's dpe/dxbuf traffic
@@ -1116,7 +1134,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
             const int pt = tid % CH_MT, part = tid / CH_MT;
             const long long gp = pt0 + pt;
             float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-            if (gp < A.P) point_of(A.rays, A.z, A.S, gp, x, d);
+            if (gp < P) point_of(A.rays, A.z, A.S, A.live_idx ? (long long)A.live_idx[gp] : gp, x, d);
             float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
             const float* g = dpe + pt * BW_DPE_LD;
             for (int u = part; u < L_X + L_D; u += PARTS) {
@@ -1144,7 +1162,7 @@ __global__ __launch_bounds__(CH_NT) void mlp_chain_bwd_kernel(const MlpBwdArgs A
 #pragma unroll
             for (int p = 0; p < PARTS; ++p) sum += dxbuf[(p * CH_MT + pt) * 6 + c];
             const long long gp = pt0 + pt;
-            if (gp < A.P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum * ginv;
+            if (gp < P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum * ginv;
         }
         PROF_ADD(1, t_pe);
     }
@@ -1202,6 +1220,12 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
     static_assert(PARTS * CH_MT * 6 * 4 <= CH_NW * 4096, "the reduction scratch must fit the stash tiles");
 
     const int tid = threadIdx.x, lane = tid & 63;
+    // (a live-point launch reads its point count on the device: include/lush_march.h "Live points")
+    int P = A.P, n_tiles = A.n_tiles;
+    if (A.live_cnt != nullptr) {
+        P = __builtin_amdgcn_readfirstlane(*A.live_cnt);
+        n_tiles = (P + 255) / 256 * 256 / CH_MT;      // (whole 256-point blocks, as the host pads a launch: the weight gradients read them)
+    }
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     const char* wbase = reinterpret_cast<const char*>(A.wpk);
@@ -1232,7 +1256,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
 #pragma unroll
         for (int j = 0; j < 8; ++j) { xin[kb][0][j] = (__bf16)0.f; xnx[kb][0][j] = (__bf16)0.f; }
 
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long pt0 = (long long)tile * CH_MT;
         const long long gpt = pt0 + row;
         const long long wpt = pt0 + w * 32;
@@ -1250,7 +1274,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
             for (int rb = 0; rb < NRBH; ++rb) mw[rb] = (unsigned)m[rb * 64];
         };
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gpt < A.P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
+        if (gpt < P) dr = *reinterpret_cast<const float4*>(A.draw + gpt * 4);
         if constexpr (DT == DT_F16) { dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale; }
         wait_vm<0>();
         lds_barrier();         // also orders wtab and the previous tile's dpe / dxbuf traffic
@@ -1368,7 +1392,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
             const int pt = tid % CH_MT, part = tid / CH_MT;
             const long long gp = pt0 + pt;
             float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-            if (gp < A.P) point_of(A.rays, A.z, A.S, gp, x, d);
+            if (gp < P) point_of(A.rays, A.z, A.S, A.live_idx ? (long long)A.live_idx[gp] : gp, x, d);
             float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
             const __bf16* g = dpe + pt * BH_DPE_LD;
             auto gv = [&](int c) { return elem_to_f32<DT>(g[c]); };
@@ -1397,7 +1421,7 @@ __global__ __launch_bounds__(CH_NT, 2) void mlp_chain_bwd_half_kernel(const MlpB
 #pragma unroll
             for (int p = 0; p < PARTS; ++p) sum += dxbuf[(p * CH_MT + pt) * 6 + c];
             const long long gp = pt0 + pt;
-            if (gp < A.P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum * ginv;
+            if (gp < P) A.dpts[gp * 8 + (c < 3 ? c : c + 1)] = sum * ginv;
         }
     }
     wait_vm<0>();

@@ -99,12 +99,12 @@ __device__ __forceinline__ void sincos_rev(float hi, float lo, int k, float* sn,
 // values live across the MFMA loops of the whole tile)
 template <int NS, int MT, int NTHREADS, int DT>
 __device__ __noinline__ void pe_tile(char* peimg, int plane_bytes, int row_bytes, const float* rays, const float* z,
-                                        int S, int P, long long tile_pt0, int tid) {
+                                        int S, int P, long long tile_pt0, int tid, const int* live = nullptr) {
     constexpr int PARTS = NTHREADS / MT;
     const int pt = tid % MT, part = tid / MT;
     const long long gpt = tile_pt0 + pt;
     float x[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-    if (gpt < P) point_of(rays, z, S, gpt, x, d);
+    if (gpt < P) point_of(rays, z, S, live ? (long long)live[gpt] : gpt, x, d);      // (a live-point launch: its i-th point is grid point live[i])
     // units: 0..L_X-1 = frequency k of x; L_X..L_X+L_D-1 = frequency k of d; raw copies go with unit 0 / L_X
     for (int u = part; u < L_X + L_D; u += PARTS) {
         const bool isd = u >= L_X;

@@ -190,11 +190,12 @@ def mlp_forward(net: int, planes: int, tensors, packed, rays, z, want_stash: boo
 
 def live_backward(precision: "Precision", hooks: Optional["Hooks"]) -> bool:
     """The march of this mode runs its backward on the live points only (include/lush_march.h "Live points"; the same rule as
-    csrc/lush_march_abi.hip live_mode): one fp16 plane each way, the product's kernels, and no test hook that wants every
-    point's stash."""
+    csrc/lush_march_abi.hip live_mode): one or two planes each way (the three-plane reference mode keeps the backward over all
+    the points), the product's kernels, and no test hook that wants every point's stash."""
     older = lib.VARIANT_FWD_HALF | lib.VARIANT_FWD_512 | lib.VARIANT_BWD_HALF | lib.VARIANT_BWD_512 | lib.VARIANT_PE_ROWS | \
         lib.VARIANT_HEAD_KERNEL | lib.VARIANT_DW_SPLIT | lib.VARIANT_DENSE_BWD
-    return precision.fwd == PLANES_F16 and precision.bwd == PLANES_F16 and not (int(precision.variant) & older) and \
+    chain = (1, 2, PLANES_F16)
+    return precision.fwd in chain and precision.bwd in chain and not (int(precision.variant) & older) and \
         (hooks is None or hooks.keep is None)
 
 
@@ -618,7 +619,8 @@ class March(torch.autograd.Function):
             pk = mlp_pack(NET_NERF, pb, tensors, cfg.precision.variant)
             if getattr(ctx, "live", False):      # (the one-call march does the same inside lush_march_bwd)
                 lidx, draw_c, ray_start, cnt = live_compact(draw, z.shape[0], z.shape[1])
-                st_live = mlp_forward_live(NET_NERF, pf, tensors, pk, batch, z, lidx, cnt, stash_code(pf, pb), cfg.precision.variant, tm)
+                pk_f = pk if pf == pb else mlp_pack(NET_NERF, pf, tensors, cfg.precision.variant)      # (the forward's own fragments)
+                st_live = mlp_forward_live(NET_NERF, pf, tensors, pk_f, batch, z, lidx, cnt, stash_code(pf, pb), cfg.precision.variant, tm)
                 gr, dpts = mlp_backward(NET_NERF, stash_code(pf, pb), pb, tensors, pk, batch, z, draw_c, st_live,
                                         sink=grad_sink(tensors, cfg.hooks), variant=cfg.precision.variant, timer=tm, live=(lidx, cnt))
                 lib.call("lush_ray_grad_reduce_live", lib.ptr(dpts), lib.ptr(z), lib.ptr(lidx), lib.ptr(ray_start), z.shape[0], lib.ptr(drays), _stream())

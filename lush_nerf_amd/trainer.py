@@ -259,25 +259,29 @@ class Trainer:
         pr = self.model.precision
         return pr.variant == 0 and pr.fwd == ops.PLANES_F16 and pr.bwd == ops.PLANES_F16
 
+    def _live_mode(self) -> bool:
+        """The model's precision mode runs the live-point backward (and no explicit kernel variant is set)."""
+        pr = self.model.precision
+        return pr.variant == 0 and ops.live_backward(pr, None)
+
     def _backward_choice(self, n_rays: int, force_naive: bool) -> bool:
         """True: the step that starts now runs the dense backward.  Decided on the host from the counts that have arrived, OUTSIDE
         any graph capture (step_graph keeps one captured step per answer)."""
-        if not self._headline_default() or self._largest_launch(n_rays, force_naive) <= self.SMALL_LAUNCH_POINTS \
-                or self._live_cum is None:
+        if not self._live_mode() or self._live_cum is None:
             return False
+        if self._headline_default() and self._largest_launch(n_rays, force_naive) <= self.SMALL_LAUNCH_POINTS:
+            return False                                       # (the small-launch kernels: no live-point form)
         self._live_poll()
         return self._dense_backward_now()
 
     def _step_precision(self, n_rays: int, force_naive: bool, coarse_only: bool = False, dense: bool = False):
         """The precision mode this step's kernels run in: the model's, with the small-launch kernel variant when the step's
-        largest MLP launch is small, or with the dense backward when _backward_choice said so (headline mode only; an explicit
+        largest MLP launch is small (headline mode only), or with the dense backward when _backward_choice said so (an explicit
         variant is left alone)."""
         pr = self.model.precision
-        if not self._headline_default():
-            return pr
-        if self._largest_launch(n_rays, force_naive, coarse_only) <= self.SMALL_LAUNCH_POINTS:
+        if self._headline_default() and self._largest_launch(n_rays, force_naive, coarse_only) <= self.SMALL_LAUNCH_POINTS:
             return ops.Precision(pr.fwd, pr.bwd, ops.lib.VARIANT_FWD_HALF | ops.lib.VARIANT_BWD_HALF)
-        if dense:
+        if dense and self._live_mode():
             return ops.Precision(pr.fwd, pr.bwd, ops.lib.VARIANT_DENSE_BWD)
         return pr
 

@@ -1051,11 +1051,12 @@ def test_weight_gradient_split_agrees_with_the_walk(tmp_path):
     print(f"one job per workgroup against the walk: parameter gradients within {worst:.1e}")
 
 
-def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=False, seed=17, sharp=False):
-    """One kernel-on training forward + backward of the (h,h) model in the given kernel variant: (outputs, gradients, live counts)."""
+def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=False, seed=17, sharp=False, mode="h,h"):
+    """One kernel-on training forward + backward of the model in precision mode `mode` and the given kernel variant: (outputs,
+    gradients, live counts)."""
     from lush_nerf_amd import ops, synth
     dev = torch.device("cuda:0")
-    net = diag._nerf_all(64, seed, sharp=sharp, precision=ops.Precision(ops.PLANES_F16, ops.PLANES_F16, variant), rbk_scale=2.0e4)
+    net = diag._nerf_all(64, seed, sharp=sharp, precision=ops.Precision(*ops.parse_planes(mode), variant), rbk_scale=2.0e4)
     if alpha_bias is not None:
         with torch.no_grad():
             net.mlp_coarse.alpha_linear.bias.fill_(alpha_bias)
@@ -1122,6 +1123,36 @@ def test_live_point_march_equals_the_dense_march(diag, case):
         l2 = (num / den) ** 0.5
         print(f"live-point march [{case}]: {share:.3f} of the points live; gradients against the dense march: L2 {l2:.1e}, worst tensor {wk} {worst:.1e}")
         assert l2 < 1e-5 and worst < 2e-3, (l2, wk, worst)
+
+
+@pytest.mark.parametrize("mode,n", [("2,2", 96), ("2,2", 1536), ("2,1", 96), ("2,h", 96), ("h,1", 96), ("1,1", 96)])
+def test_live_point_march_in_the_other_modes(diag, mode, n):
+    """The live-point backward is not the headline mode's alone: every one- and two-plane mode of the 8x256 net runs it (the 128-point
+    chain kernels take the same list and device-side count; the strict mode (2,2) is the fp32-equivalent figure printed next to
+    `value`).  Same assertion as above against LUSH_VARIANT_DENSE_BWD, default-initialised net; 1 536 rays: the weight gradients walk."""
+    from lush_nerf_amd import lib
+    out_l, g_l, cnt = _march_grads(diag, 0, n, mode=mode)
+    out_d, g_d, cnt_d = _march_grads(diag, lib.VARIANT_DENSE_BWD, n, mode=mode)
+    assert cnt_d == [0, 0, 0, 0] and cnt[1] == n * 5 * 128 and cnt[3] == n * 5 * 64, (cnt, cnt_d)
+    share = (cnt[0] + cnt[2]) / (cnt[1] + cnt[3])
+    assert 0.3 < share < 0.7, share
+    assert all(torch.equal(a, b) for a, b in zip(out_l, out_d))
+    num = den = 0.0
+    worst, wk = 0.0, ""
+    for k, a in g_l.items():
+        b = g_d[k]
+        assert (a is None) == (b is None), k
+        if a is None:
+            continue
+        assert torch.isfinite(a).all(), k
+        e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        if e > worst:
+            worst, wk = e, k
+        num += float((a.double() - b.double()).pow(2).sum())
+        den += float(b.double().pow(2).sum())
+    l2 = (num / den) ** 0.5
+    print(f"live-point march ({mode}), {n} rays: {share:.3f} live; against the dense march: L2 {l2:.1e}, worst tensor {wk} {worst:.1e}")
+    assert l2 < 1e-5 and worst < 2e-3, (l2, wk, worst)
 
 
 def test_trainer_falls_back_to_the_dense_backward_when_most_points_are_live(diag):
