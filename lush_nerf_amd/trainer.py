@@ -202,8 +202,9 @@ class Trainer:
     SMALL_LAUNCH_POINTS = 32768
 
     # The live-point march costs one forward over all the points more than the dense one and saves (1 - share) of the stash-
-    # writing forward, the chain and the weight gradients: measured on BASELINE config 2, 5.2 + 15.7 x share ms against 16.2 ms,
-    # break-even at a share of 0.70.  Above LIVE_MAX_SHARE the trainer runs the dense backward and looks again (one live step)
+    # writing forward, the chain and the weight gradients: measured on BASELINE config 2 over 420 - 600 training steps
+    # (profiles/r05_live_points.md), 4.4 .. 5.3 + 14.5 .. 17.4 x share ms against 16.1 .. 16.7 ms: break-even at a share of
+    # 0.69 .. 0.76.  Above LIVE_MAX_SHARE the trainer runs the dense backward and looks again (one live step)
     # every LIVE_PROBE_EVERY steps; it returns to the live march below LIVE_MIN_SHARE.
     LIVE_MAX_SHARE, LIVE_MIN_SHARE, LIVE_PROBE_EVERY = 0.65, 0.60, 32
 
