@@ -474,3 +474,28 @@ def test_quoted_numbers_match_their_sources():
     (the file the status block names) and the committed profiles/ artefacts: no hand-edited figures."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quoted_numbers.py"), "--check"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_live_point_policy_state_machine():
+    """Trainer._dense_backward_now (no GPU: the decision logic alone): live until a share arrives; dense above LIVE_MAX_SHARE with one
+    live probe every LIVE_PROBE_EVERY steps; back to live below LIVE_MIN_SHARE (hysteresis); "live" / "dense" override."""
+    from lush_nerf_amd.trainer import Trainer
+    t = Trainer.__new__(Trainer)
+    t.live_policy, t.live_share, t._dense_now, t._dense_steps = "auto", None, False, 0
+    t.LIVE_PROBE_EVERY = 4
+    assert t._dense_backward_now() is False                      # nothing known yet
+    t.live_share = 0.5
+    assert t._dense_backward_now() is False
+    t.live_share = 0.9
+    seq = [t._dense_backward_now() for _ in range(9)]
+    assert seq == [True, True, True, True, False, True, True, True, False], seq      # every fourth dense step is a live probe
+    t.live_share = 0.62                                           # between MIN and MAX: stays dense
+    assert t._dense_backward_now() is True
+    t.live_share = 0.5
+    assert t._dense_backward_now() is False and t._dense_now is False
+    t.live_share = 0.62                                           # ... and stays live until it exceeds MAX again
+    assert t._dense_backward_now() is False
+    t.live_policy, t.live_share = "dense", 0.1
+    assert t._dense_backward_now() is True
+    t.live_policy, t.live_share = "live", 0.99
+    assert t._dense_backward_now() is False
