@@ -260,3 +260,27 @@ def test_lr_schedule_matches_reference_loop():
     used = O.lr_schedule(5)
     assert used[0] == used[1] == 5e-4
     assert used[2] == O.lr_at(1) and used[4] == O.lr_at(3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_clamped_samples_have_exactly_zero_gradient_rows(dtype):
+    """What the live-point backward rests on (include/lush_march.h "Live points"), checked on the restatement of the reference's own
+    raw2outputs (models/lushnerf.py:296-352) under autograd: a sample whose density pre-activation + noise is <= 0 (ReLU clamped,
+    :313) and that is not the last of its ray (alpha = 1, :338) receives an EXACTLY zero gradient in all four of its raw values,
+    whatever flows into the five outputs -- and every other sample a non-zero one."""
+    g = torch.Generator().manual_seed(3)
+    R, S = 64, 48
+    raw = (torch.randn(R, S, 4, generator=g, dtype=dtype) * 1.5).requires_grad_(True)
+    z = torch.sort(torch.rand(R, S, generator=g, dtype=dtype), -1)[0]
+    d = torch.randn(R, 3, generator=g, dtype=dtype)
+    noise = torch.randn(R, S - 1, generator=g, dtype=dtype)
+    for white in (False, True):
+        raw.grad = None
+        rgb_map, density, acc, weights, depth = O.raw2outputs(raw, z, d, raw_noise_std=1.0, white_bkgd=white, noise=noise)
+        ups = [torch.randn(t.shape, generator=g, dtype=dtype) for t in (rgb_map, density, acc, weights, depth)]
+        torch.autograd.backward([rgb_map, density, acc, weights, depth], ups)
+        dead = torch.zeros(R, S, dtype=torch.bool)
+        dead[:, :-1] = (raw.detach()[:, :-1, 3] + noise) <= 0
+        assert 0.3 < float(dead.float().mean()) < 0.7
+        assert float(raw.grad[dead].abs().max()) == 0.0
+        assert bool((raw.grad[~dead].abs().sum(-1) > 0).all())
