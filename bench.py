@@ -275,6 +275,11 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)                                   # never returns
+    # stdout carries ONE line, the JSON: whatever the libraries underneath print to file descriptor 1 (RCCL's version banner, gloo's
+    # connection notes) goes to stderr instead -- descriptor 1 is pointed at stderr now and the line is written to the saved one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -669,7 +674,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.cpu_n_rand, 64, 64, progress=progress)
             progress("CPU baseline done")
             out["gpu_over_cpu"] = round(rays_per_s / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     dist.destroy_process_group()
 
 
