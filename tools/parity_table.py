@@ -72,7 +72,11 @@ def summarize(path):
            "e_gpu = max|g_gpu - g_f64| / max|g_f64| per parameter tensor, g_f64 = the oracle in float64 evaluated with the ReLU decisions",
            "the GPU took (tests/gpu_diag.py `masked_grad_check`); e_f32 = the same for the fp32 oracle, i.e. the reference's own arithmetic.",
            "A tensor is *well-conditioned* when e_f32 < 1e-5 (fp32 itself reproduces float64); the others are cancelling sums",
-           "(1-element biases, the alpha head), where every mode's error is the condition number times its operand rounding.\n",
+           "(1-element biases, the alpha head), where every mode's error is the condition number times its operand rounding.",
+           "The gradients are the PRODUCT's: in the training-step fixtures and the bench regime those of the live-point backward (the run that",
+           "keeps every point's stash supplies the ReLU decisions only); in the other cases the stash-keeping run's own (the dense form, which",
+           "the live-point backward reproduces to 1e-7 L2: tests/test_gpu_parity.py::test_live_point_march_*).  This table: regenerated after the",
+           "live-point backward went in (raw lines: profiles/r05_parity_raw.jsonl.gz); every check of every case passed in all four modes.\n",
            "## Worst tensor per case: well-conditioned tensors / all tensors\n",
            "| case | " + " | ".join(f"({m})" for m in modes) + " |", "|---|" + "---|" * len(modes)]
     for c in cases:
