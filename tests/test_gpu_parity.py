@@ -1051,23 +1051,23 @@ def test_weight_gradient_split_agrees_with_the_walk(tmp_path):
     print(f"one job per workgroup against the walk: parameter gradients within {worst:.1e}")
 
 
-def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=False, seed=17, sharp=False, mode="h,h"):
+def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=False, seed=17, sharp=False, mode="h,h", ns=64, ni=64):
     """One kernel-on training forward + backward of the model in precision mode `mode` and the given kernel variant: (outputs,
     gradients, live counts)."""
     from lush_nerf_amd import ops, synth
     dev = torch.device("cuda:0")
-    net = diag._nerf_all(64, seed, sharp=sharp, precision=ops.Precision(*ops.parse_planes(mode), variant), rbk_scale=2.0e4)
+    net = diag._nerf_all(ni, seed, sharp=sharp, precision=ops.Precision(*ops.parse_planes(mode), variant), rbk_scale=2.0e4)
     if alpha_bias is not None:
         with torch.no_grad():
             net.mlp_coarse.alpha_linear.bias.fill_(alpha_bias)
             net.mlp_fine.alpha_linear.bias.fill_(alpha_bias)
     b = diag.batch_of(n, seed)
-    draws = {k: v.to(dev) for k, v in diag.util.tdraws(n * 5, 64, 64, seed).items()}
+    draws = {k: v.to(dev) for k, v in diag.util.tdraws(n * 5, ns, ni, seed).items()}
     rays = diag.gpu(b["rays"]).requires_grad_(True)
     net.hooks.live_acc = torch.zeros(4, dtype=torch.int64, device=dev)
     out = net(diag.H, diag.W, [[diag.F, 0, diag.W / 2], [0, diag.F, diag.H / 2], [0, 0, 1]], chunk=1 << 20, rays=rays,
               rays_info={"images_idx": diag.gpu(b["images_idx"])}, retraw=True, force_naive=False, allkernel=True,
-              kernel_pixel=diag.gpu(b["fq_mask"]), perturb=1., N_importance=64, N_samples=64, use_viewdirs=True, white_bkgd=False,
+              kernel_pixel=diag.gpu(b["fq_mask"]), perturb=1., N_importance=ni, N_samples=ns, use_viewdirs=True, white_bkgd=False,
               raw_noise_std=noise, inference=False, near=0., far=1., draws=draws)
     loss = ops.TrainLoss.apply(out[0], out[1], diag.gpu(b["target"]))
     (loss * 0.0 if zero_upstream else loss).backward()
@@ -1077,7 +1077,7 @@ def _march_grads(diag, variant, n, alpha_bias=None, noise=1., zero_upstream=Fals
     return [o.detach().clone() for o in (out[0], out[1], out[3], out[5])], grads, [int(x) for x in net.hooks.live_acc.tolist()]
 
 
-@pytest.mark.parametrize("case", ["default-init", "default-init-large", "all-live", "all-dead", "sharp"])
+@pytest.mark.parametrize("case", ["default-init", "default-init-large", "all-live", "all-dead", "sharp", "ragged", "ragged-samples"])
 def test_live_point_march_equals_the_dense_march(diag, case):
     """Round 5: the headline mode's march keeps no stash in its forward; its backward lists the points whose d_raw row is non-zero
     (a sample whose density pre-activation the ReLU of raw2outputs clamps has alpha = 0, weight = 0, d alpha / d raw = 0:
@@ -1086,14 +1086,15 @@ def test_live_point_march_equals_the_dense_march(diag, case):
     the fp32 sums.  Cases: the bench's regime (default init, raw_noise_std 1: about half the points live) at two sizes, every point live
     (density bias +5, no noise), no point live (zero upstream gradient: empty list), a sharp net."""
     from lush_nerf_amd import lib
-    kw = {"default-init": dict(n=96), "default-init-large": dict(n=1536), "all-live": dict(n=48, alpha_bias=5.0, noise=0.), "all-dead": dict(n=48, zero_upstream=True),
+    # (ragged: 35 marched rays -- the lists end inside a 256-point block; ragged-samples: 48 + 40 samples, rows of 88 and 48 points)
+    kw = {"default-init": dict(n=96), "default-init-large": dict(n=1536), "ragged": dict(n=7), "ragged-samples": dict(n=21, ns=48, ni=40), "all-live": dict(n=48, alpha_bias=5.0, noise=0.), "all-dead": dict(n=48, zero_upstream=True),
           "sharp": dict(n=48, sharp=True)}[case]
     out_l, g_l, cnt = _march_grads(diag, 0, **kw)
     out_d, g_d, cnt_d = _march_grads(diag, lib.VARIANT_DENSE_BWD, **kw)
     assert cnt_d == [0, 0, 0, 0]                               # the dense march lists nothing
     assert all(torch.equal(a, b) for a, b in zip(out_l, out_d))
     share = (cnt[0] + cnt[2]) / max(cnt[1] + cnt[3], 1)
-    assert cnt[1] == kw["n"] * 5 * 128 and cnt[3] == kw["n"] * 5 * 64, cnt
+    assert cnt[1] == kw["n"] * 5 * (kw.get("ns", 64) + kw.get("ni", 64)) and cnt[3] == kw["n"] * 5 * kw.get("ns", 64), cnt
     if case.startswith("default-init"):
         # (96 rays: both passes list fewer than 2^18 points -- the weight-gradient launch takes ONE job per workgroup, chosen in the
         #  kernel; 1 536 rays: the fine pass lists more -- every workgroup walks the jobs of its slice)
