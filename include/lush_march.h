@@ -372,7 +372,8 @@ int lush_ray_grad_reduce_live(const float* dpts, const float* z, const int* live
  * (mlpforward :234-266), raw2outputs (:296-352), sample_pdf + sort (:544-549, utils/run_lushnerf_helpers.py:566-609),
  * fine MLP, raw2outputs -- and its autograd backward, each as ONE call that enqueues the kernels behind the
  * piecewise entry points above on `stream`, out of one caller-provided workspace (lush_march_workspace_bytes; 256-byte
- * aligned).  The forward leaves what the backward needs (z, raw, weights, packed weights, activation stashes) in the
+ * aligned).  The forward leaves what the backward needs (z, raw, weights, packed weights; with LUSH_VARIANT_DENSE_BWD or three
+ * planes also the activation stashes -- otherwise the backward fills them for the live points itself, see "Live points") in the
  * workspace: keep it untouched between the two calls.  render_rays (:354-479) is this plus lush_zfixed + lush_mlp_fwd of
  * the noise net; the blur-kernel branch feeds it N (M+1) warped rays (lush_rbk_warp_fwd + lush_pack_rays_fwd). */
 typedef struct {
@@ -406,7 +407,8 @@ size_t lush_march_workspace_bytes(const lush_march_cfg* cfg);     /* 0 = bad con
 #define LUSH_VIEW_RAW 1           /* raw of the final pass [R][S(+Ni)][4] */
 #define LUSH_VIEW_WEIGHTS 2       /* compositing weights of the final pass [R][S(+Ni)] */
 #define LUSH_VIEW_Z_COARSE 3      /* z_vals of the coarse pass [R][S] */
-#define LUSH_VIEW_STASH_COARSE 4  /* activation stash of the coarse / fine MLP evaluation (tests: lush_debug_stash_layout) */
+#define LUSH_VIEW_STASH_COARSE 4  /* activation stash of the coarse / fine MLP evaluation (tests: lush_debug_stash_layout); after a live-point
+                                   * backward: the stash of the pass's LIVE points in list order */
 #define LUSH_VIEW_STASH_FINE 5
 #define LUSH_VIEW_LIVE_COUNTS 6   /* int32 [4] after lush_march_bwd of a live-point configuration: {live, all} points of the fine pass (or the only pass), then of the coarse pass */
 int lush_march_view(const lush_march_cfg* cfg, int which, size_t* offset, size_t* bytes);
