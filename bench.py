@@ -404,6 +404,8 @@ def main():
             sustained = {"steps": n_sus, "seconds": round(float(sdt.item()), 3), "ms_per_step": round(float(sdt.item()) / n_sus * 1e3, 3),
                          "value": round(cfg["n_rand"] * world * n_sus / float(sdt.item()), 1), "unit": "rays/s",
                          "live_points": live_share(live1, tr.live_counts()),
+                         # (the replay's check on itself: the same states and draws give the same live points, to the count)
+                         "same_live_points_as_timed_region": live_share(live1, tr.live_counts()) == live,
                          "note": "the timed region's %d steps replayed back to back for >= %g s: each cycle restores the model, the optimiser "
                                  "moments and the draw counter to the state the timed region started from (three device copies of 5 MB) "
                                  "and runs the same steps -- the same live points (live_points), the same work; what differs from the "
