@@ -19,6 +19,8 @@ w = synth.all_weights(30, 0)
 names = [f"mlp_fine.pts_linears.{l}.{s}" for l in range(8) for s in ("weight", "bias")] + \
         [f"mlp_fine.{n}.{s}" for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear") for s in ("weight", "bias")]
 tens = [torch.from_numpy(w[n]).to(dev) for n in names]
+if os.environ.get("ZERO_W"):          # same instruction stream on all-zero weights and biases: what the clock does when the operands cost nothing
+    tens = [torch.zeros_like(t) for t in tens]
 b = synth.ray_batch(R, 1)
 batch = O.pack_rays(synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, torch.from_numpy(b["rays"])).to(dev)
 z = torch.sort(torch.rand(R, S, device=dev), -1)[0]

@@ -1,12 +1,14 @@
 #!/bin/bash
-# developer aid (GPU box): SQ counters of the two-wave prototype (tools/micro/two_wave_proto.hip), two --pmc passes, no trace domains
+# developer aid (GPU box): SQ counters of the two-wave prototype (tools/micro/$BIN.hip), two --pmc passes, no trace domains
 set -u
+BIN=${1:-two_wave_proto}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/sq_proto; mkdir -p $OUT
+rm -rf $OUT/p1 $OUT/p2
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"
 P2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU"
-timeout -k 10 200 rocprofv3 --pmc $P1 --output-format csv -d $OUT/p1 -- $ROOT/build/two_wave_proto > $OUT/p1.log 2> $OUT/p1.err
-timeout -k 10 200 rocprofv3 --pmc $P2 --output-format csv -d $OUT/p2 -- $ROOT/build/two_wave_proto > $OUT/p2.log 2> $OUT/p2.err
+timeout -k 10 200 rocprofv3 --pmc $P1 --output-format csv -d $OUT/p1 -- $ROOT/build/$BIN > $OUT/p1.log 2> $OUT/p1.err
+timeout -k 10 200 rocprofv3 --pmc $P2 --output-format csv -d $OUT/p2 -- $ROOT/build/$BIN > $OUT/p2.log 2> $OUT/p2.err
 cd $ROOT
 python3 - <<'PY'
 import csv, glob, collections
