@@ -29,6 +29,11 @@ import torch.distributed as dist
 MACS_PER_EVAL = 593_408            # NeRF D=8 W=256 MLP, verified layer shapes
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# What the chip SUSTAINS on random fp16 operands with nothing but the MFMAs and their fragment reads in the loop (the forward's
+# skeleton: v_mfma_f32_32x32x16_f16, A re-read from LDS, B and the accumulators in registers; tools/micro/mfma_shape.hip,
+# profiles/r06_mfma_shape.txt): the clock is held at 1.73 GHz there (2.4 GHz on all-zero operands).  Quoted next to the datasheet
+# peak the way MI355X_MICROARCH.md quotes 6.3 TB/s next to HBM's 8: `frac` stays against the datasheet figure.
+SUSTAINED_F16_TFLOPS = 1546.0
 # stash bytes per MLP evaluation and bf16 plane ([point][feature] rows)
 # A 1- or 2-plane backward keeps neither the feature activations nor their gradients (the feature layer is linear: its
 # weight gradients follow from dZv^T h_7, FeatFactorArgs in csrc/lush_mlp.h); the 3-plane reference mode stashes both.
@@ -43,11 +48,11 @@ def BYTES_DZ_STASH(planes):
     return 2 * (8 * 256 + (256 if planes >= 3 else 0) + 128 + (8 if planes == 1 else 0))
 
 
-def make_model(args_ns, device, precision, seed=0, num_img=30):
+def make_model(args_ns, device, precision, seed=0, num_img=30, trained_like=False):
     from lush_nerf_amd import model as M, synth
     rbk = M.RBK(num_img, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4)
     net = M.NeRFAll(args_ns, rbk, precision=precision)
-    M.load_reference_weights(net, synth.all_weights(num_img, seed))
+    M.load_reference_weights(net, synth.all_weights(num_img, seed, trained_like=trained_like))
     return net.to(device)
 
 
@@ -336,15 +341,21 @@ def main():
     def evals_per_step(n_rand, ns, ni, kernel=True):
         return n_rand * (M if kernel else 1) * (ns + (ns + ni if ni else 0))
 
-    def run_mode(pf, pb, steps, warmup, cfg=None, sustained_s=0.0, variant=None):
+    def run_mode(pf, pb, steps, warmup, cfg=None, sustained_s=0.0, variant=None, trained_like=False):
         """Time `steps` optimisation steps of one BASELINE config in one precision mode (max over ranks).  sustained_s > 0: after
         the timed region, the same steps back to back for at least that many seconds (the timed region of the driver's
         `--steps 20` is a third of a second on a chip that runs at its power cap: this is its steady-state neighbour)."""
         cfg = cfg or dict(n_rand=a.n_rand, ns=a.n_samples, ni=a.n_importance, kernel=True, micro=a.micro_batch)
         batches = make_batches(cfg["n_rand"])
-        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb, a.variant if variant is None else variant))
+        net = make_model(model_args(cfg["ni"]), dev, ops.Precision(pf, pb, a.variant if variant is None else variant), trained_like=trained_like)
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, cfg["ns"], cfg["ni"], kernel_start_iter=0,
                      allkernel_start_iter=1 << 30, distributed=True, micro_batch=cfg["micro"])
+        if trained_like:
+            # The density field is HELD: every kernel of the step runs (both marches, loss, backward, all-reduce, Adam), Adam with a
+            # zero rate.  From fresh Adam moments the first updates are +-lrate whatever the gradient, and through the x3000 density
+            # head that moves the field from 0.23 live to 0.67 within three steps (tools/trained_like_probe.py): the workload would
+            # time a transient of the optimiser, not a trained scene's density distribution.
+            tr.lrate = 0.0
         for i in range(warmup):
             tr.step(batches[i % n_batches], i)
         sync()
@@ -374,6 +385,7 @@ def main():
             return None if fa + ca == 0 else {"share": round((fl + cl) / (fa + ca), 4), "fine": round(fl / fa, 4) if fa else None,
                                                "coarse": round(cl / ca, 4) if ca else None}
         live = live_share(live0, tr.live_counts())
+        dense_steps = int(getattr(tr, "_dense_steps", 0)) if getattr(tr, "_dense_now", False) else 0      # (what the trainer's policy chose)
         # kernel groups: the SAME steps once more (state restored) with HIP events around each MLP kernel group on the launch stream.
         # The timed region above runs the march as one C-ABI call per direction (lush_march_fwd / lush_march_bwd); with the timer set
         # the same kernels are launched group by group through the piecewise entry points.
@@ -422,6 +434,7 @@ def main():
         summ["_allreduce_ms"] = ar_ms
         summ["_sustained"] = sustained
         summ["_live"] = live
+        summ["_dense_steps"] = dense_steps
         return dt, summ
 
     def run_c1(pf, pb, steps, warmup):
@@ -434,7 +447,8 @@ def main():
         tr = Trainer(net, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, c["ns"], 0, kernel_start_iter=1 << 30, distributed=True)
 
         # the step itself is Trainer.step_coarse_only (render_infer at 32 + 0, one summed loss gradient, Adam): the same function
-        # tests/test_gpu_parity.py::test_c1_step_against_the_oracle checks against the oracle, eagerly and as the graph replayed here
+        # tests/test_gpu_parity.py::test_unverified_gradient_paths_in_the_headline_mode[t_train_c1] checks against the oracle, eagerly and
+        # as the graph replayed here
         for i in range(warmup):
             tr.step_coarse_only(batches[i % n_batches])
         sync()
@@ -482,7 +496,10 @@ def main():
         sp = ops.nplanes(ops.stash_code(pf, pb))
         pbn = ops.nplanes(pb)
         ree = pf == ops.PLANES_F16 and pbn == 1 and not (a.variant & (lib.VARIANT_FWD_HALF | lib.VARIANT_FWD_512 | lib.VARIANT_PE_ROWS))
-        bytes_eval = {"mlp_fwd_all": 16 + 44 / 64,      # the forward over ALL the points of a live-point march: no stash, 16 bytes of raw output
+        # the forward over ALL the points of a live-point march keeps no stash: 16 bytes of raw output and 4 of depth per point, the
+        # ray's 44 bytes once per ~96 samples, and (added per launch below) the weight stream: every XCD's L2 fetches the network's
+        # 1.19 MB of fp16 fragments from HBM once per launch (8 x 1.19 MB; the CUs re-read it from L2 per tile)
+        bytes_eval = {"mlp_fwd_all": 16 + 4 + 44 / 96,
                       "mlp_fwd": sp * BYTES_X_STASH(sp, ree) + 16 + 44 / 64,
                       "mlp_bwd_chain": pbn * BYTES_DZ_STASH(pbn) + 288 + 16 + 32,
                       "mlp_bwd_weights": pbn * (BYTES_X_STASH(pbn, ree) + BYTES_DZ_STASH(pbn))}
@@ -495,7 +512,8 @@ def main():
             avg_ms = d["ms"] / d["launches"]
             pts = d["points"] / d["launches"]
             tf = 2 * MACS_PER_EVAL * pts / (avg_ms * 1e-3) / 1e12
-            gbs = bytes_eval[g] * pts / (avg_ms * 1e-3) / 1e9
+            per_launch = 8 * 2 * MACS_PER_EVAL * (1 if g in ("mlp_fwd_all", "mlp_fwd", "mlp_bwd_chain") else 0)      # the weight stream, once per XCD
+            gbs = (bytes_eval[g] * pts + per_launch) / (avg_ms * 1e-3) / 1e9
             kern[g] = {"launches_per_step": d["launches"] / steps, "avg_ms": round(avg_ms, 4),
                        "ms_per_step": round(d["ms"] / steps, 3), "tflops_algorithmic": round(tf, 1),
                        "hbm_gbs_algorithmic": round(gbs, 1), "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 4),
@@ -527,7 +545,7 @@ def main():
         odt, ogroups = run_mode(qf, qb, osteps, 1)
         progress(f"mode {m}: {odt / osteps * 1e3:.2f} ms/step")
         others.append((m, qf, qb, odt, ogroups, osteps))
-    extra_names = [x for x in (a.extra if a.extra is not None else ("C1,C3,C5,eval" if world == 1 else "")).split(",") if x]
+    extra_names = [x for x in (a.extra if a.extra is not None else ("trained_like,C1,C3,C5,eval" if world == 1 else "")).split(",") if x]
     extras = {}
     for name in extra_names:       # the other BASELINE configs with the SAME kernels and precision mode as the headline
         progress(f"extra config {name}")
@@ -537,6 +555,20 @@ def main():
             extras["eval"] = {"value": round(n_pose * synth.H_DEF * synth.W_DEF * world / edt, 1), "unit": "rays/s (forward only)",
                               "s_per_pose": round(edt / n_pose, 4),
                               "workload": "NeRFAll.forward(poses) -> render_path, 640x1120 rays per pose, 64+64, chunk 32768"}
+        elif name == "trained_like":
+            # The headline workload from a density field shaped like a trained scene's (synth.all_weights(trained_like=True): empty
+            # space strongly negative, "surfaces" strongly positive, the fine network agreeing with the coarse one) instead of the
+            # initialisation's sigma ~ 0, where the unit noise alone decides which half of the samples is live
+            # (configs/poster_lushnerf:14, 21: 100 000 iterations at raw_noise_std = 1e0: most of a run is NOT at initialisation).
+            st = max(4, a.steps // 2)
+            tdt, tgroups = run_mode(pf, pb, st, 3, trained_like=True)
+            extras["trained_like"] = {"value": round(a.n_rand * world * st / tdt, 1), "unit": "rays/s", "ms_per_step": round(tdt / st * 1e3, 3), "steps": st,
+                                      "live_points": tgroups.get("_live"),
+                                      "backward": "dense (the policy's choice)" if tgroups.get("_dense_steps") else "live points (the policy's choice)",
+                                      "kernels": kernel_table(tgroups, pf, pb, st),
+                                      "workload": "BASELINE config 2 from synth.all_weights(trained_like=True): sigma = 3000 w.h + 20 (positive in ~13 % of "
+                                                  "the volume, tens where it is; dead under the unit noise in ~85 %), fine network = coarse network; the field "
+                                                  "is held (Adam runs with a zero rate: bench.py run_mode says why); same rays, draws, kernels and mode as `value`"}
         elif name == "C1":
             st = 20
             cdt, cdt_eager = run_c1(pf, pb, st, 3)
@@ -600,6 +632,10 @@ def main():
                     "frac": k["frac_hbm"] if hbm_bound else k["frac_mfma"], "traffic": traffic,
                     "traffic_source": traffic_source,
                     "executed_mfma_frac": k["frac_mfma_executed"], **both,
+                    # the datasheet MFMA peak is not reachable on random data: the clock is held down under MFMA load
+                    # (profiles/r06_pair_proto.md section 2); frac_of_sustained = achieved over what a bare MFMA + LDS-fragment loop sustains
+                    "sustained_peak": SUSTAINED_F16_TFLOPS if (not hbm_bound and pf == ops.PLANES_F16) else None,
+                    "frac_of_sustained_peak": round(k["tflops_algorithmic"] / SUSTAINED_F16_TFLOPS, 4) if (not hbm_bound and pf == ops.PLANES_F16) else None,
                     "note": "dominant kernel group by time; achieved = algorithmic bytes (or 2*593408 FLOP) per MLP "
                             "evaluation x evaluations per launch / average launch time from HIP events on the launch stream; "
                             "the bound is the roof the kernel hits first counting the MFMAs it executes per product "
@@ -626,6 +662,11 @@ def main():
             # has an exactly zero gradient); null: the backward ran over all the points
             "live_points": groups.get("_live"),
             "dense_backward": dense,
+            # ... the same two figures where a reader of `value` looks first: `value` is (mode, live share); `value_dense` is the step
+            # whose cost does not depend on the model's state (the backward over all the points: the figure comparable with rounds 1-4)
+            "value_at": {"mode": a.planes, "live_share": (groups.get("_live") or {}).get("share")},
+            "value_dense": dense["value"] if dense else None,
+            "ms_per_step_dense": dense["ms_per_step"] if dense else None,
             "step_tflops_algorithmic": round(flop_step * world * a.steps / dt / 1e12, 2),
             # ... and what the kernels executed: one forward over all the points + (forward, chain, weight gradients) on the live ones
             "step_tflops_executed": round((1 + 3 * (groups["_live"]["share"] if groups.get("_live") else 2 / 3)) / 3 * flop_step * world * a.steps / dt / 1e12, 2),
@@ -668,6 +709,16 @@ def main():
                 out["live_points_strict_2_2"] = out["modes"]["2,2"]["live_points"]      # (the live-point backward runs in every one- / two-plane mode)
         if extras:
             out["extra_configs"] = extras
+            tl = extras.get("trained_like")
+            if tl and tl.get("live_points") and out["live_points"] and abs(tl["live_points"]["share"] - out["live_points"]["share"]) > 0.05:
+                # the step against the live share, from the two workloads of THIS run (same box, same process): ms = a + b x share
+                s1, m1, s2, m2 = out["live_points"]["share"], out["ms_per_step"], tl["live_points"]["share"], tl["ms_per_step"]
+                b_ = (m1 - m2) / (s1 - s2)
+                out["ms_per_step_vs_live_share"] = {"a_ms": round(m1 - b_ * s1, 3), "b_ms_per_unit_share": round(b_, 3),
+                                                    "from": f"this run's two workloads: share {s1} -> {m1} ms (value), share {s2} -> {m2} ms (extra_configs.trained_like)",
+                                                    "dense_ms": out["ms_per_step_dense"],
+                                                    "note": "a = the forward over all the points + everything outside the MLPs; the dense backward is the cheaper "
+                                                            "one above share = (dense_ms - a) / b (profiles/r05_live_points.md: 5.28 + 14.54 x share over 600 steps)"}
         if world > 1:      # a SCALE line explains what it leaves out
             out["n1_only"] = ("cpu_baseline, roofline.traffic (live rocprofv3 --pmc passes) and extra_configs are N = 1 quantities: see the "
                               "N = 1 line of the same round (BENCH_rNN.json); roofline.traffic here quotes profiles/pmc_traffic.json")

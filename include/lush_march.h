@@ -401,7 +401,11 @@ typedef struct { float *rgb, *depth, *acc, *density, *rgb0, *depth0, *acc0, *den
  * received a gradient is skipped (the coarse net of the consistency branch, models/lushnerf.py:949-989). */
 typedef struct { const float *rgb, *depth, *acc, *rgb0, *depth0, *acc0; } lush_march_gout;
 
-size_t lush_march_workspace_bytes(const lush_march_cfg* cfg);     /* 0 = bad configuration */
+/* 0 = bad configuration, which includes R * (N_samples + N_importance) >= 2^27: no launch behind the march takes that many points
+ * (see lush_mlp_fwd), so the march is refused when it is sized, not half way through its backward.  A live-point march with a fine
+ * pass keeps ONE stash region for both passes (the coarse pass's is the head of the fine pass's: LUSH_VIEW_STASH_COARSE / _FINE then
+ * name overlapping bytes; the dense form, which is what a caller that wants to read the stash runs, keeps two). */
+size_t lush_march_workspace_bytes(const lush_march_cfg* cfg);
 /* Where the forward left its by-products inside the workspace (byte offset, size): */
 #define LUSH_VIEW_Z 0             /* z_vals of the final pass [R][S(+Ni)], sorted */
 #define LUSH_VIEW_RAW 1           /* raw of the final pass [R][S(+Ni)][4] */

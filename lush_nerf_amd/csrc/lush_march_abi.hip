@@ -41,20 +41,30 @@ inline bool live_mode(const lush_march_cfg* c) {
 bool layout(const lush_march_cfg* c, Layout& L) {
     if (!c || c->R <= 0 || c->N_samples < 2 || c->N_importance < 0) return false;
     const long long R = c->R, S = c->N_samples, Ni = c->N_importance, Sf = S + Ni;
+    // (every MLP launch and lush_live_compact take at most 2^27 - 1 points: refused HERE, not by the first launch that meets them --
+    // round 5's layout sized a workspace for such a march and its backward then failed half way)
+    if (R * Sf >= (1LL << 27)) return false;
     const int pf = c->planes_fwd, pb = c->planes_bwd, sc = stash_code(pf, pb);
     const size_t pk_f = lush_mlp_packed_bytes(0, pf), pk_b = pb ? lush_mlp_packed_bytes(0, pb) : 0;
     if (pk_f == 0 || (pb && pk_b == 0)) return false;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
     L = Layout{};
+    L.live = pb != 0 && live_mode(c);
     L.zc = take(R * S * 4); L.wc = take(R * S * 4); L.rawc = take(R * S * 16); L.pkc = take(pk_f);
     L.stashc_bytes = lush_mlp_stash_bytes(0, pf, sc, R * S);
-    L.stashc = take(L.stashc_bytes);
+    // Live-point march with a fine pass: ONE stash region for both passes.  Its forward keeps no stash (the region is the
+    // inference kernels' scratch), its backward re-runs the forward with the stash pass by pass, fine first, and a pass is done with
+    // its stash before the next one starts: the coarse pass's region is the head of the fine pass's (-4.4 KB per coarse point of
+    // workspace: 5.8 GB at BASELINE config 2).
+    const bool share_stash = L.live && Ni > 0;
+    if (!share_stash) L.stashc = take(L.stashc_bytes);
     if (Ni > 0) {
         L.zf = take(R * Sf * 4); L.zs = take(R * Ni * 4); L.wf = take(R * Sf * 4); L.rawf = take(R * Sf * 16);
         L.pkf = c->same_net ? L.pkc : take(pk_f);
         L.stashf_bytes = lush_mlp_stash_bytes(0, pf, sc, R * Sf);
         L.stashf = take(L.stashf_bytes);
+        if (share_stash) L.stashc = L.stashf;
     }
     if (pb) {
         const long long Pmax = R * (Ni > 0 ? Sf : S);
@@ -63,7 +73,6 @@ bool layout(const lush_march_cfg* c, Layout& L) {
         L.draw = take(Pmax * 16);
         L.dstash = take(lush_mlp_dstash_bytes(0, pb, Pmax));
         L.dpts = take(Pmax * 32);
-        L.live = live_mode(c);
         if (L.live) {
             L.live_idx = take(Pmax * 4);
             L.draw_c = take(Pmax * 16);

@@ -94,12 +94,24 @@ def rbk_weights(num_img: int, seed: int, embed_ch: int = 64, W: int = 64, D: int
     return p
 
 
+# ``trained_like``: alpha_linear x TRAINED_SCALE, bias TRAINED_BIAS (see all_weights).  Calibrated for seed 0 on the synthetic rays'
+# points: the coarse network's w_alpha . h_7 there is -0.0168 +- 0.0089, so sigma = 3000 w.h + 20 = -30 +- 27: positive (mean +13,
+# alpha ~ 0.3 per sample: a surface takes a handful of samples) in ~13 % of the volume, below -1 (dead under the unit noise) in ~85 %; measured on the GPU (tools/trained_like_probe.py): coarse pass 0.106 live, fine pass 0.289.
+TRAINED_SCALE, TRAINED_BIAS = 3000.0, 20.0
+
+
 def all_weights(num_img: int = 30, seed: int = 0, netwidth: int = 256, netdepth: int = 8,
-                sharp: bool = False, rbk_scale: float = 1.0) -> Dict[str, np.ndarray]:
+                sharp: bool = False, rbk_scale: float = 1.0, trained_like=False) -> Dict[str, np.ndarray]:
     """Full NeRFAll parameter set.  ``sharp`` rescales alpha_linear so raw sigma spans
     roughly 0..100 (default init leaves the compositing scan and
     sample_pdf nearly untested).  ``rbk_scale`` multiplies r_linear/v_linear weights
-    so the SE(3) warp is not numerically the identity in tests."""
+    so the SE(3) warp is not numerically the identity in tests.
+    ``trained_like`` (True, or a (scale, bias) pair): a density field shaped like a trained scene's instead of the
+    initialisation's sigma = -0.003 +- 0.008 everywhere -- alpha_linear x scale with a bias chosen so that raw sigma is
+    strongly negative in most of the volume (dead even under raw_noise_std = 1, configs/*_lushnerf:21) and strongly positive
+    (tens, far above the noise) in the blobs where the random field peaks -- its "surfaces"; and the fine network is a COPY of
+    the coarse one, as a trained pair agrees on where the surfaces are (so sample_pdf's new samples land where the fine
+    network's density is, too).  What bench.py's ``trained_like`` workload starts from."""
     p: Dict[str, np.ndarray] = {}
     p.update(nerf_weights("mlp_coarse", netdepth, netwidth, seed + 1))
     p.update(nerf_weights("mlp_fine", netdepth, netwidth, seed + 2))
@@ -109,6 +121,13 @@ def all_weights(num_img: int = 30, seed: int = 0, netwidth: int = 256, netdepth:
         for net in ("mlp_coarse", "mlp_fine"):
             p[f"{net}.alpha_linear.weight"] = p[f"{net}.alpha_linear.weight"] * 400.0
             p[f"{net}.alpha_linear.bias"] = p[f"{net}.alpha_linear.bias"] * 0.0 + 20.0
+    if trained_like:
+        scale, bias = (TRAINED_SCALE, TRAINED_BIAS) if trained_like is True else trained_like
+        for k in [k for k in p if k.startswith("mlp_coarse.")]:
+            p["mlp_fine." + k[len("mlp_coarse."):]] = p[k].copy()
+        for net in ("mlp_coarse", "mlp_fine"):
+            p[f"{net}.alpha_linear.weight"] = p[f"{net}.alpha_linear.weight"] * np.float32(scale)
+            p[f"{net}.alpha_linear.bias"] = p[f"{net}.alpha_linear.bias"] * np.float32(0.0) + np.float32(bias)
     if rbk_scale != 1.0:
         for n in ("r_linear", "v_linear"):
             p[f"mlp_rbk.{n}.weight"] = p[f"mlp_rbk.{n}.weight"] * rbk_scale

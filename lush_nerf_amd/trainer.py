@@ -149,8 +149,10 @@ class Trainer:
         self._live_cum = torch.zeros(4, dtype=torch.int64, device=self.flat.param.device) if self.flat.param.is_cuda else None
         self._live_ring = torch.zeros(8, 4, dtype=torch.int64).pin_memory() if self.flat.param.is_cuda else None
         self._live_slot = 0
-        self._live_snaps = []             # [(event, ring row)], oldest first
+        self._live_snaps = []             # [(event, ring row, step number, accumulator id)], oldest first
         self._live_prev = [0, 0, 0, 0]    # last snapshot read (cumulative counts)
+        self._live_prev_acc = None        # ... and the accumulator it was read from (a caller may hand the march its own)
+        self._live_step = 0               # steps whose backward choice has been taken
         self.live_share = None            # share of live points in the most recent step whose counts have arrived
         self._dense_now = False
         self._dense_steps = 0
@@ -204,31 +206,47 @@ class Trainer:
     # The live-point march costs one forward over all the points more than the dense one and saves (1 - share) of the stash-
     # writing forward, the chain and the weight gradients: measured on BASELINE config 2 over 420 - 600 training steps
     # (profiles/r05_live_points.md), 4.4 .. 5.3 + 14.5 .. 17.4 x share ms against 16.1 .. 16.7 ms: break-even at a share of
-    # 0.69 .. 0.76.  Above LIVE_MAX_SHARE the trainer runs the dense backward and looks again (one live step)
-    # every LIVE_PROBE_EVERY steps; it returns to the live march below LIVE_MIN_SHARE.
-    LIVE_MAX_SHARE, LIVE_MIN_SHARE, LIVE_PROBE_EVERY = 0.65, 0.60, 32
+    # 0.69 .. 0.76.  Above LIVE_MAX_SHARE the trainer runs the dense backward and looks again (one live step, which at such a
+    # share costs what a dense one does) every LIVE_PROBE_EVERY steps; it returns to the live march below LIVE_MIN_SHARE.
+    # (Round 5 switched at 0.65 / 0.60 and probed every 32 steps: inside the band where the live march is still the cheaper one,
+    # and up to 32 steps late on a falling share.)
+    LIVE_MAX_SHARE, LIVE_MIN_SHARE, LIVE_PROBE_EVERY = 0.70, 0.65, 8
+    # The choice for step i is taken from the counts of step i - LIVE_LAG, whatever the host's and the device's relative timing:
+    # the trainer WAITS for that step's snapshot (two steps behind the one being enqueued: it has all but always arrived, and the
+    # host never gets more than LIVE_LAG steps ahead of the device), so a run with a fixed seed makes the same choices every time
+    # (round 5 polled with event.query(): which steps ran dense depended on how far the host was ahead).
+    LIVE_LAG = 2
 
     def _live_poll(self):
-        """Read the count snapshots that have arrived (never blocks): updates live_share."""
-        while self._live_snaps and self._live_snaps[0][0].query():
-            _, row = self._live_snaps.pop(0)
+        """Consume the count snapshots of the steps up to LIVE_LAG behind the one that starts now (waits for them: see LIVE_LAG):
+        updates live_share."""
+        while self._live_snaps and self._live_snaps[0][2] <= self._live_step - self.LIVE_LAG:
+            ev, row, _, acc_id = self._live_snaps.pop(0)
+            ev.synchronize()
             cur = [int(x) for x in self._live_ring[row].tolist()]
+            if acc_id != self._live_prev_acc:          # another accumulator (a caller's own): its counts start a new series
+                self._live_prev, self._live_prev_acc = cur, acc_id
+                continue
             d_live = (cur[0] - self._live_prev[0]) + (cur[2] - self._live_prev[2])
             d_all = (cur[1] - self._live_prev[1]) + (cur[3] - self._live_prev[3])
             if d_all > 0:
                 self.live_share = d_live / d_all
             self._live_prev = cur
 
-    def _live_snapshot(self):
-        """Enqueue a copy of the cumulative counts into the next row of the pinned ring (no allocation, nothing blocks)."""
-        if self._live_cum is None or len(self._live_snaps) >= self._live_ring.shape[0]:
-            return                         # (the host ran a ring ahead of the device: this step's delta folds into the next snapshot)
+    def _live_snapshot(self, acc=None):
+        """Enqueue a copy of the cumulative counts the step's marches added to (the trainer's accumulator, or the one a caller put
+        into hooks.live_acc) into the next row of the pinned ring (no allocation, nothing blocks)."""
+        acc = self._live_cum if acc is None else acc
+        if acc is None or self._live_ring is None or len(self._live_snaps) >= self._live_ring.shape[0]:
+            return                         # (cannot happen with LIVE_LAG < ring rows; a skipped step's delta folds into the next snapshot)
         row = self._live_slot
         self._live_slot = (row + 1) % self._live_ring.shape[0]
-        self._live_ring[row].copy_(self._live_cum, non_blocking=True)
+        self._live_ring[row].copy_(acc, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._live_snaps.append((ev, row))
+        if self._live_prev_acc is None:
+            self._live_prev_acc = acc.data_ptr()       # (the first series starts from zero counts)
+        self._live_snaps.append((ev, row, self._live_step, acc.data_ptr()))
 
     def live_counts(self):
         """Cumulative {live, all} point counts of the fine and the coarse passes of every live-point march so far (a
@@ -272,6 +290,7 @@ class Trainer:
             return False
         if self._headline_default() and self._largest_launch(n_rays, force_naive) <= self.SMALL_LAUNCH_POINTS:
             return False                                       # (the small-launch kernels: no live-point form)
+        self._live_step += 1
         self._live_poll()
         return self._dense_backward_now()
 
@@ -397,8 +416,8 @@ class Trainer:
                 loss = loss + w * self._consistency(consist, w)
         finally:
             hooks.sink, hooks.packed, hooks.live_acc = sink_before, None, acc_before
-        if acc_before is None and not dense:
-            self._live_snapshot()
+        if not dense and self._live_mode():
+            self._live_snapshot(acc_before)      # (the caller's accumulator when it supplied one: the policy sees those steps too)
         if self.distributed:
             self._all_reduce()          # RCCL sum over xGMI; the 1/world mean is folded into Adam
         lr = self.lr() if self._lr_next is None else self._lr_next

@@ -416,6 +416,27 @@ def test_mlp_launch_refuses_more_points_than_its_32_bit_offsets_reach():
     assert rc != 0 and b"2^27" in l.lush_last_error(), l.lush_last_error()
 
 
+def test_march_is_refused_when_it_is_sized_not_half_way_through_its_backward():
+    """A march with R * (N_samples + N_importance) >= 2^27 points cannot run (no MLP launch, nor lush_live_compact, takes that many):
+    lush_march_workspace_bytes says so (0) for every form of the backward, instead of sizing a workspace whose forward runs and
+    whose backward then fails (advisor, round 5).  And the live-point march with a fine pass keeps ONE stash region for both passes:
+    its workspace is smaller than the dense form's by the coarse pass's stash."""
+    from lush_nerf_amd import lib
+    l = lib.load()
+    mk = lambda R, S, Ni, variant: lib.MarchCfgC(R, S, Ni, 1.0, 1.0, 0, 0, 0.0, 17, 17, variant, 0)
+    for variant in (0, lib.VARIANT_DENSE_BWD):
+        assert l.lush_march_workspace_bytes(ctypes.byref(mk(1 << 20, 64, 64, variant))) == 0, variant      # exactly 2^27 points
+        assert l.lush_march_workspace_bytes(ctypes.byref(mk((1 << 20) - 1, 64, 64, variant))) > 0, variant
+    live, dense = (l.lush_march_workspace_bytes(ctypes.byref(mk(20480, 64, 64, v))) for v in (0, lib.VARIANT_DENSE_BWD))
+    stash_c = l.lush_mlp_stash_bytes(0, 17, 17, 20480 * 64)
+    assert stash_c > 5e9 and 0 < dense - live and abs((dense - live) - (stash_c - 20 * 20480 * 128)) < 0.02 * stash_c, (live, dense, stash_c)
+    off_c, off_f, n = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    cfg = mk(20480, 64, 64, 0)
+    assert l.lush_march_view(ctypes.byref(cfg), lib.VIEW_STASH_COARSE, ctypes.byref(off_c), ctypes.byref(n)) == 0
+    assert l.lush_march_view(ctypes.byref(cfg), lib.VIEW_STASH_FINE, ctypes.byref(off_f), ctypes.byref(n)) == 0
+    assert off_c.value == off_f.value
+
+
 def test_bench_self_launch_builds_the_documented_command(monkeypatch):
     """`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` as a CHILD (never an exec) and exits with its code; the
@@ -489,13 +510,57 @@ def test_live_point_policy_state_machine():
     t.live_share = 0.9
     seq = [t._dense_backward_now() for _ in range(9)]
     assert seq == [True, True, True, True, False, True, True, True, False], seq      # every fourth dense step is a live probe
-    t.live_share = 0.62                                           # between MIN and MAX: stays dense
+    assert (t.LIVE_MIN_SHARE, t.LIVE_MAX_SHARE) == (0.65, 0.70)   # inside the measured break-even band 0.69 .. 0.76 (profiles/r05_live_points.md)
+    t.live_share = 0.67                                           # between MIN and MAX: stays dense
     assert t._dense_backward_now() is True
     t.live_share = 0.5
     assert t._dense_backward_now() is False and t._dense_now is False
-    t.live_share = 0.62                                           # ... and stays live until it exceeds MAX again
+    t.live_share = 0.67                                           # ... and stays live until it exceeds MAX again
     assert t._dense_backward_now() is False
     t.live_policy, t.live_share = "dense", 0.1
     assert t._dense_backward_now() is True
     t.live_policy, t.live_share = "live", 0.99
     assert t._dense_backward_now() is False
+
+
+def test_live_point_policy_reads_a_fixed_lag():
+    """The choice for step n is taken from the counts of step n - LIVE_LAG, whatever has or has not arrived: _live_poll WAITS for that
+    snapshot (event.synchronize) and leaves younger ones alone, so a seeded run makes the same choices every time (advisor, round 5:
+    event.query() made them depend on host / device timing).  Counts a caller accumulated in a buffer of its own start a new series
+    instead of being subtracted from the trainer's."""
+    from lush_nerf_amd.trainer import Trainer
+
+    class Ev:
+        def __init__(self):
+            self.waited = False
+
+        def synchronize(self):
+            self.waited = True
+
+    t = Trainer.__new__(Trainer)
+    t._live_ring = torch.zeros(8, 4, dtype=torch.int64)
+    t._live_snaps, t._live_prev, t._live_prev_acc, t._live_step, t.live_share = [], [0, 0, 0, 0], 111, 0, None
+    evs = []
+
+    def snap(step, counts, acc=111):
+        row = len(evs) % 8
+        t._live_ring[row] = torch.tensor(counts)
+        evs.append(Ev())
+        t._live_snaps.append((evs[-1], row, step, acc))
+
+    snap(1, [40, 100, 10, 100])
+    t._live_step = 2
+    t._live_poll()
+    assert t.live_share is None and not evs[0].waited            # step 1's counts are not step 2's business yet
+    snap(2, [100, 200, 20, 200])
+    t._live_step = 3
+    t._live_poll()
+    assert evs[0].waited and not evs[1].waited and t.live_share == 0.25      # step 3 decides on step 1: (40 + 10) / 200
+    t._live_step = 4
+    t._live_poll()
+    assert evs[1].waited and t.live_share == (60 + 10) / 200
+    snap(4, [5, 10, 5, 10], acc=222)                               # a caller's accumulator: a new series, no negative delta
+    snap(5, [15, 20, 15, 20], acc=222)
+    t._live_step = 7
+    t._live_poll()
+    assert t.live_share == 1.0 and t._live_prev_acc == 222 and not t._live_snaps

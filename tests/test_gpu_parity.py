@@ -567,6 +567,36 @@ if rank == 0:
     ep = float((tr.flat.param - tr1.flat.param).abs().max()) / float(tr1.flat.param.abs().max())
     print(f"2 ranks vs 1 rank on the concatenated batch: gradient {eg:.1e}, parameters {ep:.1e}", flush=True)
     assert eg < 2e-4 and ep < 1e-5, (eg, ep)
+    del tr1, net1
+# Ranks that CHOOSE DIFFERENTLY (the live-point policy decides per rank, from its own live share: trainer.py _dense_backward_now):
+# rank 0 runs the live-point backward, rank 1 the backward over all the points, in the headline mode.  Both forms add into the
+# same flat gradient and every step holds exactly one collective, so: no hang, replicas identical after every step, and the pair
+# still equals one rank on the concatenated batch.
+H16 = ops.Precision(ops.PLANES_F16, ops.PLANES_F16)
+net2 = bench.make_model(bench.model_args(Ni), dev, H16, seed=rank)
+tr2 = Trainer(net2, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni, distributed=True)
+tr2.live_policy = "live" if rank == 0 else "dense"
+start2 = tr2.flat.param.clone()
+tr2.step(batches[rank], 0, draws=draws[rank])
+assert tr2.replica_checksum() == 0.0
+assert (tr2.live_counts()[1] > 0) == (rank == 0), (rank, tr2.live_counts())      # rank 0's march listed live points, rank 1's never did
+if rank == 0:
+    net3 = bench.make_model(bench.model_args(Ni), dev, H16, seed=0)
+    tr3 = Trainer(net3, synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, Ns, Ni, distributed=False)
+    assert torch.equal(tr3.flat.param, start2)
+    tr3.step(cat, 0, draws=dcat)
+    scale = float(tr3.flat.grad.abs().max())
+    eg = float((tr2.flat.grad / 2 - tr3.flat.grad).abs().max()) / scale
+    ep = float((tr2.flat.param - tr3.flat.param).abs().max()) / float(tr3.flat.param.abs().max())
+    print(f"rank 0 live-point / rank 1 dense backward vs 1 rank on the concatenated batch: gradient {eg:.1e}, parameters {ep:.1e}", flush=True)
+    assert eg < 2e-4 and ep < 1e-5, (eg, ep)
+# ... and under step_graph (two eager steps, then each rank captures ITS choice as two graphs around the un-captured collective)
+pix = [{k: torch.from_numpy(v).to(dev) for k, v in synth.ray_batch(N, 200 + 2 * s + rank).items()} for s in range(6)]
+for s in range(6):
+    tr2.step_graph(pix[s], 1 + s)
+    assert tr2.replica_checksum() == 0.0, s
+assert tr2._graph is not None and list(tr2._graph["sub"]) == [rank == 1], (rank, tr2._graph and list(tr2._graph["sub"]))
+assert bool(torch.isfinite(tr2.flat.param).all()) and tr2.faults() == 0
 dist.barrier()
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], f"r{rank}.ok"), "w").write("ok")
