@@ -246,7 +246,13 @@ struct WbPass {
         constexpr int b = it.b, t = it.t, c = b % 2, rbl = b / 2;
         if constexpr (it.kind == WI_L) {
             unsigned a;
+#ifdef LUSH_ABL_LUTFREE      // timing ablation only (wrong masks): every lane of a 16-lane group reads its own bank quad -- what the table reads' bank
+            // conflicts cost.  Entry 17 x (lane & 15) = 0x00, 0x11 .. 0xFF: bank quad lane & 15, and HALF of the decisions set on average,
+            // as in the real masks (entries 0 .. 15 would zero three quarters of dZ: a lighter operand stream, a higher clock)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_and_b32 %0, 15, %0\n\tv_mul_u32_u24 %0, 17, %0" : "=v"(a) : "v"(r.ct.w[b]));
+#else
             asm volatile("v_bfe_u32 %0, %1, %2, 8" : "=v"(a) : "v"(r.ct.w[b]), "n"(8 * t));
+#endif
             r.ct.Y[(2 * b + t) % 2] = *reinterpret_cast<const u32x4*>(rt.lut + a * 16);
         } else if constexpr (it.kind == WI_P || it.kind == WI_ID) {
             constexpr int i = it.i;
