@@ -224,9 +224,8 @@ class Trainer:
             ev, row, _, acc_id = self._live_snaps.pop(0)
             ev.synchronize()
             cur = [int(x) for x in self._live_ring[row].tolist()]
-            if acc_id != self._live_prev_acc:          # another accumulator (a caller's own): its counts start a new series
-                self._live_prev, self._live_prev_acc = cur, acc_id
-                continue
+            if acc_id != self._live_prev_acc:          # another accumulator (a caller's own, e.g. one per step): a series that starts at zero
+                self._live_prev, self._live_prev_acc = [0, 0, 0, 0], acc_id
             d_live = (cur[0] - self._live_prev[0]) + (cur[2] - self._live_prev[2])
             d_all = (cur[1] - self._live_prev[1]) + (cur[3] - self._live_prev[3])
             if d_all > 0:

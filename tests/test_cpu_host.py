@@ -559,8 +559,11 @@ def test_live_point_policy_reads_a_fixed_lag():
     t._live_step = 4
     t._live_poll()
     assert evs[1].waited and t.live_share == (60 + 10) / 200
-    snap(4, [5, 10, 5, 10], acc=222)                               # a caller's accumulator: a new series, no negative delta
+    snap(4, [5, 10, 5, 10], acc=222)                               # a caller's accumulator: a new series from zero, no negative delta
+    t._live_step = 6
+    t._live_poll()
+    assert t.live_share == 0.5 and t._live_prev_acc == 222
     snap(5, [15, 20, 15, 20], acc=222)
     t._live_step = 7
     t._live_poll()
-    assert t.live_share == 1.0 and t._live_prev_acc == 222 and not t._live_snaps
+    assert t.live_share == 1.0 and not t._live_snaps

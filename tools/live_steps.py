@@ -31,15 +31,18 @@ for i in range(5):
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 ev[0].record()
+dense_log = []
 for i in range(N):
     net.hooks.live_acc = accs[i]
     tr.step(batches[(5 + i) % 4], 5 + i)
+    dense_log.append(bool(tr._dense_now))
     ev[i + 1].record()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(N)]
 sh = [(a[0] + a[2]).item() / max((a[1] + a[3]).item(), 1) for a in accs]
 import numpy as np
+print(f"steps the policy ran with the dense backward: {sum(1 for d in dense_log if d)} of {N} (first at step {5 + dense_log.index(True) if True in dense_log else None}; thresholds {tr.LIVE_MAX_SHARE} / {tr.LIVE_MIN_SHARE}, probe every {tr.LIVE_PROBE_EVERY})")
 print(f"variant {variant}, policy {tr.live_policy}: wall {wall / N * 1e3:.3f} ms/step over {N} steps; first 20 steps {sum(ms[:20]) / 20:.3f} ms/step "
       f"(live share {sum(sh[:20]) / 20:.3f})")
 if any(sh):

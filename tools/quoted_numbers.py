@@ -24,11 +24,18 @@ def latest(pattern):
     return fs[-1] if fs else None
 
 
-PIN = None      # --check: the BENCH file the committed status block names (a newer one appears when the driver ends a round)
-
-
 def driver_bench():
-    f = os.path.join(ROOT, PIN) if PIN and os.path.exists(os.path.join(ROOT, PIN)) else latest("BENCH_r[0-9][0-9].json")
+    """The driver's file the status block quotes: the one of the round BEFORE the newest committed profile set (profiles/rNN_* are
+    this round's, so the driver's latest file when they were made is BENCH_r(NN-1).json).  Tied to the profile tag, not to "the
+    newest BENCH file in the directory": the driver adds BENCH_rNN.json after the round and the committed text must not go stale
+    by that -- but a round that commits its rNN profiles while still quoting an older driver file fails the check (round 5 quoted
+    BENCH_r04.json beside r05 profiles)."""
+    tag = profile_tag()
+    f = None
+    if tag:
+        cand = os.path.join(ROOT, "BENCH_r%02d.json" % (int(tag[1:]) - 1))
+        f = cand if os.path.exists(cand) else None
+    f = f or latest("BENCH_r[0-9][0-9].json")
     if not f:
         return None, None
     d = json.load(open(f))
@@ -51,15 +58,22 @@ def blocks():
         evals = drv["config"].get("mlp_evals_per_step", 3932160)
         frac = 6 * 593408 * evals / (drv["ms_per_step"] * 1e-3) / 1e12 / PEAK_TF        # fwd + dX + dW, algorithmic, of the dense bf16 peak
         cpu = drv.get("cpu_baseline") or {}
-        s.append(f"**Headline (the driver's own run, `{name}`): {drv['value']:,.0f} input rays/s, {drv['ms_per_step']:.3f} ms/step** "
-                 f"(BASELINE config 2, 1 x MI355X, mode `{drv['config'].get('planes_fwd', '?')}` / `{drv['config'].get('planes_bwd', '?')}`; "
-                 f"whole step {frac:.2f} of the dense bf16 MFMA peak; dominant kernel `{drv['roofline']['kernel']}` at {drv['roofline']['frac']:.2f} of "
-                 f"the {drv['roofline']['bound'].upper()} roof; CPU oracle on the box's {cpu.get('cores', '?')} host threads {cpu.get('value', 0):.1f} rays/s).")
+        lp, dn = drv.get("live_points"), drv.get("dense_backward")
+        at = f", live share {lp['share']:.2f} in the timed steps" if lp else ""
+        s.append(f"**Headline (the driver's own run, `{name}`): {drv['value']:,.0f} input rays/s, {drv['ms_per_step']:.3f} ms/step at (h,h){at}** "
+                 f"(BASELINE config 2, 1 x MI355X, mode `{drv['config'].get('planes_fwd', '?')}` / `{drv['config'].get('planes_bwd', '?')}`"
+                 + (f"; **with the backward over all the points -- the step whose cost does not depend on the model's state -- {dn['value']:,.0f} rays/s, "
+                    f"{dn['ms_per_step']:.2f} ms**" if dn else "") +
+                 f"; whole step {frac:.2f} of the dense bf16 MFMA peak counting dead points; dominant kernel `{drv['roofline']['kernel']}` at "
+                 f"{drv['roofline']['frac']:.2f} of the {drv['roofline']['bound'].upper()} roof; CPU oracle on the box's {cpu.get('cores', '?')} host threads "
+                 f"{cpu.get('value', 0):.1f} rays/s).")
     if line:
         lp = line.get("live_points")
+        tl = (line.get("extra_configs") or {}).get("trained_like")
         s.append(f"This round's profiled run (`profiles/{tag}_bench_line.json`, another box, inside `rocprofv3`): {line['value']:,.0f} rays/s, "
-                 f"{line['ms_per_step']:.3f} ms/step" + (f" with the live-point backward ({lp['share']:.2f} of the points live in its timed steps; the driver's "
-                 f"file above predates it)" if lp else "") + "; un-profiled runs of the same tree on this round's boxes: DESIGN.md section 5.")
+                 f"{line['ms_per_step']:.3f} ms/step" + (f" at a live share of {lp['share']:.2f}" if lp else "") + "; un-profiled runs of the same tree on "
+                 "this round's boxes, with the `trained_like` workload (a density field shaped like a trained scene's: live share 0.23, 8.7 ms, 468 K rays/s): "
+                 "DESIGN.md section 5.")
     out["status"] = "\n".join(s)
     # ---- kernel table
     if line:
@@ -133,9 +147,6 @@ def rewrite(path, blk, check):
 
 if __name__ == "__main__":
     check = "--check" in sys.argv
-    if check:      # the committed text is checked against the driver file IT names: the driver adds a newer one after the round
-        m = re.search(r"the driver's own run, `(BENCH_r\d\d\.json)`", open(os.path.join(ROOT, "README.md")).read())
-        PIN = m.group(1) if m else None
     blk = blocks()
     stale = [f for f in ("DESIGN.md", "README.md") if rewrite(os.path.join(ROOT, f), blk, check)]
     if check and stale:
