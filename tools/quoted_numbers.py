@@ -58,22 +58,28 @@ def blocks():
         evals = drv["config"].get("mlp_evals_per_step", 3932160)
         frac = 6 * 593408 * evals / (drv["ms_per_step"] * 1e-3) / 1e12 / PEAK_TF        # fwd + dX + dW, algorithmic, of the dense bf16 peak
         cpu = drv.get("cpu_baseline") or {}
-        lp, dn = drv.get("live_points"), drv.get("dense_backward")
-        at = f", live share {lp['share']:.2f} in the timed steps" if lp else ""
-        s.append(f"**Headline (the driver's own run, `{name}`): {drv['value']:,.0f} input rays/s, {drv['ms_per_step']:.3f} ms/step at (h,h){at}** "
-                 f"(BASELINE config 2, 1 x MI355X, mode `{drv['config'].get('planes_fwd', '?')}` / `{drv['config'].get('planes_bwd', '?')}`"
-                 + (f"; **with the backward over all the points -- the step whose cost does not depend on the model's state -- {dn['value']:,.0f} rays/s, "
-                    f"{dn['ms_per_step']:.2f} ms**" if dn else "") +
-                 f"; whole step {frac:.2f} of the dense bf16 MFMA peak counting dead points; dominant kernel `{drv['roofline']['kernel']}` at "
+        s.append(f"**Headline (the driver's own run, `{name}`): {drv['value']:,.0f} input rays/s, {drv['ms_per_step']:.3f} ms/step at (h,h)** "
+                 f"(BASELINE config 2, 1 x MI355X, mode `{drv['config'].get('planes_fwd', '?')}` / `{drv['config'].get('planes_bwd', '?')}`; "
+                 f"whole step {frac:.2f} of the dense bf16 MFMA peak counting dead points; dominant kernel `{drv['roofline']['kernel']}` at "
                  f"{drv['roofline']['frac']:.2f} of the {drv['roofline']['bound'].upper()} roof; CPU oracle on the box's {cpu.get('cores', '?')} host threads "
-                 f"{cpu.get('value', 0):.1f} rays/s).")
+                 f"{cpu.get('value', 0):.1f} rays/s).  The driver's record keeps the contract's keys only; what that figure depends on is in the "
+                 "full line of the same command:")
+    un = os.path.join(ROOT, "profiles", f"{tag}_bench_unprofiled.json") if tag else None
+    if un and os.path.exists(un):
+        u = json.load(open(un))
+        lp, tl, rf = u.get("live_points") or {}, (u.get("extra_configs") or {}).get("trained_like") or {}, u.get("roofline") or {}
+        s.append(f"**This round's un-profiled run of the driver's command (`profiles/{tag}_bench_unprofiled.json`, another box): {u['value']:,.0f} rays/s, "
+                 f"{u['ms_per_step']:.3f} ms/step at (h,h) and a live share of {lp.get('share', 0):.2f}** (the timed steps and their draws are "
+                 f"deterministic: the same share in every run); **with the backward over all the points -- the step whose cost does not depend on the "
+                 f"model's state -- {u.get('value_dense', 0):,.0f} rays/s, {u.get('ms_per_step_dense', 0):.2f} ms**; from a density field shaped like a "
+                 f"trained scene's (`extra_configs.trained_like`, live share {(tl.get('live_points') or {}).get('share', 0):.2f}) "
+                 f"**{tl.get('value', 0):,.0f} rays/s, {tl.get('ms_per_step', 0):.2f} ms**; strict fp32-equivalent mode (2,2) {u.get('value_strict_2_2', 0):,.0f} rays/s; "
+                 f"dominant kernel `{rf.get('kernel')}` at {rf.get('frac', 0):.2f} of the 2.5-PF datasheet peak = {rf.get('frac_of_sustained_peak') or 0:.2f} of the "
+                 f"{rf.get('sustained_peak') or 0:,.0f} TFLOP/s a bare MFMA loop of its shape sustains on this chip (DESIGN.md section 5).")
     if line:
         lp = line.get("live_points")
-        tl = (line.get("extra_configs") or {}).get("trained_like")
-        s.append(f"This round's profiled run (`profiles/{tag}_bench_line.json`, another box, inside `rocprofv3`): {line['value']:,.0f} rays/s, "
-                 f"{line['ms_per_step']:.3f} ms/step" + (f" at a live share of {lp['share']:.2f}" if lp else "") + "; un-profiled runs of the same tree on "
-                 "this round's boxes, with the `trained_like` workload (a density field shaped like a trained scene's: live share 0.23, 8.7 ms, 468 K rays/s): "
-                 "DESIGN.md section 5.")
+        s.append(f"This round's profiled run (`profiles/{tag}_bench_line.json`, `--steps 4`, inside `rocprofv3`): {line['value']:,.0f} rays/s, "
+                 f"{line['ms_per_step']:.3f} ms/step" + (f" at a live share of {lp['share']:.2f}" if lp else "") + ".")
     out["status"] = "\n".join(s)
     # ---- kernel table
     if line:
