@@ -495,6 +495,16 @@ def test_quoted_numbers_match_their_sources():
     (the file the status block names) and the committed profiles/ artefacts: no hand-edited figures."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quoted_numbers.py"), "--check"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+    # ... and the driver file quoted is the one that was the newest when this round's profiles were made: round N's profiles
+    # (profiles/rNN_bench_line.json) go with BENCH_r(N-1).json -- round 5 quoted BENCH_r04.json beside r05 profiles (verdict item 7); a
+    # BENCH_rNN.json the driver adds AFTER the round does not make the committed text stale
+    import glob, re
+    tags = sorted(int(os.path.basename(f)[1:3]) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_line.json")))
+    for doc in ("README.md", "DESIGN.md"):
+        m = re.search(r"the driver's own run, `BENCH_r(\d\d)\.json`", open(os.path.join(ROOT, doc)).read())
+        assert m, doc
+        if os.path.exists(os.path.join(ROOT, "BENCH_r%02d.json" % (tags[-1] - 1))):
+            assert int(m.group(1)) == tags[-1] - 1, (doc, m.group(1), tags[-1])
 
 
 def test_live_point_policy_state_machine():
