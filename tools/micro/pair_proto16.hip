@@ -1,0 +1,407 @@
+// Go / no-go prototype, second shape (round 6; needs a GPU): the row-split wave pairs of pair_proto.hip on v_mfma_f32_16x16x32_f16 -- the
+// shape that sustains 1.14 x the 32x32x16 rate at two waves per SIMD (tools/micro/mfma_shape.hip: 1.77 against 1.56 PFLOP/s on random
+// data) and that ONE wave per SIMD cannot use (8 of its 16 cycles are issue).  Same organisation, same counts per pass and wave -- 32
+// accumulators, 16 weight fragments, 4 ds_write_b128, the B operand of the layer in 128 registers -- other index maps:
+//   * a wave's 64 points are FOUR 16-column blocks, a pass's 32 rows TWO 16-row blocks: every weight fragment (16 rows x 32 k, 1 KiB)
+//     feeds four MFMAs; a position (4 fragments per wave) is 16 MFMAs of 16 cycles;
+//   * K is 8 blocks of 32, consumed in the order 0, 1, 4, 5, 2, 6, 3, 7 (two per position) in every pass; pass q of half hb produces
+//     exactly k-block 4 hb + q of the next layer: lane (n, g) of the two row blocks holds rows 4 g + e, and the weight rows are
+//     permuted at pack time so that they are features 8 g + 4 rbk + e of that k-block: 8 values = one B fragment per column block;
+//   * the biases are the C operand of a pass's first k-step (D != C): 2 ds_read_b128 per pass instead of 8.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/pair_proto16.hip -o build/pair_proto16 && ./build/pair_proto16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include <utility>
+#include <type_traits>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+constexpr int NL = 9, HW = 256, KB = HW / 16, MT = 256, NT = 512;
+#ifndef PP_SLOTS
+#define PP_SLOTS 7
+#endif
+constexpr int SLOTS = PP_SLOTS, POSB = 8192, NPOSL = 16, STREAM = NL * NPOSL;
+// k-blocks of 32: consumed i-th in every pass
+__host__ __device__ constexpr int kord(int i) {
+    constexpr int K[8] = {0, 1, 4, 5, 2, 6, 3, 7};
+    return K[i];
+}
+// exchange-image slot of k-block kb (4 KiB each: four column blocks): k-blocks 3, 7 (written in positions 0, 1 of a layer, read in its
+// position 2) share the slots of k-blocks 0, 4 (written in positions 4, 5, read in positions 13, 14): 6 slots per pair
+__host__ __device__ constexpr int xslot(int kb) { return kb == 3 ? 0 : kb == 7 ? 3 : kb < 3 ? kb : kb - 1; }
+constexpr int XPAIR = 6 * 4096;                        // bytes of one pair's exchange image
+// feature that MFMA row `rho` (0..15) of row block rbk of the pass producing k-block KBn computes: lane (n, g) holds rows 4 g + e
+__host__ __device__ constexpr int feat_of(int KBn, int rbk, int rho) { return 32 * KBn + 8 * (rho >> 2) + 4 * rbk + (rho & 3); }
+
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int B, int E, class F>
+__device__ __forceinline__ void unroll(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        unroll<B + 1, E>(f);
+    }
+}
+
+struct Args {
+    const _Float16* x0;      // [P][256]
+    const char* wstream;     // [NL][pass 4][position 4][half 2][k 4][64 lanes][16 B]
+    const float* bias;       // [NL][256]
+    _Float16* out;           // [P][256] (write_all) or [P][8]
+    int n_tiles, write_all;
+    unsigned long long* stamps;      // [grid][2]: shader cycles (s_memtime) and 100-MHz ticks (s_memrealtime) of the workgroup's run
+};
+
+typedef __attribute__((address_space(3))) char lchar;      // LDS pointers stay 32-bit (a generic pointer costs two registers each)
+typedef __attribute__((address_space(3))) float lfloat;
+struct Ctx {
+    lchar* exch;             // this pair's exchange image
+    const lchar* ring;
+    lfloat* biasl;           // [2][256]
+    const char* wstream;
+    unsigned ring_lds;
+    int w, hb, lane;
+    unsigned rd_off;         // ring byte offset of the position whose fragments are read next (consumed position + 1)
+    unsigned wr_off;         // ring byte offset of the slot the next DMA fills (consumed position, free at its barrier)
+    unsigned fetch_off;      // stream byte offset of the position the next DMA fetches (consumed position + SLOTS, wrapped)
+#ifdef PP_PROF
+    unsigned long long prof[8], tlast;
+#endif
+};
+#ifdef PP_PROF
+#define PSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cx.prof[slot] += t_ - cx.tlast; cx.tlast = t_; } while (0)
+#else
+#define PSTAMP(slot)
+#endif
+
+__device__ __forceinline__ void issue(Ctx& cx) {      // this wave's piece of the next stream position, into the slot just freed
+#ifndef PP_NODMA
+    dma16(cx.wstream + cx.fetch_off, (unsigned)(cx.w * 1024 + cx.lane * 16), __builtin_amdgcn_readfirstlane(cx.ring_lds + cx.wr_off + cx.w * 1024));
+#endif
+    cx.fetch_off = cx.fetch_off + POSB == (unsigned)STREAM * POSB ? 0u : cx.fetch_off + POSB;
+    cx.wr_off = cx.wr_off + POSB == (unsigned)SLOTS * POSB ? 0u : cx.wr_off + POSB;
+}
+
+__device__ __forceinline__ unsigned convert_pair(float x, float y) {
+    f32x2 v = {x, y};
+    f16x2 hv = __builtin_convertvector(v, f16x2);
+    const f16x2 zero = {(_Float16)0, (_Float16)0};
+    hv = __builtin_elementwise_max(hv, zero);
+    return __builtin_bit_cast(unsigned, hv);
+}
+
+// One position: Q = pass, I = position of the pass: 16 MFMAs (fragment j = (k-block kord(2 I + j / 2), row block j % 2) x column block cb),
+// the mid-step behind MFMA 7.  Fillers: gap 0 the refill DMA; positions 0, 1: conversion of the pending set, one pair per gap in gaps
+// 0..7 (column blocks 2 I, 2 I + 1; written in gaps 3 and 7); position 2 gaps 0, 1: the next pass's biases; gaps 8, 10, 12, 15: the
+// fragments of position g + 1; gaps 8..15: operand re-loads.
+// STAG (the younger wave of each SIMD, MI355X_MICROARCH.md "Two waves per SIMD" item 9): the barrier stands at the HEAD of the position
+// instead of behind MFMA 7 -- the wave runs half a position behind its partner, so that its DMA / conversion half coincides with the
+// partner's LDS-read half.  The barrier instances are the same ones (one per position for every wave); what must hold at one -- slot
+// g free, position g + 1 landed, the exchange writes of the half position before last visible -- holds for both phases (header).
+template <int Q, int I, bool FIRST, bool LAST, int STAG>
+__device__ __forceinline__ void position(Ctx& cx, const Args& A, f32x4v (&act)[4][2], f32x4v (&pend)[4][2], f32x4v (&biasr)[2], u32x4 (&B)[4][8], f16x8 (&a)[4],
+                                         u32x4& o, int l, long long pt0, float& bias_next) {
+    const int lane = cx.lane, hb = cx.hb;
+    constexpr int QP = (Q + 3) % 4;
+    const int xsp = QP == 3 ? 3 * hb : 3 * hb + QP;            // xslot(4 hb + QP): slot of the pending set's k-block
+    constexpr bool pend_valid = Q > 0 || !FIRST;
+    constexpr bool pend_out = LAST && Q > 0;
+#ifndef PP_NOCONV
+    constexpr int N_HEAD = (I < 2) ? ((pend_valid && !pend_out) ? 2 : 0) : (I == 2 ? 2 : 0);      // LDS operations of gaps 0..7 of this position
+#else
+    constexpr int N_HEAD = 0;
+#endif
+    // STAG: the LDS operations of gaps 8..15 of the position BEFORE (4 fragment reads, 8 operand re-loads where it had them) may be
+    // outstanding at the barrier; everything older -- its exchange writes -- must be complete
+    constexpr int QB = I == 0 ? (Q + 3) % 4 : Q, IB = (I + 3) % 4;
+#ifndef PP_NORELOAD
+    constexpr bool reload_before = (QB == 3 && IB >= 1 && !(I == 0 && Q == 0 ? false : LAST)) || (QB == 0 && IB == 2 && !FIRST);
+#else
+    constexpr bool reload_before = false;
+#endif
+    constexpr int N_FIRST = STAG ? (Q == 0 && I == 0 ? 0 : 4 + (reload_before ? 8 : 0)) : N_HEAD;
+    const lchar* nxt = nullptr;
+    __builtin_amdgcn_sched_barrier(0);
+    unroll<0, 16>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int M = decltype(mc)::value, j = M / 4, cb = M % 4, kb = kord(2 * I + j / 2), rbk = j % 2;
+        if constexpr (M == (STAG ? 0 : 8)) {
+            PSTAMP(0);
+#ifndef PP_NODMA
+            wait_vm<SLOTS - 2>();
+#endif
+            PSTAMP(1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_FIRST) : "memory");
+            PSTAMP(2);
+#ifndef PP_NOBAR
+            asm volatile("s_barrier" ::: "memory");
+#endif
+            PSTAMP(3);
+            nxt = cx.ring + cx.rd_off + hb * 4096 + lane * 16;
+            cx.rd_off = cx.rd_off + POSB == (unsigned)SLOTS * POSB ? 0u : cx.rd_off + POSB;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (I == 0 && j < 2)      // the pass's first k-step takes the biases as its C operand (the same for every column block)
+            act[cb][rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], __builtin_bit_cast(f16x8, B[cb][kb]), biasr[rbk], 0, 0, 0);
+        else
+            act[cb][rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], __builtin_bit_cast(f16x8, B[cb][kb]), act[cb][rbk], 0, 0, 0);
+        // ---- fillers of gap M ----
+        if constexpr (M == 0) issue(cx);
+        // fragment f of the next position, behind the last MFMA that uses this position's (fragment f feeds MFMAs 4 f .. 4 f + 3)
+        if constexpr (M == 8 || M == 10 || M == 12 || M == 15) {
+            constexpr int f = M == 15 ? 3 : (M - 8) / 2;
+            a[f] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(nxt + f * 1024);
+        }
+#ifndef PP_NOCONV
+        if constexpr (pend_valid && I < 2 && M < 8) {      // pair M % 4 of column block 2 I + M / 4: rows (rbk' = pair / 2, e = 2 (pair % 2) ..)
+            constexpr int cc = 2 * I + M / 4, pr = M % 4;
+            o[pr] = convert_pair(pend[cc][pr / 2][2 * (pr % 2)], pend[cc][pr / 2][2 * (pr % 2) + 1]);
+            if constexpr (pr == 3) {
+                if constexpr (!pend_out) {
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cx.exch + xsp * 4096 + cc * 1024 + lane * 16) = o;
+                } else {
+                    const long long pt = pt0 + 16 * cc + (lane & 15);
+                    const int f0 = 32 * (4 * hb + QP) + 8 * (lane >> 4);
+                    if (A.write_all) *reinterpret_cast<u32x4*>(A.out + pt * HW + f0) = o;
+                    else if (f0 == 0) *reinterpret_cast<u32x4*>(A.out + pt * 8) = o;
+                }
+            }
+        }
+        if constexpr (I == 2 && M < 2) {      // biases of the pass after this one: rows 32 KBn + 8 g + 4 rbk + e, KBn = 4 hb + (Q + 1) % 4
+            const lfloat* bp = cx.biasl + (Q == 3 ? ((l + 1) & 1) * HW : (l & 1) * HW) + 32 * (4 * hb + (Q + 1) % 4) + 8 * (lane >> 4) + 4 * M;
+            biasr[M] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4v*>(bp);
+        }
+#endif
+#ifndef PP_NORELOAD
+        if constexpr (!LAST && Q == 3 && I >= 1 && M >= 8) {         // position I of the last pass re-loads the k-blocks of position I - 1
+            constexpr int kr = kord(2 * (I - 1) + (M - 8) / 4), c2 = M % 4;
+            B[c2][kr] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cx.exch + xslot(kr) * 4096 + c2 * 1024 + lane * 16);
+        }
+        if constexpr (!FIRST && Q == 0 && I == 2 && M >= 8) {         // k-blocks 3, 7: converted in positions 0, 1 of this pass, used in position 3
+            constexpr int kr = kord(6 + (M - 8) / 4), c2 = M % 4;
+            B[c2][kr] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(cx.exch + xslot(kr) * 4096 + c2 * 1024 + lane * 16);
+        }
+#endif
+        if constexpr (!LAST && Q == 1 && I == 0 && M == 13) {
+            if ((int)threadIdx.x < HW) bias_next = A.bias[(l + 1) * HW + threadIdx.x];
+        }
+        if constexpr (!LAST && Q == 1 && I == 1 && M == 13) {
+            if ((int)threadIdx.x < HW) cx.biasl[((l + 1) & 1) * HW + threadIdx.x] = bias_next;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    PSTAMP(4);
+}
+
+template <bool FIRST, bool LAST, int STAG>
+__device__ __forceinline__ void layer(Ctx& cx, const Args& A, f32x4v (&accA)[4][2], f32x4v (&accB)[4][2], f32x4v (&biasr)[2], u32x4 (&B)[4][8], f16x8 (&a)[4], u32x4& o, int l,
+                                      long long pt0, float& bias_next) {
+    unroll<0, 4>([&](auto ic) __attribute__((always_inline)) { position<0, decltype(ic)::value, FIRST, LAST, STAG>(cx, A, accA, accB, biasr, B, a, o, l, pt0, bias_next); });
+    unroll<0, 4>([&](auto ic) __attribute__((always_inline)) { position<1, decltype(ic)::value, FIRST, LAST, STAG>(cx, A, accB, accA, biasr, B, a, o, l, pt0, bias_next); });
+    unroll<0, 4>([&](auto ic) __attribute__((always_inline)) { position<2, decltype(ic)::value, FIRST, LAST, STAG>(cx, A, accA, accB, biasr, B, a, o, l, pt0, bias_next); });
+    unroll<0, 4>([&](auto ic) __attribute__((always_inline)) { position<3, decltype(ic)::value, FIRST, LAST, STAG>(cx, A, accB, accA, biasr, B, a, o, l, pt0, bias_next); });
+}
+
+__global__ __launch_bounds__(NT, 2) void pair_fwd(const Args A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lchar* exch = (lchar*)smem;                          // 4 pairs x 24 KiB
+    lchar* ring = exch + 4 * XPAIR;                      // SLOTS x 8 KiB
+    lfloat* biasl = reinterpret_cast<lfloat*>(ring + SLOTS * POSB);      // 2 x 256 fp32
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = w & 3, hb = w >> 2;                 // (waves w and w + 4 share a SIMD)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    Ctx cx;
+    cx.exch = exch + pair * XPAIR;
+    cx.ring = ring;
+    cx.biasl = biasl;
+    cx.wstream = A.wstream;
+    cx.ring_lds = (unsigned)(size_t)ring;
+    cx.w = w; cx.hb = hb; cx.lane = lane;
+    cx.wr_off = 0; cx.fetch_off = 0; cx.rd_off = 0;
+#ifdef PP_PROF
+    for (int i = 0; i < 8; ++i) cx.prof[i] = 0;
+#endif
+    // the ring is one position ahead of the reads: positions 0 .. SLOTS - 1 in flight, the first read (of position 0) below
+    for (int t = 0; t < SLOTS; ++t) {
+#ifdef PP_NODMA      // timing ablation: the ring is filled ONCE with real weights (random data, as in the product run), never refilled
+        dma16(cx.wstream + cx.fetch_off, (unsigned)(cx.w * 1024 + cx.lane * 16), __builtin_amdgcn_readfirstlane(cx.ring_lds + cx.wr_off + cx.w * 1024));
+#endif
+        issue(cx);
+    }
+#ifdef PP_PRIO      // MI355X_MICROARCH.md, two waves per SIMD, item 4: static priority for the younger half
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    f32x4v accA[4][2], accB[4][2], biasr[2];
+    u32x4 B[4][8];
+    f16x8 a[4];
+    float bias_next = 0.f;
+    bool first_tile = true;
+    auto run = [&](auto stag) __attribute__((always_inline)) {
+    constexpr int STAG = decltype(stag)::value;
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const long long pt0 = (long long)tile * MT + 64 * pair;
+        // tile input: the 32 fragments of this pair's points straight from the [point][256] rows into the operand registers
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) B[c][kb] = *reinterpret_cast<const u32x4*>(A.x0 + (pt0 + 16 * c + (lane & 15)) * HW + 32 * kb + 8 * (lane >> 4));
+        lds_barrier();                                   // (the previous tile's last bias reads are done)
+        if (tid < HW) biasl[tid] = A.bias[tid];
+        wait_vm<0>();
+        lds_barrier();
+        if (first_tile) {                                // fragments of stream position 0 (later tiles: read during the tile before's last position)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(ring + hb * 4096 + j * 1024 + lane * 16);
+            cx.rd_off = POSB;
+            first_tile = false;
+        }
+        {   // biases of (layer 0, pass 0): the C operand of its first k-step
+            typedef const __attribute__((address_space(3))) f32x4v lf4;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) biasr[r] = *reinterpret_cast<lf4*>(biasl + 32 * (4 * hb) + 8 * (lane >> 4) + 4 * r);
+        }
+        u32x4 o;
+#ifdef PP_PROF
+        cx.tlast = __builtin_amdgcn_s_memtime();
+#endif
+        layer<true, false, STAG>(cx, A, accA, accB, biasr, B, a, o, 0, pt0, bias_next);
+#pragma unroll 1
+        for (int l = 1; l < NL - 1; ++l) layer<false, false, STAG>(cx, A, accA, accB, biasr, B, a, o, l, pt0, bias_next);
+        layer<false, true, STAG>(cx, A, accA, accB, biasr, B, a, o, NL - 1, pt0, bias_next);
+        // the last layer's last pass (set B): no MFMAs left to hide behind
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u32x4 ol;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) ol[pr] = convert_pair(accB[c][pr / 2][2 * (pr % 2)], accB[c][pr / 2][2 * (pr % 2) + 1]);
+            const long long pt = pt0 + 16 * c + (lane & 15);
+            const int f0 = 32 * (4 * hb + 3) + 8 * (lane >> 4);
+            if (A.write_all) *reinterpret_cast<u32x4*>(A.out + pt * HW + f0) = ol;
+            else if (f0 == 0) *reinterpret_cast<u32x4*>(A.out + pt * 8) = ol;
+        }
+    }
+    };
+#ifndef PP_STAG
+#define PP_STAG 1
+#endif
+    if (hb == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, PP_STAG>{});      // the younger wave of each SIMD runs half a position behind
+    wait_vm<0>();
+#ifdef PP_PROF
+    if (blockIdx.x == 0 && lane == 0 && A.stamps != nullptr)
+        for (int i = 0; i < 5; ++i) A.stamps[1024 + w * 8 + i] = cx.prof[i];
+#endif
+    if (tid == 0 && A.stamps != nullptr) {
+        A.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        A.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const long long P = argc > 1 ? atoll(argv[1]) : 20480LL * 128;
+    const int n_tiles = (int)(P / MT);
+    std::vector<float> W((size_t)NL * HW * HW), Bv((size_t)NL * HW);
+    unsigned s = 12345;
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : W) v = rnd() * 0.2165f;
+    for (auto& v : Bv) v = rnd() * 0.1f;
+    // stream: [layer][pass q][position i][half hb][fragment j = (k-block kord(2 i + j / 2), row block j % 2)][lane][8]
+    std::vector<_Float16> stream((size_t)NL * 16 * 8 * 64 * 8);
+    for (int l = 0; l < NL; ++l)
+        for (int q = 0; q < 4; ++q)
+            for (int i = 0; i < 4; ++i)
+                for (int hb = 0; hb < 2; ++hb)
+                    for (int j = 0; j < 4; ++j)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int kb = kord(2 * i + j / 2), rbk = j % 2, rho = lane & 15, g = lane >> 4;
+                                const int f = feat_of(4 * hb + q, rbk, rho), k = 32 * kb + 8 * g + e;
+                                stream[(((((size_t)l * 16 + q * 4 + i) * 2 + hb) * 4 + j) * 64 + lane) * 8 + e] = (_Float16)W[((size_t)l * HW + f) * HW + k];
+                            }
+    const int NCHK = 512;                                // points verified on the host (two tiles: the tile boundary is exercised)
+    std::vector<_Float16> x0((size_t)NCHK * HW);
+    for (auto& v : x0) v = (_Float16)(rnd() * 2.f);
+    _Float16 *d_x, *d_out; char* d_w; float* d_b;
+    CK(hipMalloc(&d_x, (size_t)P * HW * 2)); CK(hipMalloc(&d_out, (size_t)P * HW * 2));
+    CK(hipMalloc(&d_w, stream.size() * 2)); CK(hipMalloc(&d_b, Bv.size() * 4));
+    CK(hipMemcpy(d_w, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_b, Bv.data(), Bv.size() * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<_Float16> big((size_t)(1 << 20) * 8);
+        for (auto& v : big) v = (_Float16)(rnd() * 2.f);
+        for (size_t off = 0; off < (size_t)P * HW; off += big.size()) CK(hipMemcpy(d_x + off, big.data(), std::min(big.size(), (size_t)P * HW - off) * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_x, x0.data(), x0.size() * 2, hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const size_t lds = 4 * (size_t)XPAIR + (size_t)SLOTS * POSB + 2 * HW * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (1) correctness on the first NCHK points, every output; ONE workgroup walks both tiles
+    unsigned long long* d_st; CK(hipMalloc(&d_st, (1024 + 64) * 8));
+    Args a{d_x, d_w, d_b, d_out, NCHK / MT, 1, nullptr};
+    hipLaunchKernelGGL(pair_fwd, dim3(1), dim3(NT), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    std::vector<_Float16> got((size_t)NCHK * HW);
+    CK(hipMemcpy(got.data(), d_out, got.size() * 2, hipMemcpyDeviceToHost));
+    double worst = 0, scale = 0;
+    for (int p = 0; p < NCHK; ++p) {
+        std::vector<float> h(HW), n(HW);
+        for (int i = 0; i < HW; ++i) h[i] = (float)x0[(size_t)p * HW + i];
+        for (int l = 0; l < NL; ++l) {
+            for (int o = 0; o < HW; ++o) {
+                float acc = Bv[(size_t)l * HW + o];
+                for (int i = 0; i < HW; ++i) acc += (float)(_Float16)W[((size_t)l * HW + o) * HW + i] * h[i];
+                n[o] = (float)(_Float16)std::max(acc, 0.f);
+            }
+            h = n;
+        }
+        for (int o = 0; o < HW; ++o) { worst = std::max(worst, (double)std::fabs((float)got[(size_t)p * HW + o] - h[o])); scale = std::max(scale, (double)std::fabs(h[o])); }
+    }
+    // (2) time on P points
+    Args b{d_x, d_w, d_b, d_out, n_tiles, 0, d_st};
+    float best = 1e9f, sum = 0;
+    const int reps = 12;
+    for (int r = 0; r < reps + 2; ++r) {
+        hipEventRecord(e0); hipLaunchKernelGGL(pair_fwd, dim3(256), dim3(NT), lds, 0, b); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 2) { best = std::min(best, ms); sum += ms; }
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(512);
+    CK(hipMemcpy(st.data(), d_st, 512 * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, tick = 0;
+    for (int i = 0; i < 256; ++i) { cyc += (double)st[2 * i]; tick += (double)st[2 * i + 1]; }
+    const double npos = (double)((n_tiles + 255) / 256) * NL * NPOSL;
+    printf("in-kernel: %.0f shader cycles per workgroup = %.0f per position (512 = the matrix pipe's 16 MFMAs per SIMD), clock %.0f MHz\n", cyc / 256, cyc / 256 / npos,
+           cyc / tick * 100.0);
+#ifdef PP_PROF
+    {
+        std::vector<unsigned long long> pr(64);
+        CK(hipMemcpy(pr.data(), d_st + 1024, 64 * 8, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; ++w)
+            printf("  wave %d, cycles per position: first half %.0f, vmcnt %.0f, lgkmcnt %.0f, barrier %.0f, second half %.0f\n", w, pr[w * 8] / npos, pr[w * 8 + 1] / npos,
+                   pr[w * 8 + 2] / npos, pr[w * 8 + 3] / npos, pr[w * 8 + 4] / npos);
+    }
+#endif
+    const double fl = 2.0 * NL * HW * HW * (double)P;
+    printf("row-split wave pairs on v_mfma_f32_16x16x32_f16, B operand in registers, 256-point tiles, %d ring slots; 9 x (256 -> 256) fp16 MLP = %.0f MACs per point (NeRF net: 593 408)\n", SLOTS, (double)NL * HW * HW);
+    printf("LDS %3zu KB: max |err| %.3e of %.2f (%s); %lld points: best %.3f ms, mean %.3f ms = %.0f TFLOP/s algorithmic (mean)\n", lds >> 10, worst, scale,
+           worst <= 2e-3 * scale ? "ok" : "WRONG", P, best, sum / reps, fl / (sum / reps) / 1e9);
+    return 0;
+}
