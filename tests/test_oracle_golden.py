@@ -284,3 +284,31 @@ def test_clamped_samples_have_exactly_zero_gradient_rows(dtype):
         assert 0.3 < float(dead.float().mean()) < 0.7
         assert float(raw.grad[dead].abs().max()) == 0.0
         assert bool((raw.grad[~dead].abs().sum(-1) > 0).all())
+
+
+def test_trained_like_field_has_empty_space_and_surfaces():
+    """bench.py's `trained_like` workload (synth.all_weights(trained_like=True)): the density field it starts from has what the
+    initialisation's does not -- empty space that is dead under the unit noise, and surfaces far above it -- and the fine network
+    agrees with the coarse one, so sample_pdf's new samples land where the fine density is: under the oracle, on the synthetic rays,
+    the coarse pass has roughly a tenth of its samples live, the fine pass more (the importance samples), far fewer than the ~0.45
+    of the initialisation."""
+    import torch
+    from lush_nerf_amd import synth
+    from oracle import lush_oracle as O
+    b = {k: torch.from_numpy(v) for k, v in synth.ray_batch(96, 1000, 30, step=0).items()}
+    d = {k: torch.from_numpy(v) for k, v in synth.draws(96, 64, 64, 0, step=0).items()}
+    batch = O.pack_rays(synth.H_DEF, synth.W_DEF, synth.FOCAL_DEF, b["rays"])
+    shares = {}
+    for name, tl in (("init", False), ("trained_like", True)):
+        w = synth.all_weights(30, 0, trained_like=tl)
+        if tl:
+            assert all((w["mlp_fine." + k[11:]] == v).all() for k, v in w.items() if k.startswith("mlp_coarse."))
+        p = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+        with torch.no_grad():
+            ret, _ = O.render_rays(p, batch, 64, retraw=True, perturb=1., N_importance=64, raw_noise_std=1., draws=d)
+        sig = ret["raw"][..., 3]
+        live = ((sig[:, :-1] + d["noise_f"]) > 0).float().mean().item()
+        shares[name] = (live, float((sig > 1.0).float().mean()), float((sig < -1.0).float().mean()))
+    assert 0.35 < shares["init"][0] < 0.6 and shares["init"][1] == 0.0, shares              # sigma ~ 0: the noise alone decides
+    live, above, below = shares["trained_like"]
+    assert 0.15 < live < 0.45 and above > 0.12 and below > 0.5, shares                      # surfaces, and mostly empty space
