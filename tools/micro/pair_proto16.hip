@@ -173,7 +173,11 @@ __device__ __forceinline__ void position(Ctx& cx, const Args& A, f32x4v (&act)[4
             o[pr] = convert_pair(pend[cc][pr / 2][2 * (pr % 2)], pend[cc][pr / 2][2 * (pr % 2) + 1]);
             if constexpr (pr == 3) {
                 if constexpr (!pend_out) {
+#ifndef PP_NOWRITE
                     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(cx.exch + xsp * 4096 + cc * 1024 + lane * 16) = o;
+#else
+                    asm volatile("" ::"v"(o));
+#endif
                 } else {
                     const long long pt = pt0 + 16 * cc + (lane & 15);
                     const int f0 = 32 * (4 * hb + QP) + 8 * (lane >> 4);
