@@ -90,6 +90,10 @@ def save_checkpoint(path: str, model: NeRFAll, global_step: int, trainer=None):
     """Write a file the reference's loader (run_lushnerf.py:373-389) accepts."""
     ck = {"global_step": int(global_step), "network_state_dict": reference_state_dict(model),
           "optimizer_state_dict": adam_state_to_reference(model, trainer)}
+    if trainer is not None and hasattr(trainer, "live_policy_state"):
+        # one key the reference's loader never looks at (it reads the three above): where the live-point policy stands, so that a
+        # resumed run makes the choices the uninterrupted one would have made (trainer.py, "Policy")
+        ck["lush_live_policy"] = trainer.live_policy_state()
     torch.save(ck, path)
 
 
@@ -106,6 +110,8 @@ def load_checkpoint(path: str, model: NeRFAll, trainer=None, map_location="cpu")
     if trainer is not None:
         trainer.global_step = int(ck.get("global_step", 0))       # start = ckpt['global_step'] (run_lushnerf.py:385, 419)
         load_adam_state(trainer, ck.get("optimizer_state_dict") or {"state": {}, "param_groups": []})
+        if hasattr(trainer, "load_live_policy_state"):
+            trainer.load_live_policy_state(ck.get("lush_live_policy"))   # (absent in a reference-written file: the policy starts over)
         trainer.sync_replicas()                                   # a file read on one rank must not fork the replicas
         trainer.invalidate_graph()                                # a captured step's device counters / rate are stale now
     return int(ck.get("global_step", 0))

@@ -252,6 +252,22 @@ class Trainer:
         synchronisation; bench.py reads it around its timed region)."""
         return [0, 0, 0, 0] if self._live_cum is None else [int(x) for x in self._live_cum.tolist()]
 
+    def live_policy_state(self) -> dict:
+        """Where the policy stands (checkpoint.save_checkpoint keeps it; the advisor's note of round 5: none of it was part of any
+        saved state).  The snapshots still in flight belong to steps the file does not contain and are dropped on load."""
+        return {"policy": self.live_policy, "dense_now": bool(self._dense_now), "dense_steps": int(self._dense_steps),
+                "live_share": None if self.live_share is None else float(self.live_share)}
+
+    def load_live_policy_state(self, st: Optional[dict]):
+        self._live_snaps, self._live_step = [], 0
+        if self._live_cum is not None:
+            self._live_prev, self._live_prev_acc = [int(x) for x in self._live_cum.tolist()], self._live_cum.data_ptr()
+        if st is None:
+            self._dense_now, self._dense_steps, self.live_share = False, 0, None
+            return
+        self.live_policy = st.get("policy", self.live_policy)
+        self._dense_now, self._dense_steps, self.live_share = bool(st["dense_now"]), int(st["dense_steps"]), st["live_share"]
+
     def _dense_backward_now(self) -> bool:
         """The policy's choice for the step that starts now."""
         if self.live_policy == "dense":

@@ -348,9 +348,11 @@ def test_checkpoint_interop_with_reference_layout(tmp_path):
     tr.m.copy_(torch.from_numpy(synth.normal((tr.m.numel(),), 1)))
     tr.v.copy_(torch.from_numpy(synth.uniform((tr.v.numel(),), 0, 1, 2)))
     path = str(tmp_path / "000007.tar")
+    tr._dense_now, tr._dense_steps, tr.live_share = True, 5, 0.73          # where the live-point policy stands (round 6: saved too)
     CK.save_checkpoint(path, net, 7, tr)
     ck = torch.load(path, weights_only=False)
-    assert set(ck) == {"global_step", "network_state_dict", "optimizer_state_dict"}
+    # the reference's three keys (all its loader reads, run_lushnerf.py:373-389) + one of ours it never looks at
+    assert set(ck) == {"global_step", "network_state_dict", "optimizer_state_dict", "lush_live_policy"}
     assert list(ck["network_state_dict"].keys()) == [str(k) for k in g["keys"]]
     assert [str(tuple(v.shape)) for v in ck["network_state_dict"].values()] == [str(s) for s in g["shapes"]]
     osd = ck["optimizer_state_dict"]
@@ -373,6 +375,7 @@ def test_checkpoint_interop_with_reference_layout(tmp_path):
     for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
         assert torch.equal(a, b), k
     assert tr2.steps == [7, 5, 0] and tr2.global_step == 7
+    assert (tr2._dense_now, tr2._dense_steps, tr2.live_share, tr2._live_snaps) == (True, 5, 0.73, [])      # a resumed run chooses as the uninterrupted one
     a, b = tr.flat.segments[1]
     assert torch.equal(tr2.m[:b], tr.m[:b]) and torch.equal(tr2.v[:b], tr.v[:b])
     # the reference resumes with the rate its optimizer was saved with (lr of global_step 7), for one step
@@ -382,12 +385,15 @@ def test_checkpoint_interop_with_reference_layout(tmp_path):
     path2 = str(tmp_path / "000009.tar")
     CK.save_checkpoint(path2, net, 9)
     ck2 = torch.load(path2, weights_only=False)
+    assert set(ck2) == {"global_step", "network_state_dict", "optimizer_state_dict"}
     opt2 = torch.optim.Adam([{"params": base}, {"params": noise, "lr": 5e-4}], lr=5e-4)
     opt2.load_state_dict(ck2["optimizer_state_dict"])
     assert len(opt2.state) == 0
     net3, tr3 = _small_trainer(5)
     tr3.m.fill_(1.0); tr3.steps = [4, 4, 0]
+    tr3._dense_now, tr3.live_share = True, 0.9
     assert CK.load_checkpoint(path2, net3, tr3) == 9
+    assert (tr3._dense_now, tr3.live_share) == (False, None)                   # a file without the key: the policy starts over
     assert tr3.global_step == 9 and tr3.steps == [0, 0, 0] and float(tr3.m.abs().max()) == 0.0
 
 
