@@ -619,8 +619,10 @@ def test_trainer_two_ranks(diag, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_two_ranks_rehearsal(diag, tmp_path):
-    """bench.py's multi-rank control flow with real kernels on the box we have: `--gpus 2` starts two ranks itself; with
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_two_ranks_rehearsal(diag, tmp_path, ranks):
+    """bench.py's multi-rank control flow with real kernels on the box we have: `--gpus 2` (and 4: the driver's scaling run goes 1, 2,
+    4, 8) starts the ranks itself; with
     `--rehearse-on-one-gpu` both use the one card and the collectives go over gloo.  What it pins: no rank-dependent loop count
     in front of a collective (every step of every pass holds one: warm-up, timed region, kernel-group pass, sustained cycles,
     the dense-backward comparison, the other modes), ONE JSON line from rank 0 with n_gpus = 2 and the whole-job value, the
@@ -630,17 +632,18 @@ def test_bench_two_ranks_rehearsal(diag, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "2",
-                        "--n-rand", "1024", "--no-cpu-baseline", "--also=2,2", "--sustained", "0.3"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "2",
+                        "--n-rand", "1024", "--no-cpu-baseline", "--also=2,2" if ranks == 2 else "--also=", "--sustained", "0.3"], capture_output=True, text=True,
                        timeout=420, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "rehearsal" in d and "n1_only" in d
-    assert d["config"]["parallelism"] == "dp2" and d["live_points"]["share"] > 0.2
-    assert d["dense_backward"]["ms_per_step"] > 0 and d["sustained"]["steps"] % 3 == 0 and "2,2" in d["modes"]
-    print(f"bench.py --gpus 2 rehearsed on one GPU: {d['ms_per_step']} ms/step of two time-shared ranks, all-reduce {d['allreduce_ms']} ms over gloo")
+    assert d["n_gpus"] == ranks and d["steps"] == 3 and d["value"] > 0 and "rehearsal" in d and "n1_only" in d
+    assert d["config"]["parallelism"] == f"dp{ranks}" and d["live_points"]["share"] > 0.2
+    assert d["dense_backward"]["ms_per_step"] > 0 and d["sustained"]["steps"] % 3 == 0 and (ranks != 2 or "2,2" in d["modes"])
+    assert d["value_dense"] == d["dense_backward"]["value"] and d["value_at"]["live_share"] == d["live_points"]["share"]
+    print(f"bench.py --gpus {ranks} rehearsed on one GPU: {d['ms_per_step']} ms/step of {ranks} time-shared ranks, all-reduce {d['allreduce_ms']} ms over gloo")
 
 
 @pytest.mark.parametrize("kernel_on", [True, False])
