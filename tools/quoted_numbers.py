@@ -81,6 +81,31 @@ def blocks():
         s.append(f"This round's profiled run (`profiles/{tag}_bench_line.json`, `--steps 4`, inside `rocprofv3`): {line['value']:,.0f} rays/s, "
                  f"{line['ms_per_step']:.3f} ms/step" + (f" at a live share of {lp['share']:.2f}" if lp else "") + ".")
     out["status"] = "\n".join(s)
+    # ---- every configuration of this round's un-profiled line (README)
+    if un and os.path.exists(un):
+        u = json.load(open(un))
+        ex = u.get("extra_configs") or {}
+        rows = ["| workload (1 x MI355X, mode (h,h) unless said) | rays/s | ms/step | note |", "|---|---|---|---|"]
+        rows.append(f"| BASELINE config 2 (N_rand 4096, 64 + 64, blur kernel on): `value` | {u['value']:,.0f} | {u['ms_per_step']:.3f} | live share {(u.get('live_points') or {}).get('share', 0):.2f} (a freshly initialised model) |")
+        if u.get("value_dense"):
+            rows.append(f"| ... backward over all the points (`value_dense`) | {u['value_dense']:,.0f} | {u['ms_per_step_dense']:.2f} | independent of the model's state |")
+        tl = ex.get("trained_like")
+        if tl:
+            rows.append(f"| ... from a trained-like density field (`extra_configs.trained_like`) | {tl['value']:,.0f} | {tl['ms_per_step']:.3f} | live share {(tl.get('live_points') or {}).get('share', 0):.2f}; {tl.get('backward', '')} |")
+        for m, lab in (("2,2", "strict fp32-equivalent mode (2,2)"), ("2,h", "mode (2,h)"), ("2,1", "mode (2,1)")):
+            if m in (u.get("modes") or {}):
+                rows.append(f"| ... {lab} | {u['modes'][m]['value']:,.0f} | {u['modes'][m]['ms_per_step']:.2f} | |")
+        for c, lab in (("C1", "BASELINE config 1 (N_rand 256, 32 + 0, naive), replayed HIP graph"), ("C3", "BASELINE config 3 (N_rand 8192, 64 + 64)"),
+                       ("C5", "BASELINE config 5, per GPU (N_rand 16384, 128 + 128)")):
+            if c in ex:
+                rows.append(f"| {lab} | {ex[c]['value']:,.0f} | {ex[c]['ms_per_step']:.3f} | |")
+        if "eval" in ex:
+            rows.append(f"| eval path, forward only (640 x 1120 rays per pose) | {ex['eval']['value']:,.0f} | {ex['eval']['s_per_pose'] * 1e3:.1f} per pose | |")
+        cb = u.get("cpu_baseline") or {}
+        if cb:
+            rows.append(f"| CPU oracle on the box's {cb.get('cores')} host threads (N_rand 512, kernel on) | {cb.get('value', 0):.1f} | {cb.get('s_per_step', 0) * 1e3:,.0f} | `cpu_baseline` (kind: port); GPU / CPU = {u.get('gpu_over_cpu', 0):,.0f} |")
+        rows.append(f"\n(`profiles/{tag}_bench_unprofiled.json`: one `python bench.py --steps 20 --warmup 5` on one box; boxes differ by 2 - 4 %.)")
+        out["configs"] = "\n".join(rows)
     # ---- kernel table
     if line:
         rows = ["| group | launches / step | avg launch ms (HIP events) | algorithmic TFLOP/s (of 2.5 PF) | algorithmic HBM GB/s (of 8 TB/s) | PMC HBM GB / step (algorithmic) |",
