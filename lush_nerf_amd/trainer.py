@@ -265,7 +265,7 @@ class Trainer:
         if st is None:
             self._dense_now, self._dense_steps, self.live_share = False, 0, None
             return
-        self.live_policy = st.get("policy", self.live_policy)
+        # (`policy` in the file is a record of how the saved run was set up; the resuming caller's own live_policy stays)
         self._dense_now, self._dense_steps, self.live_share = bool(st["dense_now"]), int(st["dense_steps"]), st["live_share"]
 
     def _dense_backward_now(self) -> bool:
