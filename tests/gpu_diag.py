@@ -551,7 +551,7 @@ def t_march_e2e():
             print(f"{'ok  ' if ok else 'FAIL'} {'e2e ' + name + ' z_std (rays beyond 2e-3, of ' + str(dz.size) + ')':58s} n={nbad} allowed={allowed}", flush=True)
 
 
-def _nerf_all(Ni=64, seed=0, sharp=True, precision=None, rbk_scale=1.0, train=True):
+def _nerf_all(Ni=64, seed=0, sharp=True, precision=None, rbk_scale=1.0, train=True, trained_like=False):
     from lush_nerf_amd import model as M
     import argparse
     args = argparse.Namespace(blur_model_type="dpnerf", multires=10, multires_views=4, i_embed=0, use_viewdirs=True,
@@ -560,7 +560,7 @@ def _nerf_all(Ni=64, seed=0, sharp=True, precision=None, rbk_scale=1.0, train=Tr
                               render_rmnearplane=80)
     net = M.NeRFAll(args, M.RBK(util.NUM_IMG, 64, 4, 64, 1, 32, 1, 32, 1, 32, 3, 3, [4], True, 0.1, 4),
                     precision=precision or ops.Precision(*E2E_PLANES))
-    M.load_reference_weights(net, synth.all_weights(util.NUM_IMG, seed, sharp=sharp, rbk_scale=rbk_scale))
+    M.load_reference_weights(net, synth.all_weights(util.NUM_IMG, seed, sharp=sharp, rbk_scale=rbk_scale, trained_like=trained_like))
     return net.to(dev).train(train)
 
 
@@ -812,6 +812,14 @@ MASKED_CAP_BY_TAG = {"bench regime": 2.5e-2, "bench regime 128+128": 1e-2, "c1 s
                      "consistency": 1e-2, "train train_naive_sharp": 3e-2, "train train_kernel_sharp": 3e-2,
                      "train train_kernel_default": 6.5e-2}
 MASKED_GATE = MASKED_FLOOR      # (name kept for the sections that only need the floor)
+# Round 6: the step from the trained-like density field (synth.all_weights(trained_like=True)).  Behind a x3000 density head the
+# derivative with respect to the RAY GEOMETRY is a cancelling sum over sharp surfaces: the fp32 oracle itself is 0.6 .. 1.5 % from
+# float64 on d(rays) and on the blur-kernel network's tensors (the sharp reference fixtures: 1e-4 .. 1e-3), and one fp16 plane in
+# the forward sits at 13 .. 21 % there (16 x fp32's miss; 1 - cos 1.2e-2), two bf16 planes at 1.7 % (1 - cos 5.8e-5); the 8 x 256
+# networks' own tensors: median 9e-3 / 7e-5.  Gates of that regime = 2 .. 3 x what was measured (profiles/r06_trained_like_grads.md).
+MASKED_CAP_BY_TAG["trained-like regime"] = 5e-1
+COS_GATE_BY_TAG = {"trained-like regime": {(ops.PLANES_F16, ops.PLANES_F16): 3e-2, (2, ops.PLANES_F16): 3e-3, (2, 2): 2e-4}}
+WELL_FLOOR_BY_TAG = {"trained-like regime": {(ops.PLANES_F16, ops.PLANES_F16): 1.2e-2}}
 
 
 def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
@@ -849,7 +857,7 @@ def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
         a, b = torch.as_tensor(a).detach().double().cpu().reshape(-1), torch.as_tensor(b).detach().double().cpu().reshape(-1)
         na, nb = float(a.norm()), float(b.norm())
         return 1.0 if na == 0.0 and nb == 0.0 else float(a @ b) / max(na * nb, 1e-300)
-    cos_gate = 1e-6 if tuple(E2E_PLANES) in ((2, 2), (3, 3)) else 1e-3
+    cos_gate = COS_GATE_BY_TAG.get(tag, {}).get(tuple(E2E_PLANES), 1e-6 if tuple(E2E_PLANES) in ((2, 2), (3, 3)) else 1e-3)
     worst_cos, worst_k, worst_f32 = 0.0, "", 0.0
     for k, got, t64, t32 in items:
         miss, miss32 = 1.0 - cosine(got, t64), 1.0 - cosine(t32, t64)
@@ -863,6 +871,7 @@ def masked_grad_check(tag, run_oracle, gpu_grads, gpu_extra, keep, prec):
     wc = [(util.relerr(got, t64), k) for k, got, t64, t32 in items if util.relerr(t32, t64) < 1e-5]
     if wc:
         e, k = max(wc)
+        floor = WELL_FLOOR_BY_TAG.get(tag, {}).get(tuple(E2E_PLANES), floor)
         RESULTS.append((f"{tag} MASKED worst well-conditioned tensor [{k}]", e, floor, bool(e <= floor)))
         print(f"{'ok  ' if e <= floor else 'FAIL'} {tag} worst error among the {len(wc)} well-conditioned tensors: {k} {e:.2e} (floor {floor:.0e})")
     flip_gate = 2e-4 if E2E_PLANES[0] in (2, 3) else 5e-3
@@ -998,7 +1007,7 @@ def t_train_e2e():
             rep(f"train {name} grad_rays vs fixture", rays.grad, g["grad_rays"], sec)
 
 
-def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
+def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64, trained_like=False, min_tiles=2048):
     """The regime bench.py runs the chain kernels in: MANY 128-point tiles per persistent workgroup, so the weight stream
     wraps into the next tile (mlp_chain_*_half_kernel: min(n_tiles, 2 n_cu) workgroups; the 512-register kernels: n_cu)
     and dw_group_kernel walks many slices.  N_rand 512 with the blur kernel on = 2 560 marched rays = 327 680 fine points
@@ -1008,10 +1017,14 @@ def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
     (models/lushnerf.py:481-583, 630-654; run_lushnerf.py:652-661).
     (n, Ns, Ni) = (256, 128, 128) is BASELINE config 5's sampling at the same point count (1 280 marched rays x 256 =
     327 680 fine points): composite_*_kernel<4>, sample_merge at 128 + 128, ray_grad_reduce over 256 samples and the
-    chain / weight-gradient kernels with 256 consecutive points per ray."""
+    chain / weight-gradient kernels with 256 consecutive points per ray.
+    trained_like (round 6): the same step from synth.all_weights(trained_like=True) -- the density field bench.py's `trained_like`
+    workload starts from (empty space and surfaces behind a x3000 density head; calibrated for seed 0) -- instead of the sharp
+    fixture field, in which the first sample of every ray is opaque."""
     prec = ops.Precision(*E2E_PLANES)
     rbk_scale = 2.0e4
-    net = _nerf_all(Ni, seed, sharp=True, precision=prec, rbk_scale=rbk_scale)
+    sharp = not trained_like
+    net = _nerf_all(Ni, seed, sharp=sharp, precision=prec, rbk_scale=rbk_scale, trained_like=trained_like)
     b = batch_of(n, seed)
     K = [[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]]
     cpu_draws = util.tdraws(n * 5, Ns, Ni, seed)
@@ -1044,14 +1057,16 @@ def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
     RESULTS.append(("bench regime fault word", float(fw), 0, fw == 0))
     tiles = keep["P_f"] // 128
     info = f"{keep['P_f']} fine points = {tiles} tiles"
-    RESULTS.append((f"bench regime is multi-tile ({info})", float(tiles), 2048., tiles >= 2048))
+    RESULTS.append((f"bench regime is multi-tile ({info})", float(tiles), float(min_tiles), tiles >= min_tiles))
+    if live_frac is None and trained_like and "live_share" in keep:
+        live_frac = keep["live_share"]
     # (1) outputs against the plain fp32 oracle (its own ReLU decisions)
     with torch.no_grad():
-        p = util.params(seed, sharp=True, rbk_scale=rbk_scale)
+        p = util.params(seed, sharp=sharp, rbk_scale=rbk_scale, trained_like=trained_like)
         ref = O.forward_train(p, H, W, F, b["rays"], b["images_idx"], Ns, Ni, force_naive=False, allkernel=True,
                               kernel_pixel=b["fq_mask"], draws=cpu_draws)
         ref_loss = O.train_loss(ref[0], ref[1], b["target"])
-    tagname = "bench regime" if (Ns, Ni) == (64, 64) else f"bench regime {Ns}+{Ni}"
+    tagname = "trained-like regime" if trained_like else ("bench regime" if (Ns, Ni) == (64, 64) else f"bench regime {Ns}+{Ni}")
     rep("bench regime rgb_blur", out[0], ref[0], 1e-4)
     rep("bench regime rgb0_blur", out[1], ref[1], 1e-4)
     rep("bench regime noise", out[3], ref[3], 1e-4)
@@ -1059,7 +1074,7 @@ def t_train_bench_regime(n=512, seed=21, Ns=64, Ni=64):
     rep("bench regime loss", loss.reshape(1), ref_loss.reshape(1), 1e-4)
     # (2) gradients: the masked float64 / fp32 oracle pair
     def run_oracle(dt):
-        pp = {k: v.to(dt).requires_grad_(True) for k, v in util.params(seed, sharp=True, rbk_scale=rbk_scale).items()}
+        pp = {k: v.to(dt).requires_grad_(True) for k, v in util.params(seed, sharp=sharp, rbk_scale=rbk_scale, trained_like=trained_like).items()}
         rays_c = b["rays"].to(dt).clone().requires_grad_(True)
         r = O.forward_train(pp, H, W, F, rays_c, b["images_idx"], Ns, Ni, force_naive=False, allkernel=True,
                             kernel_pixel=b["fq_mask"], draws={k: v.to(dt) for k, v in cpu_draws.items()})

@@ -232,6 +232,23 @@ def test_bench_regime_against_the_oracle(diag, planes, sampling, monkeypatch):
     assert diag.RESULTS and not bad, bad[:8]
 
 
+@pytest.mark.parametrize("planes", ["h,h", "2,h"])
+def test_trained_like_regime_against_the_oracle(diag, planes, monkeypatch):
+    """Round 6: a training step from the density field bench.py's `trained_like` workload starts from (empty space and surfaces behind a
+    x3000 density head; N_rand 128 with the blur kernel on = 81 920 fine points) in the headline mode and in the mode a user takes
+    for accurate gradients: outputs at 1e-4 of the fp32 oracle (measured 8.5e-5 / 5.9e-5: sample_pdf's knot discontinuities show at
+    this sharpness in every mode), every gradient tensor against the float64 oracle run with the GPU's ReLU decisions.  The gates are
+    that regime's own (gpu_diag COS_GATE_BY_TAG / WELL_FLOOR_BY_TAG / MASKED_CAP_BY_TAG, 2 - 3 x what was measured): the derivative
+    with respect to the ray geometry through a sharp field is a cancelling sum on which the fp32 oracle itself is 0.6 - 1.5 % from
+    float64; (h,h) sits at 10 - 21 % on the blur-kernel network's tensors and d(rays) (1 - cos 1.2e-2), 7e-3 (median) on the 8 x 256
+    networks'; (2,h) at 1 - 1.7 % and 6e-4 (profiles/r06_trained_like_grads.md)."""
+    monkeypatch.setattr(diag, "E2E_PLANES", diag.ops.parse_planes(planes))
+    diag.RESULTS.clear()
+    diag.t_train_bench_regime(n=128, seed=0, trained_like=True, min_tiles=512)
+    bad = [(n, e, t) for n, e, t, ok in diag.RESULTS if not ok]
+    assert diag.RESULTS and not bad, bad[:8]
+
+
 def _canon(net):
     out = {}
     for k, v in net.state_dict().items():

@@ -14,8 +14,8 @@ def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
-def params(seed, sharp=False, rbk_scale=1.0, requires_grad=False, device="cpu"):
-    w = synth.all_weights(NUM_IMG, seed, sharp=sharp, rbk_scale=rbk_scale)
+def params(seed, sharp=False, rbk_scale=1.0, requires_grad=False, device="cpu", trained_like=False):
+    w = synth.all_weights(NUM_IMG, seed, sharp=sharp, rbk_scale=rbk_scale, trained_like=trained_like)
     return {k: torch.from_numpy(v.copy()).to(device).requires_grad_(requires_grad) for k, v in w.items()}
 
 
